@@ -1,0 +1,178 @@
+/*
+ * remap_hip.h -- C ABI of libremap_hip.so, the MI355X (gfx950) weight-
+ * application engine behind pyremap's Remapper.remap_numpy()/ncremap().
+ *
+ * The reference (MPAS-Dev/pyremap v2.4.0) is pure Python and has no FFI
+ * boundary of its own; the seam this library replaces is the arithmetic of
+ *
+ *   pyremap/remapper/remap_numpy.py:134-137   COO triplets -> scipy CSR
+ *                                             -> remap_csr_from_coo()
+ *   pyremap/remapper/remap_numpy.py:258-278   masked / unmasked SpMM,
+ *                                             normalisation and masking
+ *                                             -> remap_apply_f64()
+ *   pyremap/remapper/remap_numpy.py:254-256,  permute/flatten and
+ *                                   280-295   unflatten/unpermute: absorbed
+ *                                             into the batch/row strides of
+ *                                             remap_apply_args (no copies)
+ *
+ * Conventions: extern "C"; plain pointers and sizes only; every pointer
+ * marked (device) is an address in the current HIP device's memory (e.g.
+ * torch.Tensor.data_ptr()); all launches are asynchronous on the caller's
+ * hipStream_t (passed as void*; NULL = the null stream); nothing is allocated,
+ * freed or synchronised inside the apply call, so it is graph-capturable.
+ * Return value: REMAP_OK (0) or a negative REMAP_ERR_*; the message of the
+ * last failure on the calling thread is available from remap_last_error().
+ *
+ * The reference-side binding (ctypes) is in pyremap_amd/engine.py; the stub a
+ * pyremap maintainer would add is shown in INTEGRATION.md.
+ */
+#ifndef REMAP_HIP_H
+#define REMAP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define REMAP_ABI_VERSION 1
+
+enum {
+    REMAP_OK = 0,
+    REMAP_ERR_ARG = -1,         /* bad argument (NULL, negative size, ...)  */
+    REMAP_ERR_UNSUPPORTED = -2, /* valid request this build cannot serve    */
+    REMAP_ERR_HIP = -3,         /* a HIP runtime call or launch failed      */
+    REMAP_ERR_WORKSPACE = -4    /* workspace too small                      */
+};
+
+/* element type of the source field X (the output is always float64, as in the
+ * reference: S is float64 and scipy upcasts, remap_numpy.py:264-268) */
+enum { REMAP_DTYPE_F64 = 0, REMAP_DTYPE_F32 = 1 };
+
+/* what is computed after num = A.X */
+enum {
+    /* Y = A.X, nothing else (the bare `matrix.dot`, remap_numpy.py:268) */
+    REMAP_MODE_RAW = 0,
+    /* unmasked branch, remap_numpy.py:268-278: den = frac_b[row];
+     * Y = den > 0 ? num / den : NaN.  NaNs in X propagate. */
+    REMAP_MODE_FRACB = 1,
+    /* masked branch, remap_numpy.py:262-266,277-278, with the mask taken
+     * from NaN in X (as _remap_data_array builds it, :201-204):
+     * num = A.(X, NaN->+0), den = A.(!isnan X); Y = den > threshold ?
+     * num / den : NaN. */
+    REMAP_MODE_MASKED = 2
+};
+
+enum {
+    /* accumulate with fused multiply-add.  Default (flag clear) is a separate
+     * multiply and add in CSR order, which is bit-identical to scipy's
+     * csr_matvecs; FMA is within 1 ulp per term of it, not identical. */
+    REMAP_FLAG_FMA = 1u << 0,
+    /* plain (cached) stores for Y instead of non-temporal ones */
+    REMAP_FLAG_CACHED_STORE = 1u << 1
+};
+
+/* CSR weight matrix of shape (n_rows, n_cols) = (n_b, n_a), or a row shard of
+ * it (rows [r0, r1) of the full matrix with rowptr rebased to 0). */
+typedef struct remap_csr {
+    int64_t n_rows;
+    int64_t n_cols;
+    int64_t nnz;
+    const int64_t *rowptr; /* (device) n_rows + 1                            */
+    const int32_t *col;    /* (device) nnz, ascending within a row, 0-based  */
+    const double *val;     /* (device) nnz                                   */
+} remap_csr;
+
+/*
+ * One application of the weights to a batch of fields.
+ *
+ * The flattened (n_a, K) matrix of the reference (remap_numpy.py:254-256) is
+ * addressed in place: K = n_batch * k_inner and flat column kf = b * k_inner
+ * + k lives at X[b * x_batch_stride + a * x_row_stride + k] (strides in
+ * elements, the k index contiguous).  A field laid out (n_a, K) has
+ * n_batch = 1; an MPAS field (Time, nCells, nVertLevels) has n_batch = Time,
+ * k_inner = nVertLevels, x_row_stride = nVertLevels, x_batch_stride =
+ * nCells * nVertLevels.  Y is addressed the same way with its own strides, so
+ * the output lands directly in the reference's final axis order
+ * (remap_numpy.py:280-295).
+ */
+typedef struct remap_apply_args {
+    remap_csr A;
+    int64_t row_begin;      /* rows [row_begin, row_end) of A are computed;  */
+    int64_t row_end;        /* Y / frac_b / mask_out are indexed by row      */
+    const void *X;          /* (device) source field                         */
+    int32_t x_dtype;        /* REMAP_DTYPE_*                                 */
+    int32_t mode;           /* REMAP_MODE_*                                  */
+    int64_t x_row_stride;
+    int64_t x_batch_stride;
+    double *Y;              /* (device) destination field, float64           */
+    int64_t y_row_stride;
+    int64_t y_batch_stride;
+    int64_t n_batch;
+    int64_t k_inner;
+    const double *frac_b;   /* (device) n_rows; REMAP_MODE_FRACB only        */
+    double threshold;       /* REMAP_MODE_MASKED only                        */
+    uint8_t *mask_out;      /* (device) optional, addressed like Y; 1 where
+                               the reference's result is masked (~ok)        */
+    uint32_t flags;         /* REMAP_FLAG_*                                  */
+    /* launch tuning, 0 = choose automatically:
+     * tune[0] kernel family   1 = wave per row (lanes across K),
+     *                         2 = lane per (row, k) (small K)
+     * tune[1] doubles per lane per tile (1 or 2)
+     * tune[2] K tiles per wave (1, 2 or 4)
+     * tune[3] consecutive rows per wave
+     * tune[4] block -> work map: 1 = as dispatched, 2 = XCD-contiguous
+     * tune[5] nnz unroll (loads in flight per lane)
+     * tune[6..7] reserved */
+    int32_t tune[8];
+} remap_apply_args;
+
+/* ABI / build information */
+int remap_abi_version(void);
+const char *remap_arch(void);       /* "gfx950" */
+const char *remap_last_error(void); /* thread-local, never NULL */
+
+/* Number of visible HIP devices, or a negative REMAP_ERR_HIP. */
+int remap_device_count(void);
+
+/*
+ * Apply the weights (asynchronous on `stream`).  Replaces
+ * remap_numpy.py:258-278 (and, through the strides, :254-256 and :280-295).
+ */
+int remap_apply_f64(const remap_apply_args *args, void *stream);
+
+/*
+ * COO -> CSR on the device: scipy's `csr_matrix((S, (row, col)))` of
+ * remap_numpy.py:134-137.  Stable sort by (row, col), duplicates summed in
+ * input order, explicit zeros kept.  `index_base` is subtracted from row and
+ * col (1 for a SCRIP/ESMF mapping file).
+ *
+ *   rowptr_out (device) n_rows + 1;  col_out / val_out (device) nnz entries
+ *   (only the first *nnz_out are meaningful);  nnz_out (device) one int64;
+ *   bad_out (device) one int64: number of triplets whose row or col is out
+ *   of range (the caller must treat non-zero as an error).
+ *
+ * All outputs are written asynchronously on `stream`.  Query the workspace
+ * size first; the workspace is plain device memory owned by the caller.
+ */
+int remap_csr_from_coo_workspace(int64_t nnz, int64_t n_rows,
+                                 size_t *bytes_out);
+int remap_csr_from_coo(int64_t n_rows, int64_t n_cols, int64_t nnz,
+                       const int32_t *row, const int32_t *col,
+                       const double *S, int32_t index_base,
+                       int64_t *rowptr_out, int32_t *col_out,
+                       double *val_out, int64_t *nnz_out, int64_t *bad_out,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Device-to-device streaming copy of `bytes` (16 B per lane, grid-stride):
+ * the box's achievable HBM ceiling, reported beside the roofline numbers.
+ */
+int remap_stream_copy(void *dst, const void *src, size_t bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* REMAP_HIP_H */

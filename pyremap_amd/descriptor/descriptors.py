@@ -1,0 +1,305 @@
+"""
+Descriptor classes with the public names of ``pyremap.descriptor``.
+
+Each class fills ``mesh_name, regional, dims, dim_sizes, coords`` exactly as
+its reference counterpart does (file:line cited per class); ``coords`` is a
+dict in ``DataArray.from_dict`` form, which is what
+``_remap_data_array`` merges into every remapped variable
+(``remap_numpy.py:198``).
+"""
+import sys
+
+import numpy as np
+
+
+def _history():
+    return ' '.join(sys.argv[:])
+
+
+def _round_res(res):
+    """Grid-name resolution rounding (``descriptor/utility.py:336-339``)."""
+    return f'{np.round(res * 1000.0) / 1000.0}'
+
+
+class MeshDescriptor:
+    """Base attributes (``descriptor/mesh_descriptor.py:49-69``)."""
+
+    def __init__(self, mesh_name=None, regional=None):
+        self.mesh_name = mesh_name
+        self.regional = regional
+        self.dims = None
+        self.dim_sizes = None
+        self.coords = None
+        self.format = 'NETCDF4'
+        self.engine = None
+        self.logger = None
+
+    def to_scrip(self, scrip_filename, expand_dist=None, expand_factor=None):
+        raise NotImplementedError(
+            'SCRIP files feed ESMF/MOAB weight generation, which is outside '
+            'the scope of pyremap_amd (it applies existing weights)')
+
+    def mesh_name_from_attr(self, ds):
+        """``mesh_descriptor.py:114-128``."""
+        if self.mesh_name is None:
+            for key in ('meshName', 'mesh_name'):
+                if key in ds.attrs:
+                    self.mesh_name = ds.attrs[key]
+                    break
+
+
+def _lon_is_periodic(lon, full_circle):
+    """``lat_lon_grid_descriptor.py:356-372``."""
+    dlon = lon[1] - lon[0]
+    span = lon[-1] - lon[0]
+    tol = 1e-3 * abs(dlon)
+    return bool(abs(abs(span) + abs(dlon) - full_circle) <= tol or
+                abs(abs(span) - full_circle) <= tol)
+
+
+class LatLonGridDescriptor(MeshDescriptor):
+    """
+    A 1-D lat x 1-D lon grid (``lat_lon_grid_descriptor.py:68``): dims
+    ``[lat, lon]``, coords at cell centres, default name like
+    ``0.5x0.5degree`` (:292-353).
+    """
+
+    def __init__(self, mesh_name=None, regional=None):
+        super().__init__(mesh_name=mesh_name, regional=regional)
+        self.lat = None
+        self.lon = None
+        self.lat_corner = None
+        self.lon_corner = None
+        self.units = None
+        self.history = None
+
+    @classmethod
+    def create(cls, lat_corner, lon_corner, units='degrees', mesh_name=None,
+               regional=None):
+        """From corner arrays (``lat_lon_grid_descriptor.py:180-222``)."""
+        d = cls(mesh_name=mesh_name, regional=regional)
+        d.lat_corner = np.asarray(lat_corner, dtype=np.float64)
+        d.lon_corner = np.asarray(lon_corner, dtype=np.float64)
+        d.lat = 0.5 * (d.lat_corner[:-1] + d.lat_corner[1:])
+        d.lon = 0.5 * (d.lon_corner[:-1] + d.lon_corner[1:])
+        d.units = units
+        d.history = _history()
+        d._set_coords('lat', 'lon', 'lat', 'lon')
+        return d
+
+    def _set_coords(self, lat_var, lon_var, lat_dim, lon_dim):
+        self.lat_var_name = lat_var
+        self.lon_var_name = lon_var
+        self.coords = {
+            lat_var: {'dims': lat_dim, 'data': self.lat,
+                      'attrs': {'units': self.units}},
+            lon_var: {'dims': lon_dim, 'data': self.lon,
+                      'attrs': {'units': self.units}},
+        }
+        self.dims = [lat_dim, lon_dim]
+        self.dim_sizes = [len(self.lat), len(self.lon)]
+        if 'degree' in self.units:
+            unit, circle = 'degree', 360.0
+        elif 'rad' in self.units:
+            unit, circle = 'radian', 2.0 * np.pi
+        else:
+            raise ValueError(f'Could not figure out units {self.units}')
+        if self.regional is None:
+            self.regional = not _lon_is_periodic(self.lon, circle)
+        if self.mesh_name is None:
+            dlat = abs(self.lat[1] - self.lat[0])
+            dlon = abs(self.lon[1] - self.lon[0])
+            self.mesh_name = f'{_round_res(dlat)}x{_round_res(dlon)}{unit}'
+
+
+def get_lat_lon_descriptor(dlon, dlat, lon_min=-180.0, lon_max=180.0,
+                           lat_min=-90.0, lat_max=90.0):
+    """Regular global grid (``lat_lon_grid_descriptor.py:27-65``)."""
+    nlat = int((lat_max - lat_min) / dlat) + 1
+    nlon = int((lon_max - lon_min) / dlon) + 1
+    lat = np.linspace(lat_min, lat_max, nlat)
+    lon = np.linspace(lon_min, lon_max, nlon)
+    return LatLonGridDescriptor.create(lat, lon, units='degrees')
+
+
+class LatLon2DGridDescriptor(MeshDescriptor):
+    """
+    A grid with 2-D lat/lon arrays
+    (``lat_lon_2d_grid_descriptor.py:27,251-252``): dims ``[lat_dim, lon_dim]``
+    of the 2-D arrays.
+    """
+
+    @classmethod
+    def create(cls, lat, lon, lat_dim='y', lon_dim='x', units='degrees',
+               mesh_name=None, regional=True):
+        d = cls(mesh_name=mesh_name, regional=regional)
+        d.lat = np.asarray(lat, dtype=np.float64)
+        d.lon = np.asarray(lon, dtype=np.float64)
+        d.units = units
+        d.history = _history()
+        d.dims = [lat_dim, lon_dim]
+        d.dim_sizes = list(d.lat.shape)
+        d.coords = {
+            'lat': {'dims': (lat_dim, lon_dim), 'data': d.lat,
+                    'attrs': {'units': units}},
+            'lon': {'dims': (lat_dim, lon_dim), 'data': d.lon,
+                    'attrs': {'units': units}},
+        }
+        return d
+
+
+class MpasMeshDescriptor(MeshDescriptor):
+    """Common part of the three MPAS descriptors."""
+
+    _dim = None
+    _lat = None
+    _lon = None
+    _lat_coord = None
+    _lon_coord = None
+
+    def __init__(self, filename=None, mesh_name=None, lat=None, lon=None,
+                 size=None):
+        """
+        ``filename``: an MPAS mesh file (NetCDF-3 readable without xarray),
+        as in the reference; or give ``lat``/``lon`` (radians) or just
+        ``size`` directly.
+        """
+        super().__init__()
+        self.filename = filename
+        self.mesh_name = mesh_name
+        self.regional = True
+        self.history = None
+        attrs = {}
+        if filename is not None:
+            from pyremap_amd.io.netcdf import open_dataset
+            ds = open_dataset(filename)
+            attrs = ds.attrs
+            lat = ds[self._lat].values
+            lon = ds[self._lon].values
+            self.mesh_name_from_attr(ds)
+        if self.mesh_name is None:
+            raise ValueError('No mesh_name provided or found in file.')
+        if lat is not None:
+            size = len(lat)
+            self.coords = {
+                self._lat_coord: {'dims': self._dim, 'data': np.asarray(lat),
+                                  'attrs': {'units': 'radians'}},
+                self._lon_coord: {'dims': self._dim, 'data': np.asarray(lon),
+                                  'attrs': {'units': 'radians'}},
+            }
+        else:
+            if size is None:
+                raise ValueError('one of filename, lat/lon or size is needed')
+            self.coords = {}
+        self.dims = [self._dim]
+        self.dim_sizes = [int(size)]
+        hist = _history()
+        if 'history' in attrs:
+            hist = '\n'.join([str(attrs['history']), hist])
+        self.history = hist
+
+
+class MpasCellMeshDescriptor(MpasMeshDescriptor):
+    """``mpas_cell_mesh_descriptor.py:21,69-82``."""
+    _dim = 'nCells'
+    _lat, _lon = 'latCell', 'lonCell'
+    _lat_coord, _lon_coord = 'lat_cell', 'lon_cell'
+
+
+class MpasEdgeMeshDescriptor(MpasMeshDescriptor):
+    """``mpas_edge_mesh_descriptor.py:21,68-81``."""
+    _dim = 'nEdges'
+    _lat, _lon = 'latEdge', 'lonEdge'
+    _lat_coord, _lon_coord = 'lat_edge', 'lon_edge'
+
+
+class MpasVertexMeshDescriptor(MpasMeshDescriptor):
+    """``mpas_vertex_mesh_descriptor.py:21,64-77``."""
+    _dim = 'nVertices'
+    _lat, _lon = 'latVertex', 'lonVertex'
+    _lat_coord, _lon_coord = 'lat_vertex', 'lon_vertex'
+
+
+class PointCollectionDescriptor(MeshDescriptor):
+    """``point_collection_descriptor.py:21,74-91``."""
+
+    def __init__(self, lats, lons, collection_name, units='degrees',
+                 out_dimension='n_points'):
+        super().__init__(mesh_name=collection_name, regional=True)
+        self.lat = np.asarray(lats)
+        self.lon = np.asarray(lons)
+        self.units = units
+        self.coords = {
+            'lat': {'dims': out_dimension, 'data': self.lat,
+                    'attrs': {'units': units}},
+            'lon': {'dims': out_dimension, 'data': self.lon,
+                    'attrs': {'units': units}},
+        }
+        self.dims = [out_dimension]
+        self.dim_sizes = [len(self.lat)]
+        self.history = _history()
+
+
+class ProjectionGridDescriptor(MeshDescriptor):
+    """
+    A regular grid on a map projection
+    (``projection_grid_descriptor.py:28,286-321``): dims ``[y, x]``.  The
+    reference also attaches 2-D ``lat``/``lon`` coordinates computed with
+    pyproj; they are added here when pyproj is importable or when they are
+    passed in.
+    """
+
+    def __init__(self, projection=None, mesh_name=None):
+        super().__init__(mesh_name=mesh_name, regional=True)
+        self.projection = projection
+        self.x = None
+        self.y = None
+        self.x_corner = None
+        self.y_corner = None
+        self.history = None
+
+    @classmethod
+    def create(cls, projection, x, y, mesh_name, lat=None, lon=None):
+        d = cls(projection, mesh_name=mesh_name)
+        d.x = np.asarray(x, dtype=np.float64)
+        d.y = np.asarray(y, dtype=np.float64)
+        d.x_corner = _corners_1d(d.x)
+        d.y_corner = _corners_1d(d.y)
+        d.history = _history()
+        d.x_var_name, d.y_var_name = 'x', 'y'
+        d.coords = {
+            'x': {'dims': 'x', 'data': d.x, 'attrs': {'units': 'meters'}},
+            'y': {'dims': 'y', 'data': d.y, 'attrs': {'units': 'meters'}},
+        }
+        if lat is None and projection is not None:
+            lat, lon = _project_to_lat_lon(projection, d.x, d.y)
+        if lat is not None:
+            d.coords['lat'] = {'dims': ('y', 'x'), 'data': np.asarray(lat),
+                               'attrs': {'units': 'degrees'}}
+            d.coords['lon'] = {'dims': ('y', 'x'), 'data': np.asarray(lon),
+                               'attrs': {'units': 'degrees'}}
+        d.dims = ['y', 'x']
+        d.dim_sizes = [len(d.y), len(d.x)]
+        return d
+
+
+def _corners_1d(centres):
+    """Extrapolated cell edges of a 1-D axis (``utility.py:220-228``)."""
+    c = np.asarray(centres, dtype=np.float64)
+    out = np.zeros(len(c) + 1)
+    out[1:-1] = 0.5 * (c[:-1] + c[1:])
+    out[0] = 1.5 * c[0] - 0.5 * c[1]
+    out[-1] = 1.5 * c[-1] - 0.5 * c[-2]
+    return out
+
+
+def _project_to_lat_lon(projection, x, y):
+    try:
+        import pyproj
+    except ImportError:
+        return None, None
+    lat_lon = pyproj.Proj(proj='latlong', datum='WGS84')
+    xx, yy = np.meshgrid(x, y)
+    transformer = pyproj.Transformer.from_proj(projection, lat_lon)
+    lon, lat = transformer.transform(xx, yy)
+    return lat, lon

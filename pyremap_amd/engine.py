@@ -1,0 +1,476 @@
+"""
+Host side of the MI355X weight-application engine: the ctypes binding of
+``libremap_hip.so`` (``include/remap_hip.h``) plus the device-resident plan.
+
+This is the layer that replaces, for ``Remapper.remap_numpy``:
+
+* ``remap_numpy.py:134-137`` -- ``RemapPlan.from_triplets`` (COO -> CSR on
+  the device, cached on the Remapper where the reference caches ``_matrix``);
+* ``remap_numpy.py:223-297`` -- ``remap_array`` (``_remap_numpy_array``):
+  the permute/flatten and unflatten/unpermute steps become strides handed to
+  the kernel, the SpMM + normalisation + masking is one fused HIP launch.
+
+PyTorch is used for device memory, streams and (in ``parallel.py``)
+``torch.distributed``; the arithmetic is in the HIP library.  There is no CPU
+fallback: without the library or without a GPU every compute entry point
+raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from pyremap_amd import _build
+
+MODE_RAW = 0
+MODE_FRACB = 1
+MODE_MASKED = 2
+
+FLAG_FMA = 1
+FLAG_CACHED_STORE = 2
+
+DTYPE_F64 = 0
+DTYPE_F32 = 1
+
+ABI_VERSION = 1
+
+#: every symbol ``include/remap_hip.h`` declares
+EXPORTS = (
+    'remap_abi_version', 'remap_arch', 'remap_last_error',
+    'remap_device_count', 'remap_apply_f64', 'remap_csr_from_coo_workspace',
+    'remap_csr_from_coo', 'remap_stream_copy',
+)
+
+
+class _CSR(ctypes.Structure):
+    _fields_ = [
+        ('n_rows', ctypes.c_int64),
+        ('n_cols', ctypes.c_int64),
+        ('nnz', ctypes.c_int64),
+        ('rowptr', ctypes.c_void_p),
+        ('col', ctypes.c_void_p),
+        ('val', ctypes.c_void_p),
+    ]
+
+
+class _ApplyArgs(ctypes.Structure):
+    _fields_ = [
+        ('A', _CSR),
+        ('row_begin', ctypes.c_int64),
+        ('row_end', ctypes.c_int64),
+        ('X', ctypes.c_void_p),
+        ('x_dtype', ctypes.c_int32),
+        ('mode', ctypes.c_int32),
+        ('x_row_stride', ctypes.c_int64),
+        ('x_batch_stride', ctypes.c_int64),
+        ('Y', ctypes.c_void_p),
+        ('y_row_stride', ctypes.c_int64),
+        ('y_batch_stride', ctypes.c_int64),
+        ('n_batch', ctypes.c_int64),
+        ('k_inner', ctypes.c_int64),
+        ('frac_b', ctypes.c_void_p),
+        ('threshold', ctypes.c_double),
+        ('mask_out', ctypes.c_void_p),
+        ('flags', ctypes.c_uint32),
+        ('tune', ctypes.c_int32 * 8),
+    ]
+
+
+_lib = None
+
+
+class EngineError(RuntimeError):
+    """A failure reported by libremap_hip.so (message from the C side)."""
+
+
+def library_path():
+    return _build.LIB_PATH
+
+
+def load_library():
+    """
+    Load ``libremap_hip.so``; build it first if it is missing and hipcc is
+    available.  Raises if the library cannot be provided -- there is no other
+    implementation to fall back to.
+    """
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB_PATH
+    if not os.path.exists(path):
+        if _build.find_hipcc() is None:
+            raise EngineError(
+                f'{path} is missing and hipcc is not available to build it; '
+                f'run `python -c "import __graft_entry__ as g; g.build()"` '
+                f'on a machine with ROCm')
+        _build.build_library()
+    lib = ctypes.CDLL(path)
+    missing = [name for name in EXPORTS if not hasattr(lib, name)]
+    if missing:
+        raise EngineError(f'{path} lacks symbols {missing}')
+    lib.remap_abi_version.restype = ctypes.c_int
+    lib.remap_arch.restype = ctypes.c_char_p
+    lib.remap_last_error.restype = ctypes.c_char_p
+    lib.remap_device_count.restype = ctypes.c_int
+    lib.remap_apply_f64.restype = ctypes.c_int
+    lib.remap_apply_f64.argtypes = [ctypes.POINTER(_ApplyArgs),
+                                    ctypes.c_void_p]
+    lib.remap_csr_from_coo_workspace.restype = ctypes.c_int
+    lib.remap_csr_from_coo_workspace.argtypes = [
+        ctypes.c_int64, ctypes.c_int64, ctypes.POINTER(ctypes.c_size_t)]
+    lib.remap_csr_from_coo.restype = ctypes.c_int
+    lib.remap_csr_from_coo.argtypes = [
+        ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    lib.remap_stream_copy.restype = ctypes.c_int
+    lib.remap_stream_copy.argtypes = [ctypes.c_void_p, ctypes.c_void_p,
+                                      ctypes.c_size_t, ctypes.c_void_p]
+    if lib.remap_abi_version() != ABI_VERSION:
+        raise EngineError(
+            f'{path} has ABI {lib.remap_abi_version()}, expected '
+            f'{ABI_VERSION}; rebuild it')
+    _lib = lib
+    return lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = load_library().remap_last_error().decode('utf-8', 'replace')
+        raise EngineError(f'{what} failed ({rc}): {msg}')
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def require_gpu():
+    torch = _torch()
+    if not torch.cuda.is_available():
+        raise EngineError(
+            'no HIP device is visible: the remapping engine runs on MI355X '
+            'only (there is no CPU implementation in pyremap_amd)')
+    load_library()
+    return torch
+
+
+def _stream_ptr(device):
+    torch = _torch()
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+# ---------------------------------------------------------------------------
+# the plan: device-resident CSR + frac_b
+# ---------------------------------------------------------------------------
+
+class RemapPlan:
+    """
+    Device-resident weights of one mapping file (or of a row shard of it):
+    what the reference keeps as ``remapper._matrix`` plus ``frac_b``.
+
+    Attributes
+    ----------
+    n_a, n_b : int
+        source size and number of destination rows HELD by this plan
+    n_b_global : int
+        destination size of the whole mapping
+    row_offset : int
+        global index of this plan's first row (0 unless sharded)
+    rowptr, col, val, frac_b : torch.Tensor
+        int64[n_b + 1], int32[nnz], float64[nnz], float64[n_b] on ``device``
+    """
+
+    def __init__(self, n_a, n_b, rowptr, col, val, frac_b, row_offset=0,
+                 n_b_global=None):
+        self.n_a = int(n_a)
+        self.n_b = int(n_b)
+        self.rowptr = rowptr
+        self.col = col
+        self.val = val
+        self.frac_b = frac_b
+        self.row_offset = int(row_offset)
+        self.n_b_global = int(n_b if n_b_global is None else n_b_global)
+        self.nnz = int(val.shape[0])
+        self.device = val.device
+
+    # -- construction -------------------------------------------------------
+    @classmethod
+    def from_triplets(cls, row, col, S, frac_b, n_a, n_b, index_base=1,
+                      device=None):
+        """
+        ``csr_matrix((S, (row - base, col - base)), shape=(n_b, n_a))`` on
+        the device (``remap_numpy.py:134-137``).  ``row``/``col``/``S`` may
+        be numpy arrays or torch tensors (host or device).
+        """
+        torch = require_gpu()
+        lib = load_library()
+        if device is None:
+            device = torch.device('cuda', torch.cuda.current_device())
+        device = torch.device(device)
+        row_d = torch.as_tensor(np.ascontiguousarray(row) if isinstance(
+            row, np.ndarray) else row).to(device=device, dtype=torch.int32)
+        col_d = torch.as_tensor(np.ascontiguousarray(col) if isinstance(
+            col, np.ndarray) else col).to(device=device, dtype=torch.int32)
+        s_d = torch.as_tensor(np.ascontiguousarray(S) if isinstance(
+            S, np.ndarray) else S).to(device=device, dtype=torch.float64)
+        row_d, col_d, s_d = (row_d.contiguous(), col_d.contiguous(),
+                             s_d.contiguous())
+        nnz = int(s_d.shape[0])
+        if row_d.shape[0] != nnz or col_d.shape[0] != nnz:
+            raise ValueError('row, col and S must have the same length')
+        frac_d = torch.as_tensor(
+            np.ascontiguousarray(frac_b) if isinstance(frac_b, np.ndarray)
+            else frac_b).to(device=device, dtype=torch.float64).contiguous()
+        if frac_d.shape[0] != n_b:
+            raise ValueError(f'frac_b has {frac_d.shape[0]} entries, '
+                             f'expected n_b = {n_b}')
+        with torch.cuda.device(device):
+            nbytes = ctypes.c_size_t(0)
+            _check(lib.remap_csr_from_coo_workspace(
+                nnz, n_b, ctypes.byref(nbytes)), 'remap_csr_from_coo_workspace')
+            ws = torch.empty(max(int(nbytes.value), 1), dtype=torch.uint8,
+                             device=device)
+            rowptr = torch.empty(n_b + 1, dtype=torch.int64, device=device)
+            col_out = torch.empty(max(nnz, 1), dtype=torch.int32,
+                                  device=device)
+            val_out = torch.empty(max(nnz, 1), dtype=torch.float64,
+                                  device=device)
+            counts = torch.zeros(2, dtype=torch.int64, device=device)
+            _check(lib.remap_csr_from_coo(
+                n_b, n_a, nnz, _ptr(row_d), _ptr(col_d), _ptr(s_d),
+                int(index_base), _ptr(rowptr), _ptr(col_out), _ptr(val_out),
+                ctypes.c_void_p(counts.data_ptr()),
+                ctypes.c_void_p(counts.data_ptr() + 8), _ptr(ws),
+                ws.numel(), _stream_ptr(device)), 'remap_csr_from_coo')
+            nnz_u, bad = (int(v) for v in counts.cpu())
+        if bad:
+            raise ValueError(
+                f'{bad} mapping triplets have a row or col index outside '
+                f'the ({n_b}, {n_a}) matrix')
+        return cls(n_a, n_b, rowptr, col_out[:nnz_u].clone(),
+                   val_out[:nnz_u].clone(), frac_d)
+
+    @classmethod
+    def from_csr(cls, indptr, indices, data, frac_b, n_a, device=None):
+        """Wrap an existing (host or device) CSR; arrays are copied."""
+        torch = require_gpu()
+        if device is None:
+            device = torch.device('cuda', torch.cuda.current_device())
+        rowptr = torch.as_tensor(indptr).to(device=device, dtype=torch.int64)
+        col = torch.as_tensor(indices).to(device=device, dtype=torch.int32)
+        val = torch.as_tensor(data).to(device=device, dtype=torch.float64)
+        frac = torch.as_tensor(frac_b).to(device=device, dtype=torch.float64)
+        return cls(n_a, rowptr.shape[0] - 1, rowptr.contiguous(),
+                   col.contiguous(), val.contiguous(), frac.contiguous())
+
+    # -- sharding -----------------------------------------------------------
+    def shard_bounds(self, world_size):
+        """
+        Contiguous destination-row ranges, balanced by the work per row
+        (entries + a constant per row for the output write), as a list of
+        ``world_size + 1`` row indices.
+        """
+        torch = _torch()
+        n_b = self.n_b
+        if world_size <= 1 or n_b == 0:
+            return [0] + [n_b] * max(world_size, 1)
+        rows = torch.arange(n_b + 1, device=self.device, dtype=torch.int64)
+        # cost(row range) ~ nnz + 2 * rows  (Y write + first-touch X)
+        work = self.rowptr + 2 * rows
+        total = int(work[-1])
+        targets = torch.tensor([total * r // world_size
+                                for r in range(1, world_size)],
+                               device=self.device, dtype=torch.int64)
+        cuts = torch.searchsorted(work, targets).cpu().tolist()
+        return [0] + [min(int(c), n_b) for c in cuts] + [n_b]
+
+    def shard(self, rank, world_size):
+        """The plan of rank ``rank`` of ``world_size`` (rows only)."""
+        bounds = self.shard_bounds(world_size)
+        return self.row_slice(bounds[rank], bounds[rank + 1])
+
+    def row_slice(self, r0, r1):
+        j0 = int(self.rowptr[r0])
+        j1 = int(self.rowptr[r1])
+        return RemapPlan(
+            self.n_a, r1 - r0, (self.rowptr[r0:r1 + 1] - j0).contiguous(),
+            self.col[j0:j1].contiguous(), self.val[j0:j1].contiguous(),
+            self.frac_b[r0:r1].contiguous(),
+            row_offset=self.row_offset + r0, n_b_global=self.n_b_global)
+
+    # -- accounting ---------------------------------------------------------
+    def algorithmic_bytes(self, K, x_itemsize=8, mode=MODE_FRACB):
+        """
+        SURVEY.md section 8(d): S + col read once, rowptr, X read once,
+        Y written once, frac_b in the unmasked mode.
+        """
+        b = self.nnz * 12 + (self.n_b + 1) * 8
+        b += self.n_a * K * x_itemsize + self.n_b * K * 8
+        if mode == MODE_FRACB:
+            b += self.n_b * 8
+        return b
+
+    def to_host_csr(self):
+        return (self.rowptr.cpu().numpy(), self.col.cpu().numpy(),
+                self.val.cpu().numpy())
+
+
+# ---------------------------------------------------------------------------
+# launches
+# ---------------------------------------------------------------------------
+
+def apply_strided(plan, X, Y, *, n_batch, k_inner, x_row_stride,
+                  x_batch_stride, y_row_stride, y_batch_stride, mode,
+                  threshold=0.0, mask_out=None, flags=0, tune=None,
+                  row_begin=0, row_end=None):
+    """
+    One asynchronous ``remap_apply_f64`` launch on torch's current stream.
+    ``X``/``Y``/``mask_out`` are device tensors; strides are in elements.
+    """
+    torch = _torch()
+    lib = load_library()
+    if X.device != plan.device or Y.device != plan.device:
+        raise ValueError('X, Y and the plan must live on the same device')
+    if Y.dtype != torch.float64:
+        raise TypeError('Y must be float64')
+    if X.dtype == torch.float64:
+        x_dtype = DTYPE_F64
+    elif X.dtype == torch.float32:
+        x_dtype = DTYPE_F32
+    else:
+        raise TypeError(f'X must be float64 or float32, not {X.dtype}')
+    args = _ApplyArgs()
+    args.A.n_rows = plan.n_b
+    args.A.n_cols = plan.n_a
+    args.A.nnz = plan.nnz
+    args.A.rowptr = plan.rowptr.data_ptr()
+    args.A.col = plan.col.data_ptr()
+    args.A.val = plan.val.data_ptr()
+    args.row_begin = row_begin
+    args.row_end = plan.n_b if row_end is None else row_end
+    args.X = X.data_ptr()
+    args.x_dtype = x_dtype
+    args.mode = mode
+    args.x_row_stride = x_row_stride
+    args.x_batch_stride = x_batch_stride
+    args.Y = Y.data_ptr()
+    args.y_row_stride = y_row_stride
+    args.y_batch_stride = y_batch_stride
+    args.n_batch = n_batch
+    args.k_inner = k_inner
+    args.frac_b = plan.frac_b.data_ptr() if mode == MODE_FRACB else None
+    args.threshold = float(threshold)
+    args.mask_out = mask_out.data_ptr() if mask_out is not None else None
+    args.flags = flags
+    if tune:
+        for i, v in enumerate(tune):
+            args.tune[i] = int(v)
+    with torch.cuda.device(plan.device):
+        _check(lib.remap_apply_f64(ctypes.byref(args),
+                                   _stream_ptr(plan.device)),
+               'remap_apply_f64')
+
+
+def _prod(seq):
+    out = 1
+    for s in seq:
+        out *= int(s)
+    return out
+
+
+def remap_tensor(plan, dst_grid_dims, field, remap_axes, mode, threshold=0.0,
+                 want_mask=False, flags=0, tune=None, out=None):
+    """
+    Device-level ``_remap_numpy_array``: ``field`` is a device tensor whose
+    axes ``remap_axes`` hold the source grid; returns the float64 tensor with
+    those axes replaced by ``dst_grid_dims`` at ``min(remap_axes)``
+    (``remap_numpy.py:280-295``), NaN where the reference masks, and the
+    uint8 mask (1 = masked) when ``want_mask``.
+
+    ``dst_grid_dims`` is in C order; for a row shard the leading destination
+    dimension is replaced by the shard's row count (the result is the flat
+    slab of rows ``[plan.row_offset, plan.row_offset + plan.n_b)``).
+    """
+    torch = _torch()
+    remap_axes = [int(a) % field.ndim for a in remap_axes]
+    ndim = field.ndim
+    extra_axes = [ax for ax in range(ndim) if ax not in remap_axes]
+    n_src = _prod(field.shape[ax] for ax in remap_axes)
+    if n_src != plan.n_a:
+        raise ValueError(
+            f'the remapped axes hold {n_src} source cells but the mapping '
+            f'has n_a = {plan.n_a}')
+    if field.dtype not in (torch.float64, torch.float32):
+        # scipy upcasts everything else to float64 before the product
+        field = field.to(torch.float64)
+
+    lead = min(remap_axes)
+    contiguous_block = remap_axes == list(range(lead, lead + len(remap_axes)))
+    lead_shape = [int(s) for s in field.shape[:lead]]
+    tail_shape = [int(field.shape[ax]) for ax in extra_axes if ax > lead]
+    n_batch = _prod(lead_shape)
+    k_inner = _prod(tail_shape)
+    direct = contiguous_block and (k_inner >= 8 or n_batch == 1)
+    sharded = plan.n_b != plan.n_b_global
+    dst_shape = [plan.n_b] if sharded else [int(d) for d in dst_grid_dims]
+    if not sharded and _prod(dst_shape) != plan.n_b:
+        raise ValueError(f'dst_grid_dims {dst_shape} do not hold n_b = '
+                         f'{plan.n_b} cells')
+    out_shape = lead_shape + dst_shape + tail_shape
+
+    if direct:
+        # strides do the permute/flatten of remap_numpy.py:254-256
+        X = field.contiguous()
+        Y = out if out is not None else torch.empty(
+            out_shape, dtype=torch.float64, device=field.device)
+        mask = torch.empty(out_shape, dtype=torch.uint8,
+                           device=field.device) if want_mask else None
+        apply_strided(
+            plan, X, Y, n_batch=n_batch, k_inner=k_inner,
+            x_row_stride=k_inner, x_batch_stride=plan.n_a * k_inner,
+            y_row_stride=k_inner, y_batch_stride=plan.n_b * k_inner,
+            mode=mode, threshold=threshold, mask_out=mask, flags=flags,
+            tune=tune)
+        return (Y, mask) if want_mask else Y
+
+    # general axis order (or a very short contiguous run): one device
+    # transpose to (n_a, K), the kernel, one transpose back
+    K = _prod(field.shape[ax] for ax in extra_axes)
+    X = field.permute(remap_axes + extra_axes).reshape(n_src, K).contiguous()
+    Y = torch.empty((plan.n_b, K), dtype=torch.float64, device=field.device)
+    mask = torch.empty((plan.n_b, K), dtype=torch.uint8,
+                       device=field.device) if want_mask else None
+    apply_strided(plan, X, Y, n_batch=1, k_inner=K, x_row_stride=K,
+                  x_batch_stride=0, y_row_stride=K, y_batch_stride=0,
+                  mode=mode, threshold=threshold, mask_out=mask, flags=flags,
+                  tune=tune)
+    extra_shape = [int(field.shape[ax]) for ax in extra_axes]
+    n_dst = len(dst_shape)
+    tail = list(range(n_dst, n_dst + len(extra_shape)))
+    unpermute = tail[:lead] + list(range(n_dst)) + tail[lead:]
+
+    def back(t):
+        t = t.reshape(dst_shape + extra_shape).permute(unpermute).contiguous()
+        return t
+    Y = back(Y)
+    if out is not None:
+        out.copy_(Y)
+        Y = out
+    return (Y, back(mask)) if want_mask else Y
+
+
+def stream_copy(dst, src):
+    """Asynchronous device copy through the library's streaming kernel."""
+    torch = _torch()
+    lib = load_library()
+    nbytes = src.numel() * src.element_size()
+    with torch.cuda.device(src.device):
+        _check(lib.remap_stream_copy(_ptr(dst), _ptr(src), nbytes,
+                                     _stream_ptr(src.device)),
+               'remap_stream_copy')

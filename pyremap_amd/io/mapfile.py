@@ -1,0 +1,169 @@
+"""
+Reading and writing SCRIP/ESMF-style mapping ("weights") files.
+
+The reference opens the mapping file with ``xr.open_dataset``
+(``pyremap/remapper/remap_numpy.py:88``) and consumes the dims ``n_a, n_b,
+src_grid_rank, dst_grid_rank`` and the variables ``src_grid_dims,
+dst_grid_dims, col, row, S, frac_b`` (:89-137, :270).
+Here the same members are read without xarray:
+
+* NetCDF-3 (CDF-1 / CDF-2) with ``scipy.io.netcdf_file``;
+* NetCDF-4 / HDF5 (what ESMF writes with ``--netcdf4``,
+  ``build_map.py:166``) with ``h5py`` or ``netCDF4`` when importable;
+* ``.npz`` with the same variable names (handy for synthetic maps).
+"""
+import os
+
+import numpy as np
+
+REQUIRED = ('src_grid_dims', 'dst_grid_dims', 'col', 'row', 'S', 'frac_b')
+
+
+class MappingFile:
+    """The members of a mapping file that the remapping path consumes."""
+
+    def __init__(self, n_a, n_b, src_grid_dims, dst_grid_dims, row, col, S,
+                 frac_b):
+        self.n_a = int(n_a)
+        self.n_b = int(n_b)
+        #: as stored in the file: Fortran order
+        self.src_grid_dims = np.asarray(src_grid_dims, dtype=np.int64)
+        self.dst_grid_dims = np.asarray(dst_grid_dims, dtype=np.int64)
+        #: 1-based, unsorted, duplicates allowed
+        self.row = np.asarray(row)
+        self.col = np.asarray(col)
+        self.S = np.asarray(S, dtype=np.float64)
+        self.frac_b = np.asarray(frac_b, dtype=np.float64)
+
+    @property
+    def src_grid_rank(self):
+        return int(self.src_grid_dims.shape[0])
+
+    @property
+    def dst_grid_rank(self):
+        return int(self.dst_grid_dims.shape[0])
+
+    @property
+    def n_s(self):
+        return int(self.S.shape[0])
+
+
+def _magic(filename):
+    with open(filename, 'rb') as f:
+        return f.read(8)
+
+
+def read_mapping(filename):
+    """Read the members listed above from ``filename``."""
+    if not os.path.exists(filename):
+        raise FileNotFoundError(filename)
+    magic = _magic(filename)
+    if magic[:2] == b'PK' or filename.endswith('.npz'):
+        return _read_npz(filename)
+    if magic[:3] == b'CDF':
+        if magic[3] in (1, 2):
+            return _read_netcdf3(filename)
+        raise NotImplementedError(
+            f'{filename}: NetCDF-3 CDF-{magic[3]} mapping files are not '
+            f'supported yet')
+    if magic == b'\x89HDF\r\n\x1a\n':
+        return _read_hdf5(filename)
+    raise ValueError(f'{filename}: not a NetCDF, HDF5 or npz mapping file')
+
+
+def _read_npz(filename):
+    with np.load(filename) as z:
+        missing = [k for k in REQUIRED if k not in z]
+        if missing:
+            raise ValueError(f'{filename}: missing variables {missing}')
+        n_b = int(z['n_b']) if 'n_b' in z else int(z['frac_b'].shape[0])
+        if 'n_a' in z:
+            n_a = int(z['n_a'])
+        else:
+            n_a = int(np.prod(z['src_grid_dims']))
+        return MappingFile(n_a, n_b, z['src_grid_dims'], z['dst_grid_dims'],
+                           z['row'], z['col'], z['S'], z['frac_b'])
+
+
+def _read_netcdf3(filename):
+    from scipy.io import netcdf_file
+    with netcdf_file(filename, 'r', mmap=False) as nc:
+        missing = [k for k in REQUIRED if k not in nc.variables]
+        if missing:
+            raise ValueError(f'{filename}: missing variables {missing}')
+        get = {k: np.array(nc.variables[k][:]) for k in REQUIRED}
+        n_a = nc.dimensions['n_a']
+        n_b = nc.dimensions['n_b']
+    return MappingFile(n_a, n_b, get['src_grid_dims'], get['dst_grid_dims'],
+                       get['row'], get['col'], get['S'], get['frac_b'])
+
+
+def _read_hdf5(filename):
+    try:
+        import h5py
+    except ImportError:
+        h5py = None
+    if h5py is not None:
+        with h5py.File(filename, 'r') as h5:
+            missing = [k for k in REQUIRED if k not in h5]
+            if missing:
+                raise ValueError(f'{filename}: missing variables {missing}')
+            get = {k: np.array(h5[k][...]) for k in REQUIRED}
+            n_b = get['frac_b'].shape[0]
+            n_a = h5['n_a'].shape[0] if 'n_a' in h5 else \
+                int(np.prod(get['src_grid_dims']))
+        return MappingFile(n_a, n_b, get['src_grid_dims'],
+                           get['dst_grid_dims'], get['row'], get['col'],
+                           get['S'], get['frac_b'])
+    try:
+        import netCDF4
+    except ImportError as exc:
+        raise ImportError(
+            f'{filename} is NetCDF-4/HDF5; reading it needs h5py or '
+            f'netCDF4, neither of which is installed') from exc
+    with netCDF4.Dataset(filename) as nc:
+        get = {k: np.array(nc.variables[k][:]) for k in REQUIRED}
+        n_a = len(nc.dimensions['n_a'])
+        n_b = len(nc.dimensions['n_b'])
+    return MappingFile(n_a, n_b, get['src_grid_dims'], get['dst_grid_dims'],
+                       get['row'], get['col'], get['S'], get['frac_b'])
+
+
+def write_mapping(filename, n_a, n_b, src_grid_dims, dst_grid_dims, row, col,
+                  S, frac_b, attrs=None):
+    """
+    Write a mapping file with the schema of SURVEY.md Appendix A.
+    ``*.npz`` -> numpy archive; anything else -> NetCDF-3 64-bit offset.
+    ``src_grid_dims`` / ``dst_grid_dims`` are in FILE (Fortran) order and
+    ``row`` / ``col`` are 1-based, exactly as ESMF writes them.
+    """
+    row = np.asarray(row, dtype=np.int32)
+    col = np.asarray(col, dtype=np.int32)
+    S = np.asarray(S, dtype=np.float64)
+    frac_b = np.asarray(frac_b, dtype=np.float64)
+    src_grid_dims = np.asarray(src_grid_dims, dtype=np.int32)
+    dst_grid_dims = np.asarray(dst_grid_dims, dtype=np.int32)
+    if filename.endswith('.npz'):
+        np.savez(filename, n_a=np.int64(n_a), n_b=np.int64(n_b),
+                 src_grid_dims=src_grid_dims, dst_grid_dims=dst_grid_dims,
+                 row=row, col=col, S=S, frac_b=frac_b)
+        return
+    from scipy.io import netcdf_file
+    with netcdf_file(filename, 'w', version=2) as nc:
+        nc.createDimension('n_a', int(n_a))
+        nc.createDimension('n_b', int(n_b))
+        nc.createDimension('n_s', int(S.shape[0]))
+        nc.createDimension('src_grid_rank', int(src_grid_dims.shape[0]))
+        nc.createDimension('dst_grid_rank', int(dst_grid_dims.shape[0]))
+        for name, data, dim in (
+                ('src_grid_dims', src_grid_dims, 'src_grid_rank'),
+                ('dst_grid_dims', dst_grid_dims, 'dst_grid_rank'),
+                ('col', col, 'n_s'), ('row', row, 'n_s'), ('S', S, 'n_s'),
+                ('frac_b', frac_b, 'n_b')):
+            var = nc.createVariable(name, data.dtype, (dim,))
+            var[:] = data
+        # keep n_a alive as a used dimension, as in ESMF files
+        area_a = nc.createVariable('area_a', np.float64, ('n_a',))
+        area_a[:] = np.zeros(int(n_a))
+        for key, value in (attrs or {}).items():
+            setattr(nc, key, value)

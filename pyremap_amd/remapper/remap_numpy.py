@@ -1,0 +1,276 @@
+"""
+In-memory weight application -- the host-side mirror of the reference's
+``pyremap/remapper/remap_numpy.py``, with the same function names, argument
+meaning and error behaviour, and with the arithmetic (scipy CSR build, the
+``matrix.dot`` calls and every numpy pass around them) replaced by the
+MI355X engine (:mod:`pyremap_amd.engine` -> ``libremap_hip.so``).
+
+==============================  ============================================
+reference (remap_numpy.py)      here
+==============================  ============================================
+``_remap_numpy``      :19-69    same flow, accepts xarray or xr_lite objects
+``_load_mapping``     :72-139   same validation; ``csr_matrix(...)`` becomes
+                                ``RemapPlan.from_triplets`` (device CSR)
+``_check_drop``       :142-147  identical rule
+``_remap_data_array`` :150-220  same dims/coords bookkeeping; ``isnan`` test
+                                and mask live on the device
+``_remap_numpy_array`` :223-297 ``engine.remap_tensor``: strides instead of
+                                transpose copies, one fused HIP launch
+==============================  ============================================
+"""
+import sys
+
+import numpy as np
+
+from pyremap_amd import engine, xr_lite
+from pyremap_amd.io.mapfile import read_mapping
+
+try:  # real xarray is honoured when present; it is optional
+    import xarray as _xarray
+    if not hasattr(_xarray, '__version__'):
+        _xarray = None
+except ImportError:  # pragma: no cover - depends on the environment
+    _xarray = None
+
+
+def _is_data_array(obj):
+    if isinstance(obj, xr_lite.DataArray):
+        return True
+    return _xarray is not None and isinstance(obj, _xarray.DataArray)
+
+
+def _is_dataset(obj):
+    if isinstance(obj, xr_lite.Dataset):
+        return True
+    return _xarray is not None and isinstance(obj, _xarray.Dataset)
+
+
+def _array_class(like):
+    if _xarray is not None and isinstance(like, (_xarray.DataArray,
+                                                 _xarray.Dataset)):
+        return _xarray.DataArray
+    return xr_lite.DataArray
+
+
+class _MapInfo:
+    """What the reference keeps in ``remapper._ds_map`` and reads later."""
+
+    def __init__(self, mapping):
+        self.n_a = mapping.n_a
+        self.n_b = mapping.n_b
+        self.src_grid_rank = mapping.src_grid_rank
+        self.dst_grid_rank = mapping.dst_grid_rank
+        # grid dimensions are stored in Fortran order (remap_numpy.py:108)
+        self.src_grid_dims = [int(d) for d in mapping.src_grid_dims[::-1]]
+        self.dst_grid_dims = [int(d) for d in mapping.dst_grid_dims[::-1]]
+        self.frac_b = mapping.frac_b
+
+
+def _remap_numpy(remapper, ds, renormalization_threshold):
+    """
+    Remap a Dataset or DataArray, possibly masked and renormalized
+    (reference ``_remap_numpy`` :19-69: same checks, same errors, same
+    ``history`` / ``mesh_name`` attributes).
+    """
+    if remapper.map_filename is None:
+        raise ValueError('No mapping file has been defined')
+    _load_mapping(remapper)
+
+    expected = remapper._ds_map.src_grid_dims
+    for dim, size in zip(remapper.src_descriptor.dims, expected):
+        if size != ds.sizes[dim]:
+            raise ValueError(
+                f"data set and remapping source dimension {dim} don't "
+                f'have the same size: {size} != {ds.sizes[dim]}')
+
+    args = (remapper, renormalization_threshold)
+    if _is_data_array(ds):
+        result = _remap_data_array(ds, *args)
+    elif _is_dataset(ds):
+        # variables holding only part of the source dims cannot be remapped
+        partial = [name for name in ds.data_vars
+                   if _check_drop(remapper, ds[name])]
+        result = ds.drop_vars(partial).map(_remap_data_array,
+                                           keep_attrs=True, args=args)
+    else:
+        raise TypeError('ds not an xarray Dataset or DataArray.')
+
+    command = ' '.join(sys.argv[:])
+    previous = result.attrs.get('history')
+    result.attrs['history'] = command if previous is None else \
+        '\n'.join([previous, command])
+    result.attrs['mesh_name'] = remapper.dst_descriptor.mesh_name
+    return result
+
+
+def _validate_mapping(info, src_descriptor, dst_descriptor):
+    """The rank and size checks of reference ``_load_mapping`` :92-132."""
+    n_src, n_dst = len(src_descriptor.dims), len(dst_descriptor.dims)
+    if n_src != info.src_grid_rank or n_dst != info.dst_grid_rank:
+        raise ValueError(
+            f'The number of source and/or destination dimensions does not '
+            f'match the expected \n'
+            f'number of source and destination dimensions in the mapping '
+            f'file. \n'
+            f'{n_src} != {info.src_grid_rank} and/or {n_dst} != '
+            f'{info.dst_grid_rank}')
+    sides = (
+        ('source mesh descriptor and remapping source dimension',
+         src_descriptor, info.src_grid_dims),
+        ('dest. mesh descriptor and remapping dest. dimension',
+         dst_descriptor, info.dst_grid_dims),
+    )
+    for label, descriptor, file_dims in sides:
+        for dim, have, want in zip(descriptor.dims, descriptor.dim_sizes,
+                                   file_dims):
+            if have != want:
+                raise ValueError(
+                    f"{label} {dim} don't have the same size: \n"
+                    f'{have} != {want}')
+
+
+def _load_mapping(remapper):
+    """
+    Read the mapping file once, validate it against the descriptors and sort
+    its triplets into a device-resident CSR (reference ``_load_mapping``
+    :72-139; the plan is cached where the reference caches ``_matrix``).
+    """
+    if remapper._ds_map is not None:
+        return
+    mapping = remapper._mapping_override
+    if mapping is None:
+        mapping = read_mapping(remapper.map_filename)
+    info = _MapInfo(mapping)
+    _validate_mapping(info, remapper.src_descriptor, remapper.dst_descriptor)
+    # csr_matrix((S, (row - 1, col - 1)), shape=(n_b, n_a)), on the device
+    remapper._matrix = engine.RemapPlan.from_triplets(
+        mapping.row, mapping.col, mapping.S, mapping.frac_b, info.n_a,
+        info.n_b, index_base=1, device=remapper.device)
+    remapper._ds_map = info
+
+
+def _check_drop(remapper, da):
+    """True for a variable with some, but not all, source dims (:142-147)."""
+    hits = [dim in da.dims for dim in remapper.src_descriptor.dims]
+    return any(hits) and not all(hits)
+
+
+def _remap_data_array(da, remapper, renormalization_threshold):
+    """
+    Remap one variable (reference ``_remap_data_array`` :150-220): the
+    destination dims replace the first source dim, the other source dims
+    vanish, coordinates without a source dim are kept and the destination
+    descriptor's coordinates are added.
+    """
+    src_dims = remapper.src_descriptor.dims
+    remap_axes = [axis for axis, dim in enumerate(da.dims)
+                  if dim in src_dims]
+    if not remap_axes:
+        return da  # nothing to remap
+    if len(remap_axes) != len(src_dims):
+        raise ValueError(
+            'Data array with some (but not all) required source dims cannot '
+            'be remapped and should have been dropped.')
+
+    first = remap_axes[0]
+    dims = list(da.dims[:first]) + list(remapper.dst_descriptor.dims) + \
+        [dim for dim in da.dims[first:] if dim not in src_dims]
+
+    coords = {}
+    for name in da.coords:
+        coord = da.coords[name]
+        if not any(dim in coord.dims for dim in src_dims):
+            coords[name] = {'dims': coord.dims, 'data': coord.values}
+    coords.update(remapper.dst_descriptor.coords)
+
+    # the NaN test of :201-204 and the product both run on the device; masked
+    # entries come back as NaN, which is what xarray makes of the reference's
+    # masked array
+    data = _remap_values(remapper, da.values, remap_axes,
+                         renormalization_threshold)
+    return _array_class(da).from_dict({
+        'coords': coords, 'attrs': da.attrs, 'dims': dims, 'data': data,
+        'name': da.name})
+
+
+def _upload(remapper, values):
+    torch = engine.require_gpu()
+    values = np.asarray(values)
+    if values.dtype.kind not in 'fiub':
+        raise TypeError(f'cannot remap an array of dtype {values.dtype}')
+    if values.dtype not in (np.float64, np.float32):
+        values = values.astype(np.float64)
+    if not values.flags['C_CONTIGUOUS'] or not values.flags['WRITEABLE']:
+        values = np.array(values, order='C')
+    return torch.from_numpy(values).to(remapper._matrix.device)
+
+
+def _remap_values(remapper, values, remap_axes, renormalization_threshold):
+    """ndarray in, NaN-filled float64 ndarray out (used per variable)."""
+    torch = engine.require_gpu()
+    field = _upload(remapper, values)
+    masked = False
+    if renormalization_threshold is not None:
+        # reference: a MaskedArray is made iff the field holds a NaN (:203)
+        masked = bool(torch.isnan(field).any())
+    out = engine.remap_tensor(
+        remapper._matrix, remapper._ds_map.dst_grid_dims, field, remap_axes,
+        engine.MODE_MASKED if masked else engine.MODE_FRACB,
+        threshold=renormalization_threshold if masked else 0.0,
+        flags=remapper.engine_flags)
+    return out.cpu().numpy()
+
+
+def _remap_numpy_array(remapper, in_field, remap_axes,
+                       renormalization_threshold):
+    """
+    Remap a single array (reference ``_remap_numpy_array`` :223-297).
+
+    ``in_field`` may be
+
+    * a ``numpy.ndarray`` or ``numpy.ma.MaskedArray`` -- the result is a
+      ``numpy.ma.MaskedArray`` with the reference's shape, values and mask
+      (masked mode iff the input is a MaskedArray and a threshold is given,
+      exactly as at :258-261; the data under the mask is NaN here, the
+      undivided sum in the reference -- not observable through the API);
+    * a ``torch.Tensor`` on the plan's device -- the result is a float64
+      device tensor holding NaN where the reference masks; masked mode is
+      chosen as ``_remap_data_array`` would (a threshold and at least one
+      NaN), nothing leaves the device.
+    """
+    torch = engine.require_gpu()
+    plan = remapper._matrix
+    dst_grid_dims = remapper._ds_map.dst_grid_dims
+    remap_axes = [int(a) for a in remap_axes]
+
+    if isinstance(in_field, torch.Tensor):
+        field = in_field.to(plan.device)
+        masked = False
+        if renormalization_threshold is not None:
+            masked = bool(torch.isnan(field).any())
+        return engine.remap_tensor(
+            plan, dst_grid_dims, field, remap_axes,
+            engine.MODE_MASKED if masked else engine.MODE_FRACB,
+            threshold=renormalization_threshold if masked else 0.0,
+            flags=remapper.engine_flags)
+
+    is_ma = isinstance(in_field, np.ma.MaskedArray)
+    masked = is_ma and renormalization_threshold is not None
+    data = np.ma.getdata(in_field) if is_ma else np.asarray(in_field)
+    if masked:
+        # the kernel derives the mask from NaN (what in_mask * in_field
+        # amounts to when the mask is isnan(field), :201-204 and :263)
+        host_mask = np.ma.getmaskarray(in_field)
+        if data.dtype.kind != 'f':
+            data = data.astype(np.float64)
+        if host_mask.any():
+            data = np.array(data, copy=True)
+            data[host_mask] = np.nan
+    field = _upload(remapper, data)
+    out, mask = engine.remap_tensor(
+        plan, dst_grid_dims, field, remap_axes,
+        engine.MODE_MASKED if masked else engine.MODE_FRACB,
+        threshold=renormalization_threshold if masked else 0.0,
+        want_mask=True, flags=remapper.engine_flags)
+    return np.ma.masked_array(out.cpu().numpy(),
+                              mask=mask.cpu().numpy().astype(bool))

@@ -1,0 +1,250 @@
+"""
+Seeded synthetic mapping data with the shapes of BASELINE.json's configs.
+
+pyremap never computes weights itself -- ``build_map()`` shells out to
+ESMF / MOAB (``pyremap/remapper/build_map.py:47-91``), neither of which
+exists here -- so benchmarks and tests use generated triplets that are
+faithful in shape: sizes, entries per row, 1-based unsorted (row, col, S),
+``frac_b``, Fortran-ordered grid dims.
+
+Generators run in torch so the large configs (1e8 entries) can be produced
+on the GPU; with ``device='cpu'`` they serve the CPU tests.
+
+* :func:`bilinear_map`     exact tensor-product bilinear weights between two
+  regular 2-D grids (4 entries per row, rows sum to 1, ``frac_b = 1``):
+  configs 1 and 4.
+* :func:`conservative_map` overlap-like weights: each destination cell draws
+  k ~ U{lo..hi} distinct source cells from the 2-D neighbourhood of its
+  position in a virtual raster numbering of the source mesh (so rows that
+  are neighbours in either grid direction share source cells, as real
+  overlaps do), positive (or signed, for 2nd-order) weights scaled so that a
+  row sums to ``frac_b``; a blocky "land" mask leaves rows empty with
+  ``frac_b = 0``: configs 2, 3, 5 and the north-star headline H.
+"""
+import math
+
+CONFIGS = {
+    # name: kind, source, destination dims (C order), entries/row, fields
+    'config1': dict(kind='bilinear', src_dims=(180, 360),
+                    dst_dims=(360, 720), K=1,
+                    title='1deg -> 0.5deg lat-lon bilinear, one 2-D field'),
+    'config2': dict(kind='conservative', n_a=7153, dst_dims=(180, 360),
+                    k_lo=1, k_hi=4, K=64, empty_frac=0.3,
+                    title='QU240 -> 1deg conservative, 64 fields'),
+    'config3': dict(kind='conservative', n_a=235160, dst_dims=(360, 720),
+                    k_lo=3, k_hi=7, K=512, empty_frac=0.3,
+                    title='EC30to60 -> 0.5deg conservative, 512 fields'),
+    'config4': dict(kind='bilinear', src_dims=(834, 1001),
+                    dst_dims=(5001, 6001), K=128,
+                    title='6 km -> 1 km Antarctic stereographic bilinear, '
+                          '128 fields'),
+    'config5': dict(kind='conservative', n_a=3693225, dst_dims=(1800, 3600),
+                    k_lo=12, k_hi=30, K=1024, empty_frac=0.3, signed=True,
+                    title='oRRS18to6 -> 0.1deg 2nd-order conservative, '
+                          '1024 fields'),
+    'headline': dict(kind='conservative', n_a=3693225, dst_dims=(720, 1440),
+                     k_lo=4, k_hi=12, K=512, empty_frac=0.3,
+                     title='oRRS18to6 (3.7 M) -> 0.25deg (1.0 M) '
+                           'conservative, 512 fields'),
+}
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _gen(seed, device):
+    torch = _torch()
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    return g
+
+
+class SyntheticMap:
+    """Triplets as a mapping file stores them, plus the sizes."""
+
+    def __init__(self, row, col, S, frac_b, n_a, n_b, src_dims, dst_dims):
+        self.row = row            # int32, 1-based, unsorted
+        self.col = col            # int32, 1-based
+        self.S = S                # float64
+        self.frac_b = frac_b      # float64[n_b]
+        self.n_a = int(n_a)
+        self.n_b = int(n_b)
+        self.src_dims = tuple(int(d) for d in src_dims)   # C order
+        self.dst_dims = tuple(int(d) for d in dst_dims)   # C order
+
+    @property
+    def n_s(self):
+        return int(self.S.shape[0])
+
+    def numpy(self):
+        import numpy as np
+        return dict(
+            row=self.row.cpu().numpy(), col=self.col.cpu().numpy(),
+            S=self.S.cpu().numpy(), frac_b=self.frac_b.cpu().numpy(),
+            n_a=np.int64(self.n_a), n_b=np.int64(self.n_b),
+            src_grid_dims=np.asarray(self.src_dims[::-1], dtype=np.int32),
+            dst_grid_dims=np.asarray(self.dst_dims[::-1], dtype=np.int32))
+
+    def save(self, filename):
+        from pyremap_amd.io.mapfile import write_mapping
+        m = self.numpy()
+        write_mapping(filename, m['n_a'], m['n_b'], m['src_grid_dims'],
+                      m['dst_grid_dims'], m['row'], m['col'], m['S'],
+                      m['frac_b'])
+
+
+def _shuffle(row, col, S, gen):
+    """Mapping files are not row-sorted (multi-PET ESMF output)."""
+    torch = _torch()
+    perm = torch.randperm(row.shape[0], generator=gen, device=row.device)
+    return row[perm], col[perm], S[perm]
+
+
+def bilinear_map(src_dims, dst_dims, seed=0, device='cpu', shuffle=True):
+    """Tensor-product bilinear interpolation from a regular (ny, nx) source
+    grid to a regular (my, mx) destination grid covering the same box."""
+    torch = _torch()
+    ny, nx = src_dims
+    my, mx = dst_dims
+    dev = torch.device(device)
+
+    def axis(n_src, n_dst):
+        # destination point j sits at t in [0, n_src - 1]
+        t = torch.arange(n_dst, device=dev, dtype=torch.float64) * \
+            ((n_src - 1) / max(n_dst - 1, 1))
+        i0 = torch.clamp(t.floor().to(torch.int64), 0, max(n_src - 2, 0))
+        w1 = t - i0.to(torch.float64)
+        return i0, 1.0 - w1, w1
+
+    y0, wy0, wy1 = axis(ny, my)
+    x0, wx0, wx1 = axis(nx, mx)
+    rows = torch.arange(my * mx, device=dev, dtype=torch.int64)
+    jy = rows // mx
+    jx = rows - jy * mx
+    cols, vals = [], []
+    for dy, wy in ((0, wy0), (1, wy1)):
+        for dx, wx in ((0, wx0), (1, wx1)):
+            yy = torch.clamp(y0[jy] + dy, max=ny - 1)
+            xx = torch.clamp(x0[jx] + dx, max=nx - 1)
+            cols.append(yy * nx + xx)
+            vals.append(wy[jy] * wx[jx])
+    row = rows.repeat(4)
+    col = torch.cat(cols)
+    S = torch.cat(vals)
+    keep = S != 0.0          # edge points have exact zero weights: drop them
+    row, col, S = row[keep], col[keep], S[keep]
+    if shuffle:
+        row, col, S = _shuffle(row, col, S, _gen(seed, dev))
+    frac_b = torch.ones(my * mx, device=dev, dtype=torch.float64)
+    return SyntheticMap((row + 1).to(torch.int32), (col + 1).to(torch.int32),
+                        S, frac_b, ny * nx, my * mx, (ny, nx), (my, mx))
+
+
+def conservative_map(n_a, dst_dims, k_lo, k_hi, seed=0, device='cpu',
+                     empty_frac=0.3, signed=False, locality='raster',
+                     shuffle=True):
+    """Overlap-like weights from an unstructured n_a-cell mesh to a regular
+    destination grid (see the module docstring)."""
+    torch = _torch()
+    dev = torch.device(device)
+    gen = _gen(seed, dev)
+    my, mx = dst_dims
+    n_b = my * mx
+    # neighbourhood (in destination cells) large enough for k_hi draws
+    half_y, half_x = 1, 1
+    while (2 * half_y + 1) * (2 * half_x + 1) < k_hi:
+        if half_x <= half_y:
+            half_x += 1
+        else:
+            half_y += 1
+    win_x = 2 * half_x + 1
+    win = (2 * half_y + 1) * win_x
+
+    rows = torch.arange(n_b, device=dev, dtype=torch.int64)
+    jy = rows // mx
+    jx = rows - jy * mx
+    # blocky land mask: coarse random field, upsampled
+    by, bx = max(my // 15, 1), max(mx // 15, 1)
+    coarse = torch.rand((by, bx), generator=gen, device=dev) < empty_frac
+    land = coarse[(jy * by) // my, (jx * bx) // mx]
+    ocean = ~land
+    n_ocean = max(int(ocean.sum()), 1)
+    # The source mesh exists only where there is ocean: its cells are
+    # numbered along the row-major order of the ocean destination cells,
+    # n_a / n_ocean source cells per destination cell.
+    rank = torch.cumsum(ocean.to(torch.int64), 0) - 1
+    ratio = n_a / n_ocean
+
+    k = torch.randint(k_lo, k_hi + 1, (n_b,), generator=gen, device=dev)
+    k = torch.where(land, torch.zeros_like(k), k)
+
+    # a random order of the window per row; the first k entries are taken
+    chunks_row, chunks_col, chunks_val = [], [], []
+    step = max(1, (1 << 24) // win)      # bound temporary memory
+    for a in range(0, n_b, step):
+        b = min(a + step, n_b)
+        n = b - a
+        order = torch.rand((n, win), generator=gen, device=dev).argsort(dim=1)
+        take = torch.arange(win, device=dev).unsqueeze(0) < \
+            k[a:b].unsqueeze(1)
+        sel = order[take]                      # window slots, row-major
+        r = rows[a:b].unsqueeze(1).expand(n, win)[take]
+        if locality == 'raster':
+            oy = sel // win_x - half_y
+            ox = sel % win_x - half_x
+            qy = torch.clamp(jy[r] + oy, 0, my - 1)
+            qx = (jx[r] + ox) % mx
+            q = qy * mx + qx
+            q = torch.where(ocean[q], q, r)    # land neighbour: own cell
+            u = torch.rand(sel.shape[0], generator=gen, device=dev,
+                           dtype=torch.float64)
+            c = ((rank[q].to(torch.float64) + u) * ratio).to(torch.int64)
+            c = torch.clamp(c, 0, n_a - 1)
+        elif locality == 'none':
+            # same counts, source cells anywhere: worst-case gather
+            c = torch.randint(0, n_a, (sel.shape[0],), generator=gen,
+                              device=dev)
+        else:
+            raise ValueError(f'unknown locality {locality!r}')
+        w = torch.rand(sel.shape[0], generator=gen, device=dev,
+                       dtype=torch.float64) + 0.05
+        if signed:
+            # 2nd-order conservative: some negative gradient terms
+            neg = torch.rand(sel.shape[0], generator=gen, device=dev) < 0.25
+            w = torch.where(neg, -0.3 * w, w)
+        chunks_row.append(r)
+        chunks_col.append(c)
+        chunks_val.append(w)
+    row = torch.cat(chunks_row) if chunks_row else rows[:0]
+    col = torch.cat(chunks_col) if chunks_col else rows[:0]
+    S = torch.cat(chunks_val) if chunks_val else \
+        torch.zeros(0, device=dev, dtype=torch.float64)
+
+    # scale rows to sum to frac_b in (0, 1]
+    rowsum = torch.zeros(n_b, device=dev, dtype=torch.float64)
+    rowsum.index_add_(0, row, S)
+    frac_b = torch.rand(n_b, generator=gen, device=dev,
+                        dtype=torch.float64) * 0.9 + 0.1
+    frac_b = torch.where(k > 0, frac_b, torch.zeros_like(frac_b))
+    safe = torch.where(rowsum.abs() > 1e-3, rowsum, torch.ones_like(rowsum))
+    S = S * (frac_b / safe)[row]
+    if shuffle:
+        row, col, S = _shuffle(row, col, S, gen)
+    return SyntheticMap((row + 1).to(torch.int32), (col + 1).to(torch.int32),
+                        S, frac_b, n_a, n_b, (n_a,), (my, mx))
+
+
+def make_config(name, device='cpu', seed=None, locality='raster'):
+    """The synthetic mapping of one of :data:`CONFIGS`."""
+    cfg = CONFIGS[name]
+    if seed is None:
+        seed = sorted(CONFIGS).index(name)
+    if cfg['kind'] == 'bilinear':
+        return bilinear_map(cfg['src_dims'], cfg['dst_dims'], seed=seed,
+                            device=device)
+    return conservative_map(
+        cfg['n_a'], cfg['dst_dims'], cfg['k_lo'], cfg['k_hi'], seed=seed,
+        device=device, empty_frac=cfg.get('empty_frac', 0.3),
+        signed=cfg.get('signed', False), locality=locality)

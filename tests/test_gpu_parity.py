@@ -1,0 +1,424 @@
+"""
+GPU parity tests: the HIP path, called through the C ABI, against
+
+* the golden vectors produced by the reference's own code
+  (tests/golden/*.npz, see oracle/make_goldens.py), and
+* the CPU oracle (oracle/) on seeded inputs.
+
+Tolerance: NONE in the default mode -- fp64 results must be bit-identical
+(NaN placement identical; NaN payloads are not compared).  The opt-in FMA
+mode is checked at rtol 1e-13.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import assert_bitwise, golden_cases, golden_files, golden_map
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+
+FILES = golden_files()
+IDS = [os.path.basename(f) for f in FILES]
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'these tests need an MI355X'
+    from pyremap_amd import engine
+    engine.load_library()
+    return torch.device('cuda', 0)
+
+
+class _Desc:
+    def __init__(self, dims, sizes):
+        self.dims = list(dims)
+        self.dim_sizes = [int(s) for s in sizes]
+        self.coords = {}
+        self.mesh_name = 'golden'
+
+
+def _remapper_for(m, dev):
+    from pyremap_amd import Remapper
+    src = m['src_grid_dims'][::-1]
+    dst = m['dst_grid_dims'][::-1]
+    return Remapper.from_triplets(
+        m['row'], m['col'], m['S'], m['frac_b'],
+        _Desc([f's{i}' for i in range(len(src))], src),
+        _Desc([f'd{i}' for i in range(len(dst))], dst), device=dev)
+
+
+@pytest.mark.parametrize('path', FILES, ids=IDS)
+def test_device_csr_matches_scipy_golden(path, dev):
+    """remap_csr_from_coo == the reference's csr_matrix((S, (row, col)))."""
+    from pyremap_amd import engine
+    m = golden_map(path)
+    plan = engine.RemapPlan.from_triplets(
+        m['row'], m['col'], m['S'], m['frac_b'], int(m['n_a']),
+        int(m['n_b']), index_base=1, device=dev)
+    rowptr, col, val = plan.to_host_csr()
+    assert np.array_equal(rowptr, m['csr_indptr'])
+    assert np.array_equal(col, m['csr_indices'])
+    assert_bitwise(val, m['csr_data'], 'csr data')
+
+
+@pytest.mark.parametrize('path', FILES, ids=IDS)
+def test_remap_numpy_array_matches_reference_golden(path, dev):
+    """_remap_numpy_array on the GPU == the reference's, bit for bit."""
+    m = golden_map(path)
+    remapper = _remapper_for(m, dev)
+    n = 0
+    for i, arg, axes, thr, out, mask in golden_cases(path):
+        res = remapper.remap_array(arg, axes, thr)
+        assert isinstance(res, np.ma.MaskedArray)
+        assert res.shape == out.shape, f'case {i}'
+        assert np.array_equal(np.ma.getmaskarray(res), mask), f'case {i}'
+        assert_bitwise(res.filled(np.nan), out, f'{path} case {i}')
+        n += 1
+    assert n > 0
+
+
+@pytest.mark.parametrize('path', FILES[:3], ids=IDS[:3])
+def test_device_tensor_in_device_tensor_out(path, dev):
+    """A device tensor stays on the device; NaN marks the masked cells."""
+    m = golden_map(path)
+    remapper = _remapper_for(m, dev)
+    for i, arg, axes, thr, out, mask in golden_cases(path):
+        field = np.ma.getdata(arg)
+        is_ma = isinstance(arg, np.ma.MaskedArray)
+        if thr is not None and not is_ma and np.isnan(field).any():
+            continue  # 'plain' goldens: the array API would pick masked mode
+        if thr is not None and is_ma and not np.isnan(field).any():
+            continue  # MaskedArray without NaN: no device equivalent
+        x = torch.from_numpy(np.ascontiguousarray(field)).to(dev)
+        y = remapper.remap_array(x, axes, thr)
+        assert y.is_cuda and y.dtype == torch.float64
+        assert_bitwise(y.cpu().numpy(), out, f'{path} case {i}')
+
+
+def test_unstable_duplicates_limit(dev, golden_dir):
+    """Same documented limit as the oracle: see test_oracle_golden.py."""
+    from pyremap_amd import engine
+    m = golden_map(os.path.join(golden_dir, 'gx_unstable_dups.npz'))
+    plan = engine.RemapPlan.from_triplets(
+        m['row'], m['col'], m['S'], m['frac_b'], int(m['n_a']),
+        int(m['n_b']), index_base=1, device=dev)
+    rowptr, col, val = plan.to_host_csr()
+    assert np.array_equal(rowptr, m['csr_indptr'])
+    assert np.array_equal(col, m['csr_indices'])
+    np.testing.assert_allclose(val, m['csr_data'], rtol=1e-13, atol=2e-15)
+
+
+# ---------------------------------------------------------------------------
+# kernel variants against the oracle
+# ---------------------------------------------------------------------------
+
+def _random_problem(seed, n_a, n_b, lo, hi, long_rows=0):
+    from oracle import oracle
+    rng = np.random.default_rng(seed)
+    rows, cols, vals = [], [], []
+    for i in range(n_b):
+        if rng.random() < 0.1:
+            continue
+        k = int(rng.integers(lo, hi + 1))
+        if i < long_rows:
+            k = int(rng.integers(65, 200))
+        c = rng.choice(n_a, size=min(k, n_a), replace=False)
+        rows += [i] * len(c)
+        cols += c.tolist()
+        vals += (rng.standard_normal(len(c))).tolist()
+    row = np.asarray(rows, dtype=np.int32)
+    col = np.asarray(cols, dtype=np.int32)
+    S = np.asarray(vals)
+    frac_b = rng.random(n_b)
+    frac_b[rng.random(n_b) < 0.1] = 0.0
+    csr = oracle.coo_to_csr(row, col, S, n_b, n_a)
+    return row, col, S, frac_b, csr
+
+
+@pytest.fixture(scope='module')
+def problem(dev):
+    from pyremap_amd import engine
+    n_a, n_b = 700, 531
+    row, col, S, frac_b, csr = _random_problem(11, n_a, n_b, 1, 9,
+                                               long_rows=5)
+    plan = engine.RemapPlan.from_triplets(row, col, S, frac_b, n_a, n_b,
+                                          index_base=0, device=dev)
+    return dict(plan=plan, csr=csr, frac_b=frac_b, n_a=n_a, n_b=n_b)
+
+
+KS = [1, 2, 3, 7, 31, 32, 33, 64, 65, 127, 128, 129, 130, 256, 300, 512, 514]
+
+
+def _x(seed, n_a, K, dtype, nan_frac):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((n_a, K)).astype(dtype)
+    if nan_frac:
+        x[rng.random((n_a, K)) < nan_frac] = np.nan
+    return x
+
+
+@pytest.mark.parametrize('K', KS)
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+@pytest.mark.parametrize('mode', ['raw', 'fracb', 'masked'])
+def test_modes_and_widths_bitwise(problem, dev, K, dtype, mode):
+    from oracle import oracle
+    from pyremap_amd import engine
+    p = problem
+    x = _x(K, p['n_a'], K, dtype, 0.2 if mode == 'masked' else 0.0)
+    xd = torch.from_numpy(x).to(dev)
+    y = torch.empty((p['n_b'], K), dtype=torch.float64, device=dev)
+    mask = torch.empty((p['n_b'], K), dtype=torch.uint8, device=dev)
+    emode = {'raw': engine.MODE_RAW, 'fracb': engine.MODE_FRACB,
+             'masked': engine.MODE_MASKED}[mode]
+    engine.apply_strided(p['plan'], xd, y, n_batch=1, k_inner=K,
+                         x_row_stride=K, x_batch_stride=0, y_row_stride=K,
+                         y_batch_stride=0, mode=emode, threshold=0.3,
+                         mask_out=mask)
+    torch.cuda.synchronize()
+    x64 = x.astype(np.float64)
+    if mode == 'raw':
+        ref = oracle.csr_matvecs(p['csr'], x64)
+        ref_mask = np.zeros_like(ref, dtype=bool)
+    else:
+        ref, ref_mask = oracle.remap_flat(p['csr'], p['frac_b'], x64,
+                                          mode == 'masked', 0.3)
+        ref[ref_mask] = np.nan
+    assert np.array_equal(mask.cpu().numpy().astype(bool), ref_mask)
+    assert_bitwise(y.cpu().numpy(), ref, f'K={K} {mode}')
+
+
+TUNES = [
+    (1, 1, 1, 1, 1, 0), (1, 1, 1, 3, 2, 0), (1, 2, 1, 1, 1, 0),
+    (1, 2, 1, 4, 2, 0), (1, 2, 2, 2, 2, 0), (1, 2, 4, 1, 2, 0),
+    (1, 2, 4, 5, 1, 0), (2, 0, 0, 0, 0, 0),
+]
+
+
+@pytest.mark.parametrize('tune', TUNES)
+@pytest.mark.parametrize('K', [6, 64, 200, 1024])
+def test_launch_shapes_bitwise(problem, dev, tune, K):
+    """Every kernel family / tile shape / block map gives the same bits."""
+    from oracle import oracle
+    from pyremap_amd import engine
+    p = problem
+    x = _x(100 + K, p['n_a'], K, np.float64, 0.1)
+    xd = torch.from_numpy(x).to(dev)
+    for emode, masked in ((engine.MODE_FRACB, False),
+                          (engine.MODE_MASKED, True)):
+        y = torch.full((p['n_b'], K), 7.0, dtype=torch.float64, device=dev)
+        engine.apply_strided(p['plan'], xd, y, n_batch=1, k_inner=K,
+                             x_row_stride=K, x_batch_stride=0,
+                             y_row_stride=K, y_batch_stride=0, mode=emode,
+                             threshold=0.05, tune=tune)
+        ref, ref_mask = oracle.remap_flat(p['csr'], p['frac_b'], x, masked,
+                                          0.05)
+        ref[ref_mask] = np.nan
+        assert_bitwise(y.cpu().numpy(), ref, f'tune={tune} K={K}')
+
+
+def test_row_range_and_shards(problem, dev):
+    """Row shards (rebased CSR) and [row_begin, row_end) launches."""
+    from oracle import oracle
+    from pyremap_amd import engine
+    p = problem
+    K = 96
+    x = _x(5, p['n_a'], K, np.float64, 0.0)
+    xd = torch.from_numpy(x).to(dev)
+    ref, ref_mask = oracle.remap_flat(p['csr'], p['frac_b'], x, False, 0.0)
+    ref[ref_mask] = np.nan
+    # partial launch leaves the other rows untouched
+    y = torch.full((p['n_b'], K), -1.0, dtype=torch.float64, device=dev)
+    engine.apply_strided(p['plan'], xd, y, n_batch=1, k_inner=K,
+                         x_row_stride=K, x_batch_stride=0, y_row_stride=K,
+                         y_batch_stride=0, mode=engine.MODE_FRACB,
+                         row_begin=100, row_end=333)
+    got = y.cpu().numpy()
+    assert_bitwise(got[100:333], ref[100:333])
+    assert (got[:100] == -1.0).all() and (got[333:] == -1.0).all()
+    # shards: nnz-balanced contiguous row ranges that tile [0, n_b)
+    for world in (2, 3, 8):
+        bounds = p['plan'].shard_bounds(world)
+        assert bounds[0] == 0 and bounds[-1] == p['n_b']
+        assert all(a <= b for a, b in zip(bounds, bounds[1:]))
+        parts = []
+        for rank in range(world):
+            sh = p['plan'].shard(rank, world)
+            assert sh.row_offset == bounds[rank]
+            ys = engine.remap_tensor(sh, None, xd, [0], engine.MODE_FRACB)
+            assert ys.shape == (sh.n_b, K)
+            parts.append(ys.cpu().numpy())
+        assert_bitwise(np.concatenate(parts, axis=0), ref)
+
+
+def test_layouts_bitwise(dev):
+    """(T, n, L) in place, source axes last, two source axes, 4-D."""
+    from oracle import oracle
+    from pyremap_amd import engine
+    n_b = 12 * 9
+    row, col, S, frac_b, csr = _random_problem(3, 20 * 15, n_b, 1, 6)
+    plan = engine.RemapPlan.from_triplets(row, col, S, frac_b, 300, n_b,
+                                          index_base=0, device=dev)
+    rng = np.random.default_rng(0)
+    shapes = [
+        ((4, 300, 70), [1]), ((4, 300, 3), [1]), ((300,), [0]),
+        ((5, 6, 300), [2]), ((2, 20, 15, 66), [1, 2]), ((20, 15), [0, 1]),
+        ((3, 20, 15), [1, 2]), ((2, 3, 300, 2, 35), [2]),
+        ((20, 7, 15), [0, 2]),
+    ]
+    for shape, axes in shapes:
+        f = rng.standard_normal(shape)
+        fn = f.copy()
+        fn[rng.random(shape) < 0.15] = np.nan
+        for field, mode, thr in ((f, engine.MODE_FRACB, None),
+                                 (fn, engine.MODE_MASKED, 0.1)):
+            arg = field if thr is None else np.ma.masked_array(
+                field, np.isnan(field))
+            ref = oracle.remap_numpy_array(csr, frac_b, (12, 9), arg, axes,
+                                           thr).filled(np.nan)
+            y = engine.remap_tensor(plan, (12, 9),
+                                    torch.from_numpy(field).to(dev), axes,
+                                    mode, threshold=thr or 0.0)
+            assert tuple(y.shape) == ref.shape, (shape, axes)
+            assert y.is_contiguous()
+            assert_bitwise(y.cpu().numpy(), ref, f'{shape} {axes}')
+
+
+def test_fma_flag_is_close_not_identical(problem, dev):
+    from oracle import oracle
+    from pyremap_amd import engine
+    p = problem
+    K = 256
+    x = _x(9, p['n_a'], K, np.float64, 0.0)
+    xd = torch.from_numpy(x).to(dev)
+    y = torch.empty((p['n_b'], K), dtype=torch.float64, device=dev)
+    engine.apply_strided(p['plan'], xd, y, n_batch=1, k_inner=K,
+                         x_row_stride=K, x_batch_stride=0, y_row_stride=K,
+                         y_batch_stride=0, mode=engine.MODE_RAW,
+                         flags=engine.FLAG_FMA)
+    ref = oracle.csr_matvecs(p['csr'], x)
+    got = y.cpu().numpy()
+    scale = np.abs(ref).max()
+    np.testing.assert_allclose(got, ref, rtol=1e-13, atol=1e-13 * scale)
+    assert not np.array_equal(got, ref)
+
+
+def test_edge_cases(dev):
+    from pyremap_amd import engine
+    # no triplets at all: every row empty
+    plan = engine.RemapPlan.from_triplets(
+        np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0),
+        np.asarray([1.0, 0.0, 0.5]), 4, 3, index_base=1, device=dev)
+    assert plan.nnz == 0
+    x = torch.ones((4, 5), dtype=torch.float64, device=dev)
+    y = engine.remap_tensor(plan, (3,), x, [0], engine.MODE_FRACB).cpu()
+    assert (y[0] == 0).all() and torch.isnan(y[1]).all() and (y[2] == 0).all()
+    y = engine.remap_tensor(plan, (3,), x, [0], engine.MODE_MASKED,
+                            threshold=0.0).cpu()
+    assert torch.isnan(y).all()          # den = 0 is not > 0
+    # K = 0: nothing to do, shape still right
+    y = engine.remap_tensor(plan, (3,), x[:, :0], [0], engine.MODE_FRACB)
+    assert tuple(y.shape) == (3, 0)
+    # out-of-range triplets are rejected
+    with pytest.raises(ValueError, match='outside'):
+        engine.RemapPlan.from_triplets(
+            np.asarray([1, 9], np.int32), np.asarray([1, 1], np.int32),
+            np.ones(2), np.ones(3), 4, 3, index_base=1, device=dev)
+    # wrong source size
+    with pytest.raises(ValueError, match='n_a'):
+        engine.remap_tensor(plan, (3,), torch.ones((5, 2), device=dev,
+                                                   dtype=torch.float64),
+                            [0], engine.MODE_FRACB)
+    # integer fields are upcast like scipy does
+    xi = torch.arange(8, device=dev, dtype=torch.int32).reshape(4, 2)
+    plan2 = engine.RemapPlan.from_triplets(
+        np.asarray([1, 1, 2], np.int32), np.asarray([1, 4, 2], np.int32),
+        np.asarray([0.5, 0.25, 2.0]), np.asarray([1.0, 1.0]), 4, 2,
+        index_base=1, device=dev)
+    y = engine.remap_tensor(plan2, (2,), xi, [0], engine.MODE_FRACB).cpu()
+    assert y.tolist() == [[0.5 * 0 + 0.25 * 6, 0.5 * 1 + 0.25 * 7],
+                          [4.0, 6.0]]
+
+
+def test_dataset_level_matches_reference_golden(dev, golden_dir):
+    """Remapper.remap_numpy on a Dataset == the reference's _remap_numpy."""
+    import json
+    import sys
+
+    from pyremap_amd import DataArray, Dataset, Remapper
+    g = np.load(os.path.join(golden_dir, 'g3_dataset.npz'))
+    meta = json.loads(str(g['meta_json']))
+
+    def build_input(prefix, rec):
+        ds = Dataset(attrs=rec['attrs'])
+        for v in rec['data_vars']:
+            ds[v['name']] = DataArray(g[f'{prefix}{v["name"]}'],
+                                      dims=v['dims'], attrs=v['attrs'])
+        for v in rec['coords']:
+            ds._set_coord(v['name'], DataArray(g[f'{prefix}{v["name"]}'],
+                                               dims=v['dims'],
+                                               attrs=v['attrs']))
+        return ds
+
+    dst_coords = {
+        k: {'dims': v['dims'], 'data': g[f'dst_{k}'], 'attrs': v['attrs']}
+        for k, v in meta['dst_coords'].items()}
+
+    class Desc:
+        pass
+    src = Desc()
+    src.dims, src.dim_sizes = ['nCells'], [int(g['n_a'])]
+    dst = Desc()
+    dst.dims = ['lat', 'lon']
+    dst.dim_sizes = [len(g['dst_lat']), len(g['dst_lon'])]
+    dst.coords, dst.mesh_name = dst_coords, 'toy_6x8'
+
+    def remapper():
+        return Remapper.from_triplets(g['row'], g['col'], g['S'],
+                                      g['frac_b'], src, dst, device=dev)
+
+    ds = build_input('in__', meta['input'])
+    old = sys.argv
+    sys.argv = meta['argv']
+    try:
+        for tag, thr in (('thr', 0.01), ('nothr', None)):
+            out = remapper().remap_numpy(ds, thr)
+            rec = meta[f'dataset_{tag}']
+            assert list(out.data_vars) == [v['name']
+                                           for v in rec['data_vars']]
+            assert sorted(out.coords) == sorted(v['name']
+                                                for v in rec['coords'])
+            assert {k: str(v) for k, v in out.attrs.items()} == rec['attrs']
+            for v in rec['data_vars'] + rec['coords']:
+                var = out.variables[v['name']]
+                assert list(var.dims) == v['dims'], v['name']
+                assert str(var.dtype) == v['dtype'], v['name']
+                assert {k: str(a) for k, a in var.attrs.items()} == \
+                    v['attrs'], v['name']
+                assert_bitwise(var.values.astype(np.float64),
+                               g[f'{tag}__{v["name"]}'].astype(np.float64),
+                               f'{tag} {v["name"]}')
+        da = remapper().remap_numpy(ds['temperature'], 0.01)
+        rec = meta['dataarray_thr']
+        assert da.name == rec['name'] and list(da.dims) == rec['dims']
+        assert sorted(da.coords) == sorted(c['name'] for c in rec['coords'])
+        assert_bitwise(da.values, g['da__data'])
+    finally:
+        sys.argv = old
+
+    # partial source dims are dropped from a Dataset (2-D source)
+    src2 = Desc()
+    src2.dims, src2.dim_sizes = ['y', 'x'], [5, 10]
+    r2 = Remapper.from_triplets(g['p_map__row'], g['p_map__col'],
+                                g['p_map__S'], g['p_map__frac_b'], src2, dst,
+                                device=dev)
+    ds2 = build_input('p_in__', meta['partial_input'])
+    out2 = r2.remap_numpy(ds2, None)
+    rec2 = meta['partial_dataset']
+    assert list(out2.data_vars) == [v['name'] for v in rec2['data_vars']]
+    for v in rec2['data_vars']:
+        assert list(out2.variables[v['name']].dims) == v['dims']
+        assert_bitwise(out2.variables[v['name']].values,
+                       g[f'p_out__{v["name"]}'])
