@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define REMAP_ABI_VERSION 1
+#define REMAP_ABI_VERSION 3
 
 enum {
     REMAP_OK = 0,
@@ -82,6 +82,10 @@ typedef struct remap_csr {
     const int64_t *rowptr; /* (device) n_rows + 1                            */
     const int32_t *col;    /* (device) nnz, ascending within a row, 0-based  */
     const double *val;     /* (device) nnz                                   */
+    int64_t max_row_nnz;   /* entries of the longest row, 0 = unknown (lets
+                              the library pick kernels specialised for short
+                              rows; a wrong value only costs speed if too
+                              large, but MUST NOT be smaller than the truth) */
 } remap_csr;
 
 /*
@@ -115,10 +119,21 @@ typedef struct remap_apply_args {
     double threshold;       /* REMAP_MODE_MASKED only                        */
     uint8_t *mask_out;      /* (device) optional, addressed like Y; 1 where
                                the reference's result is masked (~ok)        */
+    const int32_t *row_order; /* (device) optional processing order: entry s
+                               (row_begin <= s < row_end) names the row that
+                               work slot s computes; must be a permutation of
+                               [row_begin, row_end).  Scheduling only -- the
+                               results do not depend on it.  Used to walk a
+                               2-D destination grid in tiles so neighbouring
+                               rows (which share source rows) run together
+                               and re-touches hit the XCD's L2.             */
     uint32_t flags;         /* REMAP_FLAG_*                                  */
     /* launch tuning, 0 = choose automatically:
      * tune[0] kernel family   1 = wave per row (lanes across K),
-     *                         2 = lane per (row, k) (small K)
+     *                         2 = lane per (row, k) (small K),
+     *                         3 = 1 software-pipelined,
+     *                         4 = 3 with a branch-free buffer-addressed
+     *                             memory stream
      * tune[1] doubles per lane per tile (1 or 2)
      * tune[2] K tiles per wave (1, 2 or 4)
      * tune[3] consecutive rows per wave

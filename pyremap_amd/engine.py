@@ -32,7 +32,7 @@ FLAG_CACHED_STORE = 2
 DTYPE_F64 = 0
 DTYPE_F32 = 1
 
-ABI_VERSION = 1
+ABI_VERSION = 3
 
 #: every symbol ``include/remap_hip.h`` declares
 EXPORTS = (
@@ -50,6 +50,7 @@ class _CSR(ctypes.Structure):
         ('rowptr', ctypes.c_void_p),
         ('col', ctypes.c_void_p),
         ('val', ctypes.c_void_p),
+        ('max_row_nnz', ctypes.c_int64),
     ]
 
 
@@ -71,6 +72,7 @@ class _ApplyArgs(ctypes.Structure):
         ('frac_b', ctypes.c_void_p),
         ('threshold', ctypes.c_double),
         ('mask_out', ctypes.c_void_p),
+        ('row_order', ctypes.c_void_p),
         ('flags', ctypes.c_uint32),
         ('tune', ctypes.c_int32 * 8),
     ]
@@ -198,6 +200,12 @@ class RemapPlan:
         self.n_b_global = int(n_b if n_b_global is None else n_b_global)
         self.nnz = int(val.shape[0])
         self.device = val.device
+        #: entries of the longest row (kernel selection)
+        self.max_row_nnz = int((rowptr[1:] - rowptr[:-1]).max()) \
+            if self.n_b > 0 else 0
+        #: optional int32 permutation of the rows: the order in which work
+        #: slots visit them (scheduling only; see set_row_order)
+        self.row_order = None
 
     # -- construction -------------------------------------------------------
     @classmethod
@@ -276,19 +284,8 @@ class RemapPlan:
         (entries + a constant per row for the output write), as a list of
         ``world_size + 1`` row indices.
         """
-        torch = _torch()
-        n_b = self.n_b
-        if world_size <= 1 or n_b == 0:
-            return [0] + [n_b] * max(world_size, 1)
-        rows = torch.arange(n_b + 1, device=self.device, dtype=torch.int64)
-        # cost(row range) ~ nnz + 2 * rows  (Y write + first-touch X)
-        work = self.rowptr + 2 * rows
-        total = int(work[-1])
-        targets = torch.tensor([total * r // world_size
-                                for r in range(1, world_size)],
-                               device=self.device, dtype=torch.int64)
-        cuts = torch.searchsorted(work, targets).cpu().tolist()
-        return [0] + [min(int(c), n_b) for c in cuts] + [n_b]
+        from pyremap_amd.parallel import row_shard_bounds
+        return row_shard_bounds(self.rowptr, world_size)
 
     def shard(self, rank, world_size):
         """The plan of rank ``rank`` of ``world_size`` (rows only)."""
@@ -303,6 +300,56 @@ class RemapPlan:
             self.col[j0:j1].contiguous(), self.val[j0:j1].contiguous(),
             self.frac_b[r0:r1].contiguous(),
             row_offset=self.row_offset + r0, n_b_global=self.n_b_global)
+
+    # -- scheduling ---------------------------------------------------------
+    def set_row_order(self, order):
+        """
+        Install (or clear, with ``None``) the processing order of the rows:
+        a permutation of ``range(n_b)``.  Results never depend on it.
+        """
+        torch = _torch()
+        if order is None:
+            self.row_order = None
+            return
+        order = torch.as_tensor(order).to(device=self.device,
+                                          dtype=torch.int32).contiguous()
+        if order.shape != (self.n_b,):
+            raise ValueError(f'row order must have {self.n_b} entries')
+        self.row_order = order
+
+    def set_grid_schedule(self, grid_dims, kind='tile', tile=(32, 64)):
+        """
+        Walk a 2-D destination grid (``grid_dims`` = C-order dims of the
+        WHOLE mapping's destination) in tiles or along a Morton curve, so
+        rows that are neighbours in either direction -- and therefore share
+        source rows -- are computed close together in time and on the same
+        XCD.  1-D destinations keep their natural order.
+        """
+        torch = _torch()
+        if grid_dims is None or len(grid_dims) != 2 or kind in (None, 'none'):
+            self.row_order = None
+            return
+        my, mx = (int(d) for d in grid_dims)
+        if my * mx != self.n_b_global:
+            raise ValueError(f'grid {grid_dims} does not hold '
+                             f'{self.n_b_global} cells')
+        rows = torch.arange(self.row_offset, self.row_offset + self.n_b,
+                            device=self.device, dtype=torch.int64)
+        jy = rows // mx
+        jx = rows - jy * mx
+        if kind == 'tile':
+            ty, tx = (int(t) for t in tile)
+            ntx = (mx + tx - 1) // tx
+            key = ((jy // ty) * ntx + jx // tx) * (ty * tx) + \
+                (jy % ty) * tx + jx % tx
+        elif kind == 'morton':
+            key = torch.zeros_like(rows)
+            for bit in range(16):
+                key |= ((jx >> bit) & 1) << (2 * bit)
+                key |= ((jy >> bit) & 1) << (2 * bit + 1)
+        else:
+            raise ValueError(f'unknown schedule {kind!r}')
+        self.row_order = torch.argsort(key, stable=True).to(torch.int32)
 
     # -- accounting ---------------------------------------------------------
     def algorithmic_bytes(self, K, x_itemsize=8, mode=MODE_FRACB):
@@ -352,6 +399,7 @@ def apply_strided(plan, X, Y, *, n_batch, k_inner, x_row_stride,
     args.A.rowptr = plan.rowptr.data_ptr()
     args.A.col = plan.col.data_ptr()
     args.A.val = plan.val.data_ptr()
+    args.A.max_row_nnz = plan.max_row_nnz
     args.row_begin = row_begin
     args.row_end = plan.n_b if row_end is None else row_end
     args.X = X.data_ptr()
@@ -367,6 +415,11 @@ def apply_strided(plan, X, Y, *, n_batch, k_inner, x_row_stride,
     args.frac_b = plan.frac_b.data_ptr() if mode == MODE_FRACB else None
     args.threshold = float(threshold)
     args.mask_out = mask_out.data_ptr() if mask_out is not None else None
+    order = plan.row_order
+    if order is not None and (row_begin != 0 or
+                              args.row_end != plan.n_b):
+        order = None    # the stored order permutes the whole row range
+    args.row_order = order.data_ptr() if order is not None else None
     args.flags = flags
     if tune:
         for i, v in enumerate(tune):

@@ -194,6 +194,14 @@ TUNES = [
     (1, 1, 1, 1, 1, 0), (1, 1, 1, 3, 2, 0), (1, 2, 1, 1, 1, 0),
     (1, 2, 1, 4, 2, 0), (1, 2, 2, 2, 2, 0), (1, 2, 4, 1, 2, 0),
     (1, 2, 4, 5, 1, 0), (2, 0, 0, 0, 0, 0),
+    # software-pipelined family: rows per wave 1..32, both unrolls
+    (3, 1, 1, 1, 2, 0), (3, 1, 1, 7, 1, 0), (3, 2, 1, 8, 2, 0),
+    (3, 2, 2, 5, 2, 4), (3, 2, 2, 16, 2, 8), (3, 2, 4, 3, 2, 4),
+    (3, 2, 4, 32, 1, 8), (3, 0, 0, 0, 0, 0),
+    # branch-free buffer-addressed family
+    (4, 1, 1, 1, 2, 0), (4, 1, 1, 9, 1, 0), (4, 2, 1, 8, 2, 0),
+    (4, 2, 2, 5, 2, 4), (4, 2, 2, 16, 2, 8), (4, 2, 4, 3, 2, 4),
+    (4, 2, 4, 32, 1, 0), (4, 0, 0, 0, 0, 0),
 ]
 
 

@@ -1,0 +1,137 @@
+#!/usr/bin/env python3
+"""
+Interleaved A/B sweep of launch shapes for one workload (GPU box only).
+
+    python tools/sweep.py --workload config3 --tunes "0;1,2,1,4,2;1,2,2,4,2"
+
+Variants are timed round-robin in ONE process (several rounds, HIP events on
+the launch stream), the table reports median / min per variant -- the
+methodology of cdna_hip_programming.md section 5.4 rule 24.
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import torch  # noqa: E402
+
+from pyremap_amd import engine, synthetic  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--workload', default='config3')
+    ap.add_argument('--fields', type=int, default=None)
+    ap.add_argument('--mode', default='fracb')
+    ap.add_argument('--locality', default='raster')
+    ap.add_argument('--tunes', default='0')
+    ap.add_argument('--flags', default='0')
+    ap.add_argument('--rounds', type=int, default=7)
+    ap.add_argument('--reps', type=int, default=10)
+    ap.add_argument('--sets', type=int, default=2)
+    ap.add_argument('--dtype', default='f64')
+    ap.add_argument('--pmc', type=int, default=0,
+                    help='counter mode: launch each variant N times in '
+                         'order, no timing (run under rocprofv3 --pmc)')
+    ap.add_argument('--orders', default='none',
+                    help="';'-separated: none | morton | tile:TYxTX")
+    args = ap.parse_args()
+    dev = torch.device('cuda', 0)
+    cfg = synthetic.CONFIGS[args.workload]
+    K = args.fields or cfg['K']
+    m = synthetic.make_config(args.workload, device=dev,
+                              locality=args.locality)
+    plan = engine.RemapPlan.from_triplets(m.row, m.col, m.S, m.frac_b, m.n_a,
+                                          m.n_b, device=dev)
+    mode = {'fracb': engine.MODE_FRACB, 'masked': engine.MODE_MASKED,
+            'raw': engine.MODE_RAW}[args.mode]
+    dt = torch.float64 if args.dtype == 'f64' else torch.float32
+    xs = [torch.randn((m.n_a, K), device=dev, dtype=dt)
+          for _ in range(args.sets)]
+    if args.mode == 'masked':
+        for x in xs:
+            x[torch.rand(m.n_a, device=dev) < 0.25, :] = float('nan')
+    ys = [torch.empty((m.n_b, K), device=dev, dtype=torch.float64)
+          for _ in range(args.sets)]
+    variants = []
+    orders = {}
+    for o in args.orders.split(';'):
+        if o == 'none':
+            orders[o] = None
+        elif o == 'morton':
+            plan.set_grid_schedule(m.dst_dims, 'morton')
+            orders[o] = plan.row_order
+        else:
+            ty, tx = o.split(':')[1].split('x')
+            plan.set_grid_schedule(m.dst_dims, 'tile', (int(ty), int(tx)))
+            orders[o] = plan.row_order
+    for o in orders:
+        for fl in args.flags.split(';'):
+            for t in args.tunes.split(';'):
+                tune = [int(v) for v in t.split(',')] if t != '0' else None
+                variants.append((int(fl), tune, o))
+    bytes_alg = plan.algorithmic_bytes(K, xs[0].element_size(), mode)
+    print(f'{args.workload}: n_a={m.n_a} n_b={m.n_b} nnz={plan.nnz} K={K} '
+          f'bytes_alg={bytes_alg / 1e9:.3f} GB mode={args.mode}')
+
+    def launch(v, i):
+        fl, tune, o = v
+        plan.row_order = orders[o]
+        s = i % args.sets
+        engine.apply_strided(plan, xs[s], ys[s], n_batch=1, k_inner=K,
+                             x_row_stride=K, x_batch_stride=0,
+                             y_row_stride=K, y_batch_stride=0, mode=mode,
+                             threshold=0.01, flags=fl, tune=tune)
+
+    if args.pmc:
+        for vi, v in enumerate(variants):
+            print(f'PMCVARIANT {vi} {v[2]} flags={v[0]} tune={v[1]}')
+            for i in range(args.pmc):
+                launch(v, i)
+            torch.cuda.synchronize()
+        return
+    times = {i: [] for i in range(len(variants))}
+    ref = None
+    for vi, v in enumerate(variants):
+        try:
+            launch(v, 0)
+            torch.cuda.synchronize()
+        except Exception as exc:  # noqa: BLE001
+            print(f'variant {v}: {exc}')
+            times[vi] = None
+            continue
+        if not (v[0] & 1) and not (v[1] and len(v[1]) > 6 and v[1][6]):
+            if ref is None:
+                ref = ys[0].clone()
+            else:
+                same = torch.equal(torch.nan_to_num(ys[0], nan=1e300),
+                                   torch.nan_to_num(ref, nan=1e300))
+                assert same, f'variant {v} changes the result'
+    for rnd in range(args.rounds):
+        for vi, v in enumerate(variants):
+            if times[vi] is None:
+                continue
+            launch(v, 1)
+            a = torch.cuda.Event(enable_timing=True)
+            b = torch.cuda.Event(enable_timing=True)
+            a.record()
+            for i in range(args.reps):
+                launch(v, i)
+            b.record()
+            torch.cuda.synchronize()
+            times[vi].append(a.elapsed_time(b) / args.reps)
+    print(f'{"order":<12} {"flags":>5} {"tune":<22} {"med ms":>8} {"min ms":>8} '
+          f'{"GB/s(med)":>10} {"%8TB/s":>7}')
+    for vi, v in enumerate(variants):
+        if not times[vi]:
+            continue
+        ts = sorted(times[vi])
+        med, mn = ts[len(ts) // 2], ts[0]
+        gbps = bytes_alg / (med * 1e-3) / 1e9
+        print(f'{v[2]:<12} {v[0]:>5} {str(v[1]):<22} {med:8.4f} {mn:8.4f} '
+              f'{gbps:10.1f} {gbps / 80:7.1f}')
+
+
+if __name__ == '__main__':
+    main()
