@@ -311,6 +311,43 @@ def cpu_baseline(full, m, field, mode, budget_s):
     return out
 
 
+def pcie_inclusive(args):
+    """
+    The same workload when the boundary hands over HOST buffers (numpy in,
+    numpy out through Remapper.remap_array): upload of X, launch, download
+    of Y and of the byte mask.  Reported for DESIGN.md; never `value`.
+    """
+    import numpy as np
+    import torch
+
+    from pyremap_amd import Remapper, synthetic
+    cfg = synthetic.CONFIGS['config3']
+    m = synthetic.make_config('config3', device='cuda')
+
+    class Desc:
+        pass
+    src, dst = Desc(), Desc()
+    src.dims, src.dim_sizes = ['nCells'], [m.n_a]
+    dst.dims, dst.dim_sizes = ['lat', 'lon'], list(m.dst_dims)
+    dst.coords, dst.mesh_name = {}, 'bench'
+    mm = m.numpy()
+    r = Remapper.from_triplets(mm['row'], mm['col'], mm['S'], mm['frac_b'],
+                               src, dst, device='cuda')
+    x = np.random.default_rng(0).standard_normal((m.n_a, cfg['K']))
+    r.remap_array(x[:, :8], [0])                     # loads the weights
+    times = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        y = r.remap_array(x, [0])
+        times.append(time.perf_counter() - t0)
+    t = min(times)
+    return dict(seconds=t, cell_fields_per_s=m.n_b * cfg['K'] / t,
+                bytes_over_pcie=x.nbytes + y.data.nbytes + y.mask.nbytes,
+                note='numpy in -> numpy masked array out, pageable host '
+                     'memory, best of 3')
+
+
 def load_traffic(name, K, mode):
     """PMC-measured HBM bytes per launch, from a committed rocprofv3 run."""
     path = os.path.join(_REPO, 'profiles', f'traffic_{name}.json')
@@ -370,6 +407,11 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as exc:  # noqa: BLE001 - report, keep the line
                 extra[tag] = {'error': f'{type(exc).__name__}: {exc}'}
+        try:
+            extra['host_buffers_pcie_inclusive'] = pcie_inclusive(args)
+        except Exception as exc:  # noqa: BLE001
+            extra['host_buffers_pcie_inclusive'] = {
+                'error': f'{type(exc).__name__}: {exc}'}
 
     if rank != 0:
         if dist is not None:

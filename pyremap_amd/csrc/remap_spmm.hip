@@ -1227,9 +1227,11 @@ typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(kBlock) void stream_copy_kernel(
     u4 *__restrict__ dst, const u4 *__restrict__ src, size_t n16)
 {
-    const size_t stride = (size_t)gridDim.x * kBlock;
-    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n16;
-         i += stride)
+    // one 16-byte element per lane, blocks walk the buffer in dispatch order
+    // (measured faster on MI355X than a grid-stride loop: 6.2-6.5 vs
+    // 4.6-5.7 TB/s, tools/hbm_ceiling.hip)
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n16)
         __builtin_nontemporal_store(__builtin_nontemporal_load(src + i),
                                     dst + i);
 }
@@ -1245,9 +1247,10 @@ int stream_copy(void *dst, const void *src, size_t bytes, hipStream_t stream)
                     "remap_stream_copy: needs 16-byte aligned buffers and a "
                     "multiple of 16 bytes");
     const size_t n16 = bytes / 16;
-    size_t grid = (n16 + kBlock - 1) / kBlock;
-    if (grid > 256 * 8)
-        grid = 256 * 8;  // 8 blocks per CU, grid-stride the rest
+    const size_t grid = (n16 + kBlock - 1) / kBlock;
+    if (grid > 0x7fffffffull)
+        return fail(REMAP_ERR_UNSUPPORTED,
+                    "remap_stream_copy: more than 2^31 blocks");
     hipLaunchKernelGGL(stream_copy_kernel, dim3((uint32_t)grid), dim3(kBlock),
                        0, stream, static_cast<u4 *>(dst),
                        static_cast<const u4 *>(src), n16);

@@ -7,7 +7,7 @@ src_grid_rank, dst_grid_rank`` and the variables ``src_grid_dims,
 dst_grid_dims, col, row, S, frac_b`` (:89-137, :270).
 Here the same members are read without xarray:
 
-* NetCDF-3 (CDF-1 / CDF-2) with ``scipy.io.netcdf_file``;
+* NetCDF-3 (CDF-1 / CDF-2 / CDF-5) with :mod:`pyremap_amd.io.netcdf3`;
 * NetCDF-4 / HDF5 (what ESMF writes with ``--netcdf4``,
   ``build_map.py:166``) with ``h5py`` or ``netCDF4`` when importable;
 * ``.npz`` with the same variable names (handy for synthetic maps).
@@ -17,6 +17,11 @@ import os
 import numpy as np
 
 REQUIRED = ('src_grid_dims', 'dst_grid_dims', 'col', 'row', 'S', 'frac_b')
+
+
+def _native(a):
+    a = np.asarray(a)
+    return np.ascontiguousarray(a, dtype=a.dtype.newbyteorder('='))
 
 
 class MappingFile:
@@ -29,9 +34,9 @@ class MappingFile:
         #: as stored in the file: Fortran order
         self.src_grid_dims = np.asarray(src_grid_dims, dtype=np.int64)
         self.dst_grid_dims = np.asarray(dst_grid_dims, dtype=np.int64)
-        #: 1-based, unsorted, duplicates allowed
-        self.row = np.asarray(row)
-        self.col = np.asarray(col)
+        #: 1-based, unsorted, duplicates allowed (native byte order)
+        self.row = _native(row)
+        self.col = _native(col)
         self.S = np.asarray(S, dtype=np.float64)
         self.frac_b = np.asarray(frac_b, dtype=np.float64)
 
@@ -61,11 +66,7 @@ def read_mapping(filename):
     if magic[:2] == b'PK' or filename.endswith('.npz'):
         return _read_npz(filename)
     if magic[:3] == b'CDF':
-        if magic[3] in (1, 2):
-            return _read_netcdf3(filename)
-        raise NotImplementedError(
-            f'{filename}: NetCDF-3 CDF-{magic[3]} mapping files are not '
-            f'supported yet')
+        return _read_netcdf3(filename)
     if magic == b'\x89HDF\r\n\x1a\n':
         return _read_hdf5(filename)
     raise ValueError(f'{filename}: not a NetCDF, HDF5 or npz mapping file')
@@ -86,15 +87,17 @@ def _read_npz(filename):
 
 
 def _read_netcdf3(filename):
-    from scipy.io import netcdf_file
-    with netcdf_file(filename, 'r', mmap=False) as nc:
-        missing = [k for k in REQUIRED if k not in nc.variables]
-        if missing:
-            raise ValueError(f'{filename}: missing variables {missing}')
-        get = {k: np.array(nc.variables[k][:]) for k in REQUIRED}
-        n_a = nc.dimensions['n_a']
-        n_b = nc.dimensions['n_b']
-    return MappingFile(n_a, n_b, get['src_grid_dims'], get['dst_grid_dims'],
+    from pyremap_amd.io import netcdf3
+    nc = netcdf3.read(filename)
+    missing = [k for k in REQUIRED if k not in nc.variables]
+    if missing:
+        raise ValueError(f'{filename}: missing variables {missing}')
+    get = {k: nc.variables[k].data for k in REQUIRED}
+    for dim in ('n_a', 'n_b'):
+        if dim not in nc.dimensions:
+            raise ValueError(f'{filename}: missing dimension {dim}')
+    return MappingFile(nc.dimensions['n_a'], nc.dimensions['n_b'],
+                       get['src_grid_dims'], get['dst_grid_dims'],
                        get['row'], get['col'], get['S'], get['frac_b'])
 
 
@@ -148,22 +151,18 @@ def write_mapping(filename, n_a, n_b, src_grid_dims, dst_grid_dims, row, col,
                  src_grid_dims=src_grid_dims, dst_grid_dims=dst_grid_dims,
                  row=row, col=col, S=S, frac_b=frac_b)
         return
-    from scipy.io import netcdf_file
-    with netcdf_file(filename, 'w', version=2) as nc:
-        nc.createDimension('n_a', int(n_a))
-        nc.createDimension('n_b', int(n_b))
-        nc.createDimension('n_s', int(S.shape[0]))
-        nc.createDimension('src_grid_rank', int(src_grid_dims.shape[0]))
-        nc.createDimension('dst_grid_rank', int(dst_grid_dims.shape[0]))
-        for name, data, dim in (
-                ('src_grid_dims', src_grid_dims, 'src_grid_rank'),
-                ('dst_grid_dims', dst_grid_dims, 'dst_grid_rank'),
-                ('col', col, 'n_s'), ('row', row, 'n_s'), ('S', S, 'n_s'),
-                ('frac_b', frac_b, 'n_b')):
-            var = nc.createVariable(name, data.dtype, (dim,))
-            var[:] = data
-        # keep n_a alive as a used dimension, as in ESMF files
-        area_a = nc.createVariable('area_a', np.float64, ('n_a',))
-        area_a[:] = np.zeros(int(n_a))
-        for key, value in (attrs or {}).items():
-            setattr(nc, key, value)
+    from pyremap_amd.io import netcdf3
+    dims = {'n_a': int(n_a), 'n_b': int(n_b), 'n_s': int(S.shape[0]),
+            'src_grid_rank': int(src_grid_dims.shape[0]),
+            'dst_grid_rank': int(dst_grid_dims.shape[0])}
+    variables = [
+        netcdf3.Variable('src_grid_dims', ('src_grid_rank',), src_grid_dims),
+        netcdf3.Variable('dst_grid_dims', ('dst_grid_rank',), dst_grid_dims),
+        netcdf3.Variable('col', ('n_s',), col),
+        netcdf3.Variable('row', ('n_s',), row),
+        netcdf3.Variable('S', ('n_s',), S),
+        netcdf3.Variable('frac_b', ('n_b',), frac_b),
+        # keeps n_a a used dimension, as in ESMF files
+        netcdf3.Variable('area_a', ('n_a',), np.zeros(int(n_a))),
+    ]
+    netcdf3.write(filename, dims, variables, attrs=attrs or {}, version=2)

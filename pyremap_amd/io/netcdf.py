@@ -1,0 +1,233 @@
+"""
+Dataset-level NetCDF IO for the file -> file path, without xarray/netCDF4.
+
+``open_dataset`` plays the role of ``xarray.open_dataset`` (CF mask-and-scale
+decoding: ``_FillValue`` / ``missing_value`` become NaN, ``scale_factor`` /
+``add_offset`` are applied) and ``write_netcdf`` that of the reference's
+``pyremap.utility.write_netcdf`` (``utility.py:8-72``): a ``_FillValue`` is
+written only for numeric variables that actually hold NaNs, with netCDF4's
+default fill value for the dtype (:38-51).
+
+Classic formats (CDF-1/2/5) are handled by :mod:`pyremap_amd.io.netcdf3`;
+NetCDF-4/HDF5 input is read when ``h5py`` is importable.
+"""
+import os
+from collections import OrderedDict
+
+import numpy as np
+
+from pyremap_amd import xr_lite
+from pyremap_amd.io import netcdf3
+
+#: netCDF4.default_fillvals (netCDF4 is not installed here)
+DEFAULT_FILLVALS = {
+    'S1': b'\x00', 'i1': -127, 'u1': 255, 'i2': -32767, 'u2': 65535,
+    'i4': -2147483647, 'u4': 4294967295, 'i8': -9223372036854775806,
+    'u8': 18446744073709551614, 'f4': 9.969209968386869e+36,
+    'f8': 9.969209968386869e+36,
+}
+
+_HDF5_MAGIC = b'\x89HDF\r\n\x1a\n'
+
+
+def file_format(filename):
+    with open(filename, 'rb') as f:
+        magic = f.read(8)
+    if magic[:3] == b'CDF':
+        return {1: 'NETCDF3_CLASSIC', 2: 'NETCDF3_64BIT',
+                5: 'NETCDF3_64BIT_DATA'}.get(magic[3])
+    if magic == _HDF5_MAGIC:
+        return 'NETCDF4'
+    return None
+
+
+def _decode(data, attrs):
+    """CF mask-and-scale decoding, as xarray applies by default."""
+    attrs = OrderedDict(attrs)
+    encoding = {}
+    if data.dtype.kind not in 'fiu':
+        return data, attrs, encoding
+    fills = []
+    for key in ('_FillValue', 'missing_value'):
+        if key in attrs:
+            encoding[key] = attrs.pop(key)
+            fills.extend(np.atleast_1d(encoding[key]).tolist())
+    scale = attrs.pop('scale_factor', None)
+    offset = attrs.pop('add_offset', None)
+    if fills or scale is not None or offset is not None:
+        if data.dtype.kind != 'f':
+            data = data.astype(np.float32 if data.dtype.itemsize <= 2
+                               else np.float64)
+        else:
+            data = np.array(data, copy=True)
+        for fv in fills:
+            fv = np.asarray(fv).astype(data.dtype)
+            if not np.isnan(fv):
+                data[data == fv] = np.nan
+        if scale is not None:
+            encoding['scale_factor'] = scale
+            data = data * np.asarray(scale, dtype=data.dtype)
+        if offset is not None:
+            encoding['add_offset'] = offset
+            data = data + np.asarray(offset, dtype=data.dtype)
+    return data, attrs, encoding
+
+
+def open_dataset(filename, mask_and_scale=True):
+    """Read ``filename`` into a :class:`pyremap_amd.Dataset`."""
+    if not os.path.exists(filename):
+        raise FileNotFoundError(filename)
+    fmt = file_format(filename)
+    if fmt is None:
+        raise ValueError(f'{filename}: not a NetCDF file')
+    if fmt == 'NETCDF4':
+        return _open_hdf5(filename, mask_and_scale)
+    nc = netcdf3.read(filename)
+    ds = xr_lite.Dataset(attrs=nc.attrs)
+    ds.encoding = {
+        'format': fmt,
+        'unlimited_dims': [n for n, length in nc.dimensions.items()
+                           if length is None],
+        'dim_order': list(nc.dimensions),
+    }
+    for name, var in nc.variables.items():
+        data, attrs, enc = (var.data, var.attrs, {})
+        if mask_and_scale:
+            data, attrs, enc = _decode(data, attrs)
+        da = xr_lite.DataArray(data, dims=var.dims, name=name, attrs=attrs)
+        da.encoding = enc
+        if var.dims == (name,):
+            ds._set_coord(name, da)
+        else:
+            ds[name] = da
+        ds.variables[name].encoding = enc
+    return ds
+
+
+def _open_hdf5(filename, mask_and_scale):
+    try:
+        import h5py
+    except ImportError as exc:
+        raise ImportError(
+            f'{filename} is NetCDF-4/HDF5: reading it needs h5py, which is '
+            f'not installed; convert it to a classic format (nccopy -k '
+            f'cdf5) or install h5py') from exc
+    ds = xr_lite.Dataset()
+    ds.encoding = {'format': 'NETCDF4', 'unlimited_dims': [],
+                   'dim_order': []}
+    with h5py.File(filename, 'r') as h5:
+        for key, value in h5.attrs.items():
+            if not key.startswith('_'):
+                ds.attrs[key] = value.decode() if isinstance(value, bytes) \
+                    else value
+        scales = {}
+        for name, obj in h5.items():
+            if isinstance(obj, h5py.Dataset) and obj.attrs.get(
+                    'CLASS', b'') == b'DIMENSION_SCALE':
+                scales[obj.id.__hash__()] = name
+        for name, obj in h5.items():
+            if not isinstance(obj, h5py.Dataset):
+                continue
+            is_scale = obj.attrs.get('CLASS', b'') == b'DIMENSION_SCALE'
+            pure_dim = is_scale and b'This is a netCDF dimension' in \
+                obj.attrs.get('NAME', b'')
+            if pure_dim:
+                continue
+            dims = []
+            for axis, dim in enumerate(obj.dims):
+                dims.append(os.path.basename(dim[0].name) if len(dim)
+                            else f'{name}_dim{axis}')
+            if is_scale and not dims:
+                dims = [name]
+            attrs = OrderedDict()
+            for key, value in obj.attrs.items():
+                if key in ('DIMENSION_LIST', 'REFERENCE_LIST', 'CLASS',
+                           'NAME', '_Netcdf4Dimid', '_Netcdf4Coordinates'):
+                    continue
+                if isinstance(value, bytes):
+                    value = value.decode()
+                elif isinstance(value, np.ndarray) and value.size == 1:
+                    value = value.reshape(-1)[0]
+                attrs[key] = value
+            data = np.array(obj[...])
+            enc = {}
+            if mask_and_scale:
+                data, attrs, enc = _decode(data, attrs)
+            da = xr_lite.DataArray(data, dims=dims, name=name, attrs=attrs)
+            if tuple(dims) == (name,):
+                ds._set_coord(name, da)
+            else:
+                ds[name] = da
+            ds.variables[name].encoding = enc
+    return ds
+
+
+def write_netcdf(ds, filename, format='NETCDF3_64BIT', fillvalues=None,
+                 unlimited_dims=None):
+    """
+    Write a Dataset with netCDF4-style fill values (reference
+    ``utility.write_netcdf``): numeric variables holding NaNs get
+    ``_FillValue`` = the default fill of their dtype and have their NaNs
+    stored as that value; all other variables get no ``_FillValue``.
+    """
+    if format not in netcdf3.FORMATS:
+        raise NotImplementedError(
+            f'format {format!r}: only the classic formats '
+            f'{sorted(netcdf3.FORMATS)} can be written without netCDF4')
+    version = netcdf3.FORMATS[format]
+    if fillvalues is None:
+        fillvalues = DEFAULT_FILLVALS
+    if unlimited_dims is None:
+        unlimited_dims = getattr(ds, 'encoding', {}).get('unlimited_dims', [])
+    names = list(ds.data_vars) + list(ds.coords)
+    dimensions = OrderedDict()
+    out_vars = []
+    for name in names:
+        var = ds.variables[name]
+        data = np.asarray(var.values)
+        attrs = OrderedDict((k, v) for k, v in var.attrs.items()
+                            if k != '_FillValue')
+        if data.dtype.kind == 'f' and np.isnan(data).any():
+            key = f'{data.dtype.kind}{data.dtype.itemsize}'
+            if key in fillvalues:
+                fv = np.asarray(fillvalues[key]).astype(data.dtype)
+                data = np.where(np.isnan(data), fv, data)
+                attrs['_FillValue'] = fv
+        if data.dtype.kind in 'SU' and data.dtype.itemsize != 1:
+            # fixed-width strings -> char array with a string dimension
+            raw = np.char.encode(data, 'utf-8') if data.dtype.kind == 'U' \
+                else data
+            width = raw.dtype.itemsize
+            data = raw.reshape(raw.shape + (1,)).view('S1').reshape(
+                raw.shape + (width,))
+            dims = tuple(var.dims) + (f'string{width}',)
+        else:
+            dims = tuple(var.dims)
+        for dim, size in zip(dims, data.shape):
+            if dim in unlimited_dims:
+                dimensions.setdefault(dim, None)
+            else:
+                dimensions.setdefault(dim, int(size))
+        out_vars.append(netcdf3.Variable(name, dims, data, attrs))
+    # the record dimension must lead its variables; demote it otherwise
+    for dim in [d for d, length in dimensions.items() if length is None]:
+        if any(dim in v.dims[1:] for v in out_vars):
+            size = next(v.data.shape[v.dims.index(dim)] for v in out_vars
+                        if dim in v.dims)
+            dimensions[dim] = int(size)
+    if sum(1 for length in dimensions.values() if length is None) > 1:
+        first = True
+        for dim, length in list(dimensions.items()):
+            if length is None:
+                if not first:
+                    size = next(v.data.shape[v.dims.index(dim)]
+                                for v in out_vars if dim in v.dims)
+                    dimensions[dim] = int(size)
+                first = False
+    attrs = OrderedDict()
+    for key, value in ds.attrs.items():
+        attrs[key] = value if isinstance(value, (str, bytes, np.ndarray,
+                                                 int, float, np.generic)) \
+            else str(value)
+    netcdf3.write(filename, dimensions, out_vars, attrs=attrs,
+                  version=version)

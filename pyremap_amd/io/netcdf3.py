@@ -1,0 +1,416 @@
+"""
+Self-contained reader / writer for the NetCDF classic formats:
+CDF-1 (``NETCDF3_CLASSIC``), CDF-2 (``NETCDF3_64BIT`` offsets) and CDF-5
+(``NETCDF3_64BIT_DATA``, the reference's default for SCRIP files,
+``pyremap/remapper/remapper.py:129``).
+
+The reference does all file IO through xarray + netCDF4
+(``remap_numpy.py:88``, ``utility.py:53-67``); neither exists on the MI355X
+boxes, and the NCO tools behind ``ncremap`` do not either, so the file ->
+file path of this package (``remapper/remap_file.py``) reads and writes
+classic-format files itself.  Only numpy is needed.
+
+Format reference: the NetCDF classic format specification (header =
+magic, numrecs, dim_list, gatt_list, var_list; big-endian; values padded to
+4 bytes; record variables interleaved per record).
+"""
+import struct
+from collections import OrderedDict
+
+import numpy as np
+
+NC_DIMENSION = 10
+NC_VARIABLE = 11
+NC_ATTRIBUTE = 12
+
+# nc_type -> big-endian numpy dtype
+_TYPES = {
+    1: np.dtype('>i1'), 2: np.dtype('S1'), 3: np.dtype('>i2'),
+    4: np.dtype('>i4'), 5: np.dtype('>f4'), 6: np.dtype('>f8'),
+    # CDF-5 only
+    7: np.dtype('>u1'), 8: np.dtype('>u2'), 9: np.dtype('>u4'),
+    10: np.dtype('>i8'), 11: np.dtype('>u8'),
+}
+_CODES = {
+    ('i', 1): 1, ('S', 1): 2, ('i', 2): 3, ('i', 4): 4, ('f', 4): 5,
+    ('f', 8): 6, ('u', 1): 7, ('u', 2): 8, ('u', 4): 9, ('i', 8): 10,
+    ('u', 8): 11,
+}
+
+FORMATS = {'NETCDF3_CLASSIC': 1, 'NETCDF3_64BIT': 2,
+           'NETCDF3_64BIT_OFFSET': 2, 'NETCDF3_64BIT_DATA': 5}
+
+
+def _pad4(n):
+    return (n + 3) // 4 * 4
+
+
+class Variable:
+    """A variable of a classic-format file."""
+
+    def __init__(self, name, dims, data, attrs=None, is_record=False):
+        self.name = name
+        self.dims = tuple(dims)
+        self.data = data
+        self.attrs = OrderedDict(attrs) if attrs else OrderedDict()
+        self.is_record = is_record
+
+    @property
+    def dtype(self):
+        return self.data.dtype
+
+    @property
+    def shape(self):
+        return self.data.shape
+
+
+class NetCDF3File:
+    """Dimensions, global attributes and variables of one file."""
+
+    def __init__(self):
+        self.version = 2
+        self.dimensions = OrderedDict()   # name -> length (None = record)
+        self.attrs = OrderedDict()
+        self.variables = OrderedDict()
+        self.numrecs = 0
+
+
+# ---------------------------------------------------------------------------
+# reading
+# ---------------------------------------------------------------------------
+
+class _Reader:
+    def __init__(self, buf, version):
+        self.buf = buf
+        self.pos = 4
+        self.wide = version == 5
+
+    def u32(self):
+        v = struct.unpack_from('>I', self.buf, self.pos)[0]
+        self.pos += 4
+        return v
+
+    def nonneg(self):
+        if self.wide:
+            v = struct.unpack_from('>Q', self.buf, self.pos)[0]
+            self.pos += 8
+            return v
+        return self.u32()
+
+    def name(self):
+        n = self.nonneg()
+        s = bytes(self.buf[self.pos:self.pos + n]).decode('utf-8')
+        self.pos += _pad4(n)
+        return s
+
+    def values(self, nc_type, n):
+        dt = _TYPES[nc_type]
+        nbytes = n * dt.itemsize
+        raw = np.frombuffer(self.buf, dtype=dt, count=n, offset=self.pos)
+        self.pos += _pad4(nbytes)
+        return raw
+
+    def attrs(self):
+        tag = self.u32()
+        n = self.nonneg()
+        out = OrderedDict()
+        if tag == 0:
+            return out
+        if tag != NC_ATTRIBUTE:
+            raise ValueError('corrupt NetCDF header (attribute list)')
+        for _ in range(n):
+            name = self.name()
+            nc_type = self.u32()
+            nelems = self.nonneg()
+            vals = self.values(nc_type, nelems)
+            if nc_type == 2:
+                out[name] = vals.tobytes().decode('utf-8', 'replace')
+            else:
+                vals = vals.astype(vals.dtype.newbyteorder('='))
+                out[name] = vals[0] if nelems == 1 else vals
+        return out
+
+
+def read(filename):
+    """Read a whole classic-format file into a :class:`NetCDF3File`."""
+    buf = np.memmap(filename, dtype=np.uint8, mode='r')
+    if bytes(buf[:3]) != b'CDF' or buf[3] not in (1, 2, 5):
+        raise ValueError(f'{filename}: not a NetCDF classic (CDF-1/2/5) file')
+    nc = NetCDF3File()
+    nc.version = int(buf[3])
+    rd = _Reader(buf, nc.version)
+    numrecs = rd.nonneg()
+    streaming = numrecs == (0xFFFFFFFFFFFFFFFF if rd.wide else 0xFFFFFFFF)
+
+    tag = rd.u32()
+    n = rd.nonneg()
+    dim_names = []
+    if tag == NC_DIMENSION:
+        for _ in range(n):
+            name = rd.name()
+            length = rd.nonneg()
+            nc.dimensions[name] = None if length == 0 else int(length)
+            dim_names.append(name)
+    elif tag != 0:
+        raise ValueError('corrupt NetCDF header (dimension list)')
+    nc.attrs = rd.attrs()
+
+    tag = rd.u32()
+    n = rd.nonneg()
+    headers = []
+    if tag == NC_VARIABLE:
+        for _ in range(n):
+            name = rd.name()
+            ndims = rd.nonneg()
+            dimids = [rd.nonneg() for _ in range(ndims)]
+            attrs = rd.attrs()
+            nc_type = rd.u32()
+            vsize = rd.nonneg()
+            if nc.version == 1:
+                begin = rd.u32()
+            else:
+                begin = struct.unpack_from('>Q', buf, rd.pos)[0]
+                rd.pos += 8
+            headers.append((name, dimids, attrs, nc_type, vsize, begin))
+    elif tag != 0:
+        raise ValueError('corrupt NetCDF header (variable list)')
+
+    def is_rec(dimids):
+        return len(dimids) > 0 and nc.dimensions[dim_names[dimids[0]]] is None
+
+    rec_vars = [h for h in headers if is_rec(h[1])]
+    if len(rec_vars) == 1:
+        h = rec_vars[0]
+        shape = [nc.dimensions[dim_names[d]] for d in h[1][1:]]
+        recsize = int(np.prod(shape, dtype=np.int64)) * _TYPES[h[3]].itemsize
+    else:
+        recsize = sum(h[4] for h in rec_vars)
+    if streaming:
+        if rec_vars and recsize:
+            first = min(h[5] for h in rec_vars)
+            numrecs = (len(buf) - first) // recsize
+        else:
+            numrecs = 0
+    nc.numrecs = int(numrecs)
+
+    for name, dimids, attrs, nc_type, vsize, begin in headers:
+        dims = [dim_names[d] for d in dimids]
+        dt = _TYPES[nc_type]
+        if is_rec(dimids):
+            inner = [nc.dimensions[d] for d in dims[1:]]
+            count = int(np.prod(inner, dtype=np.int64))
+            if nc.numrecs == 0:
+                data = np.zeros([0] + inner, dtype=dt)
+            else:
+                # strided view over the interleaved records
+                base = np.frombuffer(buf, dtype=np.uint8, offset=begin)
+                rows = np.lib.stride_tricks.as_strided(
+                    base, shape=(nc.numrecs, count * dt.itemsize),
+                    strides=(recsize, 1), writeable=False)
+                data = np.ascontiguousarray(rows).view(dt).reshape(
+                    [nc.numrecs] + inner)
+            rec = True
+        else:
+            shape = [nc.dimensions[d] for d in dims]
+            count = int(np.prod(shape, dtype=np.int64)) if shape else 1
+            data = np.frombuffer(buf, dtype=dt, count=count,
+                                 offset=begin).reshape(shape)
+            rec = False
+        if dt.kind != 'S':
+            data = data.astype(dt.newbyteorder('='))
+        else:
+            data = np.array(data)
+        nc.variables[name] = Variable(name, dims, data, attrs, rec)
+    return nc
+
+
+# ---------------------------------------------------------------------------
+# writing
+# ---------------------------------------------------------------------------
+
+class _Writer:
+    def __init__(self, version):
+        self.parts = []
+        self.wide = version == 5
+        self.version = version
+
+    def u32(self, v):
+        self.parts.append(struct.pack('>I', v))
+
+    def nonneg(self, v):
+        self.parts.append(struct.pack('>Q' if self.wide else '>I', v))
+
+    def offset(self, v):
+        self.parts.append(struct.pack('>I' if self.version == 1 else '>Q', v))
+
+    def name(self, s):
+        b = s.encode('utf-8')
+        self.nonneg(len(b))
+        self.parts.append(b + b'\x00' * (_pad4(len(b)) - len(b)))
+
+    def attrs(self, attrs):
+        if not attrs:
+            self.u32(0)
+            self.nonneg(0)
+            return
+        self.u32(NC_ATTRIBUTE)
+        self.nonneg(len(attrs))
+        for key, value in attrs.items():
+            self.name(key)
+            if isinstance(value, bytes):
+                value = value.decode('utf-8', 'replace')
+            if isinstance(value, str):
+                raw = value.encode('utf-8')
+                self.u32(2)
+                self.nonneg(len(raw))
+            else:
+                arr = np.atleast_1d(np.asarray(value))
+                if arr.dtype == np.bool_:
+                    arr = arr.astype(np.int8)
+                arr = _storable(arr, self.version)
+                self.u32(_code(arr.dtype, self.version))
+                self.nonneg(arr.size)
+                raw = arr.astype(arr.dtype.newbyteorder('>')).tobytes()
+            self.parts.append(raw + b'\x00' * (_pad4(len(raw)) - len(raw)))
+
+    def size(self):
+        return sum(len(p) for p in self.parts)
+
+
+def _code(dtype, version):
+    key = (dtype.kind if dtype.kind != 'U' else 'S', dtype.itemsize)
+    if dtype.kind == 'S':
+        key = ('S', 1)
+    if key not in _CODES:
+        raise TypeError(f'dtype {dtype} cannot be stored in a NetCDF-3 file')
+    code = _CODES[key]
+    if code > 6 and version != 5:
+        raise TypeError(f'dtype {dtype} needs NETCDF3_64BIT_DATA (CDF-5)')
+    return code
+
+
+def _storable(arr, version):
+    """Map dtypes the target version lacks onto the closest stored type."""
+    if arr.dtype.kind == 'b':
+        return arr.astype(np.int8)
+    if version != 5:
+        if arr.dtype.kind == 'i' and arr.dtype.itemsize == 8:
+            return arr.astype(np.int32) if np.all(
+                np.abs(arr) < 2 ** 31) else arr.astype(np.float64)
+        if arr.dtype.kind == 'u':
+            return arr.astype({1: np.int16, 2: np.int32}.get(
+                arr.dtype.itemsize, np.float64))
+    return arr
+
+
+def write(filename, dimensions, variables, attrs=None, version=2):
+    """
+    Write a classic-format file.
+
+    dimensions : dict name -> length (``None`` for the record dimension)
+    variables  : iterable of :class:`Variable`; a variable whose first
+                 dimension is the record dimension becomes a record variable
+    """
+    dimensions = OrderedDict(dimensions)
+    dim_ids = {name: i for i, name in enumerate(dimensions)}
+    rec_dim = next((n for n, length in dimensions.items() if length is None),
+                   None)
+    prepared = []
+    numrecs = 0
+    for var in variables:
+        data = np.asarray(var.data)
+        if data.dtype.kind == 'U':
+            data = np.char.encode(data, 'utf-8')
+        if data.dtype.kind == 'S' and data.dtype.itemsize != 1:
+            raise TypeError(f'{var.name}: store strings as S1 char arrays')
+        data = _storable(data, version)
+        rec = len(var.dims) > 0 and var.dims[0] == rec_dim
+        if rec:
+            numrecs = max(numrecs, data.shape[0])
+        prepared.append((var, data, rec))
+
+    rec_list = [p for p in prepared if p[2]]
+
+    def vsize(data, rec):
+        shape = data.shape[1:] if rec else data.shape
+        n = int(np.prod(shape, dtype=np.int64)) if len(shape) else 1
+        return n * data.dtype.itemsize
+
+    single_rec = len(rec_list) == 1
+
+    def build(begins):
+        w = _Writer(version)
+        w.parts.append(b'CDF' + bytes([version]))
+        w.nonneg(numrecs)
+        if dimensions:
+            w.u32(NC_DIMENSION)
+            w.nonneg(len(dimensions))
+            for name, length in dimensions.items():
+                w.name(name)
+                w.nonneg(0 if length is None else int(length))
+        else:
+            w.u32(0)
+            w.nonneg(0)
+        w.attrs(attrs or {})
+        if prepared:
+            w.u32(NC_VARIABLE)
+            w.nonneg(len(prepared))
+            for (var, data, rec), begin in zip(prepared, begins):
+                w.name(var.name)
+                w.nonneg(len(var.dims))
+                for d in var.dims:
+                    w.nonneg(dim_ids[d])
+                w.attrs(var.attrs)
+                w.u32(_code(data.dtype, version))
+                w.nonneg(_pad4(vsize(data, rec)))
+                w.offset(begin)
+        else:
+            w.u32(0)
+            w.nonneg(0)
+        return w
+
+    header = build([0] * len(prepared))
+    pos = header.size()
+    begins = [0] * len(prepared)
+    for idx, (var, data, rec) in enumerate(prepared):
+        if not rec:
+            begins[idx] = pos
+            pos += _pad4(vsize(data, rec))
+    rec_start = pos
+    recsize = 0
+    for idx, (var, data, rec) in enumerate(prepared):
+        if rec:
+            begins[idx] = rec_start + recsize
+            recsize += vsize(data, rec) if single_rec else \
+                _pad4(vsize(data, rec))
+    header = build(begins)
+    assert header.size() == begins[0] if prepared and not prepared[0][2] \
+        else True
+
+    with open(filename, 'wb') as f:
+        f.write(b''.join(header.parts))
+        for var, data, rec in prepared:
+            if rec:
+                continue
+            raw = np.ascontiguousarray(
+                data.astype(data.dtype.newbyteorder('>')
+                            if data.dtype.kind != 'S' else data.dtype))
+            n = raw.nbytes
+            f.write(raw.tobytes())
+            f.write(b'\x00' * (_pad4(n) - n))
+        if rec_list:
+            big = [np.ascontiguousarray(
+                data.astype(data.dtype.newbyteorder('>')
+                            if data.dtype.kind != 'S' else data.dtype))
+                   for _, data, _ in rec_list]
+            for r in range(numrecs):
+                for raw in big:
+                    # slices keep the big-endian dtype (scalars would not)
+                    if r < raw.shape[0]:
+                        chunk = raw[r:r + 1].tobytes()
+                    else:
+                        chunk = b'\x00' * (raw[0:1].nbytes if raw.shape[0]
+                                           else 0)
+                    f.write(chunk)
+                    if not single_rec:
+                        f.write(b'\x00' * (_pad4(len(chunk)) - len(chunk)))

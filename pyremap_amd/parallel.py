@@ -71,14 +71,17 @@ def gather_rows(y_local, bounds, row_axis=0, group=None):
             dist.get_world_size(group) == 1:
         return y_local
     world = dist.get_world_size(group)
-    shape = list(y_local.shape)
-    slabs = []
-    for r in range(world):
-        shape[row_axis] = bounds[r + 1] - bounds[r]
-        slabs.append(torch.empty(shape, dtype=y_local.dtype,
-                                 device=y_local.device))
-    dist.all_gather(slabs, y_local.contiguous(), group=group)
-    return torch.cat(slabs, dim=row_axis)
+    # all_gather wants equal shapes: pad every slab to the largest shard
+    counts = [bounds[r + 1] - bounds[r] for r in range(world)]
+    y_local = y_local.movedim(row_axis, 0).contiguous()
+    padded_shape = [max(counts)] + list(y_local.shape[1:])
+    mine = torch.zeros(padded_shape, dtype=y_local.dtype,
+                       device=y_local.device)
+    mine[:y_local.shape[0]] = y_local
+    slabs = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(slabs, mine, group=group)
+    full = torch.cat([slab[:n] for slab, n in zip(slabs, counts)], dim=0)
+    return full.movedim(0, row_axis)
 
 
 class ShardedRemap:

@@ -55,6 +55,7 @@ class DataArray:
         self.name = name
         self.attrs = OrderedDict(attrs) if attrs is not None else \
             OrderedDict()
+        self.encoding = {}
         self.coords = OrderedDict()
         if coords is not None:
             for cname, cval in coords.items():
@@ -185,6 +186,7 @@ class Dataset:
     def __init__(self, data_vars=None, coords=None, attrs=None):
         self._vars = OrderedDict()
         self._coord_names = set()
+        self.encoding = {}
         self.attrs = OrderedDict(attrs) if attrs is not None else \
             OrderedDict()
         if data_vars is not None:
@@ -289,6 +291,7 @@ class Dataset:
         for name, var in self._vars.items():
             out._vars[name] = var
         out._coord_names = set(self._coord_names)
+        out.encoding = dict(self.encoding)
         return out
 
     def drop_vars(self, names):

@@ -1,0 +1,365 @@
+"""
+CPU tests: host logic, file formats, the C-ABI surface (no compute calls).
+"""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from helpers import REPO
+
+
+# ---------------------------------------------------------------------------
+# C ABI: the library loads and exports every symbol the header declares
+# ---------------------------------------------------------------------------
+
+def _header_functions():
+    text = open(os.path.join(REPO, 'include', 'remap_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(remap_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_header_and_binding_agree():
+    from pyremap_amd import engine
+    assert _header_functions() == sorted(engine.EXPORTS)
+
+
+def test_library_loads_and_exports_every_symbol():
+    from pyremap_amd import engine
+    lib = engine.load_library()
+    for name in _header_functions():
+        assert hasattr(lib, name), name
+    assert lib.remap_abi_version() == engine.ABI_VERSION
+    header = open(os.path.join(REPO, 'include', 'remap_hip.h')).read()
+    assert f'#define REMAP_ABI_VERSION {engine.ABI_VERSION}' in header
+    assert lib.remap_arch() == b'gfx950'
+
+
+def test_struct_layout_matches_header():
+    """Field order of the ctypes mirror == field order in the header."""
+    from pyremap_amd import engine
+    text = open(os.path.join(REPO, 'include', 'remap_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+
+    def fields(struct):
+        body = re.search(r'typedef struct %s \{(.*?)\} %s;' % (struct,
+                                                               struct),
+                         text, flags=re.S).group(1)
+        return [re.sub(r'\[.*\]', '', m) for m in
+                re.findall(r'([A-Za-z_0-9\[\]]+)\s*;', body)]
+    assert fields('remap_csr') == [f[0] for f in engine._CSR._fields_]
+    assert fields('remap_apply_args') == \
+        [f[0] for f in engine._ApplyArgs._fields_]
+
+
+def test_no_gpu_means_loud_failure():
+    """Without a device the product path raises; it never falls back."""
+    import torch
+
+    from pyremap_amd import engine
+    if torch.cuda.is_available():
+        pytest.skip('a GPU is present')
+    with pytest.raises(engine.EngineError, match='no HIP device'):
+        engine.RemapPlan.from_triplets([1], [1], [1.0], [1.0], 1, 1)
+
+
+def test_product_does_not_import_the_oracle():
+    """oracle/ is test infrastructure: nothing under pyremap_amd names it."""
+    for root, _, files in os.walk(os.path.join(REPO, 'pyremap_amd')):
+        for fn in files:
+            if fn.endswith('.py'):
+                src = open(os.path.join(root, fn)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', src,
+                                     flags=re.M), fn
+
+
+# ---------------------------------------------------------------------------
+# validation errors: identical types and messages to the reference
+# ---------------------------------------------------------------------------
+
+class _Desc:
+    def __init__(self, dims, sizes, coords=None, name='m'):
+        self.dims, self.dim_sizes = list(dims), list(sizes)
+        self.coords, self.mesh_name = coords or {}, name
+
+
+def test_error_messages_match_reference(golden_dir):
+    from pyremap_amd import DataArray, Dataset, Remapper
+    from pyremap_amd.remapper.remap_numpy import _remap_data_array
+    g = np.load(os.path.join(golden_dir, 'g3_dataset.npz'))
+    errors = json.loads(str(g['meta_json']))['errors']
+    n_cells, nlat, nlon = int(g['n_a']), len(g['dst_lat']), len(g['dst_lon'])
+
+    def remapper(src, dst):
+        r = Remapper.from_triplets(g['row'], g['col'], g['S'], g['frac_b'],
+                                   _Desc(['nCells'], [n_cells]),
+                                   _Desc(['lat', 'lon'], [nlat, nlon]))
+        r.src_descriptor, r.dst_descriptor = src, dst
+        return r
+
+    ds = Dataset()
+    ds['ssh'] = DataArray(np.zeros((3, n_cells)), dims=('Time', 'nCells'))
+    good_src = _Desc(['nCells'], [n_cells])
+    good_dst = _Desc(['lat', 'lon'], [nlat, nlon])
+    cases = {
+        'src_rank': (_Desc(['y', 'x'], [5, 10]), good_dst, ds),
+        'dst_rank': (good_src, _Desc(['n'], [nlat * nlon]), ds),
+        'src_size': (_Desc(['nCells'], [n_cells + 1]), good_dst, ds),
+        'dst_size': (good_src, _Desc(['lat', 'lon'], [nlon, nlat]), ds),
+    }
+    for tag, (src, dst, data) in cases.items():
+        with pytest.raises(ValueError) as info:
+            remapper(src, dst).remap_numpy(data, None)
+        assert str(info.value) == errors[tag]['message'], tag
+    r = remapper(good_src, good_dst)
+    r.map_filename = None
+    with pytest.raises(ValueError) as info:
+        r.remap_numpy(ds, None)
+    assert str(info.value) == errors['no_map']['message']
+    # the remaining reference errors fire after the weights are loaded;
+    # stub the device plan so the host checks can run without a GPU
+
+    def loaded():
+        from pyremap_amd.io.mapfile import MappingFile
+        from pyremap_amd.remapper.remap_numpy import _MapInfo
+        r = remapper(good_src, good_dst)
+        r._ds_map = _MapInfo(MappingFile(
+            n_cells, nlat * nlon, [n_cells], [nlon, nlat], g['row'],
+            g['col'], g['S'], g['frac_b']))
+        return r
+    bad = Dataset()
+    bad['ssh'] = DataArray(np.zeros((3, n_cells + 2)),
+                           dims=('Time', 'nCells'))
+    with pytest.raises(ValueError) as info:
+        loaded().remap_numpy(bad, None)
+    assert str(info.value) == errors['ds_size']['message']
+
+    class Sized:
+        sizes = {'nCells': n_cells}
+    with pytest.raises(TypeError) as info:
+        loaded().remap_numpy(Sized(), None)
+    assert str(info.value) == errors['type_error']['message']
+    r2 = loaded()
+    r2.src_descriptor = _Desc(['y', 'x'], [5, 10])
+    with pytest.raises(ValueError) as info:
+        _remap_data_array(DataArray(np.zeros(5), dims=('y',)), r2, None)
+    assert str(info.value) == errors['partial_dataarray']['message']
+
+
+def test_remapper_surface_matches_reference():
+    """Constructor defaults, attributes and method names of remapper.py."""
+    import inspect
+
+    from pyremap_amd import Remapper
+    r = Remapper()
+    expected = dict(ntasks=1, map_filename=None, method='bilinear',
+                    use_tmp=True, expand_dist=None, expand_factor=None,
+                    src_scrip_filename='src_mesh.nc',
+                    dst_scrip_filename='dst_mesh.nc',
+                    format='NETCDF3_64BIT_DATA', src_descriptor=None,
+                    dst_descriptor=None, map_tool='esmf', esmf_path=None,
+                    moab_path=None, parallel_exec='mpirun',
+                    src_grid_info={}, dst_grid_info={})
+    for key, value in expected.items():
+        assert getattr(r, key) == value, key
+    for name in ('src_from_lon_lat', 'dst_from_lon_lat', 'dst_global_lon_lat',
+                 'src_from_proj', 'dst_from_proj', 'dst_from_points',
+                 'src_from_mpas', 'dst_from_mpas', 'build_map', 'ncremap',
+                 'remap_numpy', 'remap', 'remap_file'):
+        assert callable(getattr(r, name)), name
+    sig = inspect.signature(Remapper.ncremap)
+    assert list(sig.parameters)[1:] == [
+        'in_filename', 'out_filename', 'variable_list', 'overwrite',
+        'renormalize', 'logger', 'replace_mpas_fill', 'parallel_exec']
+    sig = inspect.signature(Remapper.remap_numpy)
+    assert list(sig.parameters)[1:] == ['ds', 'renormalization_threshold']
+    r.dst_global_lon_lat(0.5, 0.5)
+    assert r.dst_grid_info == {'type': 'lon-lat', 'dlon': 0.5, 'dlat': 0.5,
+                               'lon_min': -180.0}
+    with pytest.raises(ValueError, match='proj_attr'):
+        r.src_from_proj('f.nc', 'm')
+    with pytest.raises(NotImplementedError):
+        r.build_map()
+
+
+def test_setup_remapper_default_name_and_validation():
+    from pyremap_amd import (
+        PointCollectionDescriptor,
+        Remapper,
+        get_lat_lon_descriptor,
+    )
+    from pyremap_amd.remapper.setup import _setup_remapper
+    src = get_lat_lon_descriptor(1.0, 1.0)
+    dst = get_lat_lon_descriptor(0.5, 0.5)
+    assert src.dim_sizes == [180, 360] and dst.dim_sizes == [360, 720]
+    assert src.mesh_name == '1.0x1.0degree' and not src.regional
+    r = Remapper(src_descriptor=src, dst_descriptor=dst, method='conserve')
+    _setup_remapper(r)
+    assert r.map_filename == \
+        'map_1.0x1.0degree_to_0.5x0.5degree_esmfaave.nc'
+    r = Remapper(src_descriptor=src, dst_descriptor=dst, map_tool='moab',
+                 method='neareststod', map_filename='x.nc')
+    with pytest.raises(ValueError, match='neareststod not supported'):
+        _setup_remapper(r)
+    pts = PointCollectionDescriptor(np.zeros(3), np.zeros(3), 'pts')
+    r = Remapper(src_descriptor=src, dst_descriptor=pts, method='conserve',
+                 map_filename='x.nc')
+    with pytest.raises(ValueError, match='PointCollectionDescriptor'):
+        _setup_remapper(r)
+    r = Remapper(map_filename='x.nc')
+    with pytest.raises(ValueError, match='src_from'):
+        _setup_remapper(r)
+    r = Remapper(map_filename='x.nc')
+    r.src_grid_info = {'type': 'lon-lat', 'dlon': 2.0, 'dlat': 2.0,
+                       'lon_min': -180.0}
+    r.dst_global_lon_lat(1.0, 1.0, mesh_name='one')
+    _setup_remapper(r)
+    assert r.src_descriptor.dim_sizes == [90, 180]
+    assert r.dst_descriptor.mesh_name == 'one'
+
+
+# ---------------------------------------------------------------------------
+# containers and files
+# ---------------------------------------------------------------------------
+
+def test_xr_lite_semantics():
+    from pyremap_amd import DataArray, Dataset
+    ds = Dataset(attrs={'a': 1})
+    ds['t'] = DataArray(np.arange(6.).reshape(2, 3), dims=('time', 'x'),
+                        attrs={'units': 'K'})
+    ds['s'] = (('time',), np.arange(2))
+    ds._set_coord('x', DataArray(np.asarray([10., 20., 30.]), dims=('x',)))
+    assert list(ds.data_vars) == ['t', 's'] and list(ds.coords) == ['x']
+    assert dict(ds.sizes) == {'time': 2, 'x': 3}
+    assert list(ds['t'].coords) == ['x'] and list(ds['s'].coords) == []
+    with pytest.raises(ValueError, match='conflicting sizes'):
+        ds['bad'] = (('x',), np.zeros(4))
+    out = ds.drop_vars(['s']).map(lambda da: da, keep_attrs=True)
+    assert list(out.data_vars) == ['t'] and out.attrs == {'a': 1}
+    assert out['t'].attrs == {'units': 'K'} and list(out.coords) == ['x']
+    masked = np.ma.masked_array([1.0, 2.0], mask=[False, True])
+    da = DataArray.from_dict({'dims': ('n',), 'data': masked, 'name': 'm',
+                              'attrs': {}, 'coords': {}})
+    assert np.isnan(da.values[1]) and da.values[0] == 1.0
+
+
+@pytest.mark.parametrize('fmt', ['NETCDF3_CLASSIC', 'NETCDF3_64BIT',
+                                 'NETCDF3_64BIT_DATA'])
+def test_netcdf_roundtrip(tmp_path, fmt):
+    from pyremap_amd import DataArray, Dataset
+    from pyremap_amd.io.netcdf import open_dataset, write_netcdf
+    rng = np.random.default_rng(0)
+    ds = Dataset(attrs={'title': 'roundtrip', 'n': np.int32(3)})
+    f = rng.standard_normal((4, 5, 3))
+    f[1, 2, :] = np.nan
+    ds['f64'] = DataArray(f, dims=('Time', 'nCells', 'lev'),
+                          attrs={'units': 'm'})
+    ds['f32'] = DataArray(rng.standard_normal((4, 5)).astype(np.float32),
+                          dims=('Time', 'nCells'))
+    ds['i32'] = DataArray(np.arange(4, dtype=np.int32), dims=('Time',))
+    ds['xtime'] = DataArray(
+        np.frombuffer(b'0001-01-01_00:00:000002-01-01_00:00:00'
+                      b'0003-01-01_00:00:000004-01-01_00:00:00',
+                      dtype='S1').reshape(4, 19), dims=('Time', 'StrLen'))
+    ds['static'] = DataArray(rng.standard_normal(5), dims=('nCells',))
+    ds._set_coord('lev', DataArray(np.asarray([1., 2., 3.]), dims=('lev',)))
+    path = str(tmp_path / 'rt.nc')
+    write_netcdf(ds, path, format=fmt, unlimited_dims=['Time'])
+    back = open_dataset(path)
+    assert back.encoding['format'] == fmt
+    assert back.encoding['unlimited_dims'] == ['Time']
+    assert list(back.data_vars) == list(ds.data_vars)
+    assert list(back.coords) == ['lev']
+    for name in ds.variables:
+        a, b = ds.variables[name].values, back.variables[name].values
+        assert a.dtype == b.dtype and a.shape == b.shape, name
+        assert np.array_equal(a, b, equal_nan=a.dtype.kind == 'f'), name
+    # fill value only where NaNs exist (reference utility.py:38-51)
+    from pyremap_amd.io import netcdf3
+    raw = netcdf3.read(path)
+    assert raw.variables['f64'].attrs['_FillValue'] == 9.969209968386869e+36
+    assert '_FillValue' not in raw.variables['f32'].attrs
+    assert raw.variables['f64'].attrs['units'] == 'm'
+    assert raw.attrs['title'] == 'roundtrip' and raw.attrs['n'] == 3
+    if fmt != 'NETCDF3_64BIT_DATA':
+        from scipy.io import netcdf_file
+        with netcdf_file(path, 'r', mmap=False) as nc:
+            assert nc.dimensions['Time'] is None
+            assert np.array_equal(nc.variables['i32'][:], np.arange(4))
+            assert np.array_equal(nc.variables['static'][:],
+                                  ds.variables['static'].values)
+
+
+def test_cf_decoding(tmp_path):
+    from pyremap_amd.io import netcdf3
+    from pyremap_amd.io.netcdf import open_dataset
+    path = str(tmp_path / 'cf.nc')
+    sst = np.asarray([[1.0, 1e20], [2.0, 3.0]], dtype=np.float32)
+    packed = np.asarray([1, 2, -999], dtype=np.int16)
+    netcdf3.write(path, {'y': 2, 'x': 2, 'n': 3}, [
+        netcdf3.Variable('SST', ('y', 'x'), sst,
+                         {'_FillValue': np.float32(1e20),
+                          'missing_value': np.float32(1e20)}),
+        netcdf3.Variable('p', ('n',), packed,
+                         {'_FillValue': np.int16(-999), 'scale_factor': 0.5,
+                          'add_offset': 10.0}),
+    ], version=1)
+    ds = open_dataset(path)
+    assert ds['SST'].dtype == np.float32 and np.isnan(ds['SST'].values[0, 1])
+    assert '_FillValue' not in ds['SST'].attrs
+    p = ds['p'].values
+    assert p[0] == 10.5 and p[1] == 11.0 and np.isnan(p[2])
+
+
+@pytest.mark.parametrize('ext', ['.npz', '.nc'])
+def test_mapping_file_roundtrip(tmp_path, ext):
+    from pyremap_amd import synthetic
+    from pyremap_amd.io.mapfile import read_mapping
+    m = synthetic.conservative_map(300, (10, 12), 1, 5, seed=3)
+    path = str(tmp_path / f'map{ext}')
+    m.save(path)
+    back = read_mapping(path)
+    mm = m.numpy()
+    assert back.n_a == 300 and back.n_b == 120
+    assert back.src_grid_rank == 1 and back.dst_grid_rank == 2
+    assert list(back.dst_grid_dims) == [12, 10]        # Fortran order
+    for key in ('row', 'col', 'S', 'frac_b'):
+        assert np.array_equal(getattr(back, key), mm[key]), key
+
+
+def test_synthetic_maps_are_well_formed():
+    from pyremap_amd import synthetic
+    m = synthetic.make_config('config2')
+    mm = m.numpy()
+    assert m.n_a == 7153 and m.n_b == 180 * 360
+    assert mm['row'].min() >= 1 and mm['row'].max() <= m.n_b
+    assert mm['col'].min() >= 1 and mm['col'].max() <= m.n_a
+    rowsum = np.zeros(m.n_b)
+    np.add.at(rowsum, mm['row'] - 1, mm['S'])
+    np.testing.assert_allclose(rowsum, mm['frac_b'], atol=1e-12)
+    counts = np.bincount(mm['row'] - 1, minlength=m.n_b)
+    assert counts.max() <= 4 and 0.2 < (counts == 0).mean() < 0.4
+    assert not np.all(np.diff(mm['row']) >= 0)      # unsorted, like ESMF
+    b = synthetic.make_config('config1').numpy()
+    rowsum = np.zeros(360 * 720)
+    np.add.at(rowsum, b['row'] - 1, b['S'])
+    np.testing.assert_allclose(rowsum, 1.0, atol=1e-12)
+
+
+def test_row_shard_bounds_balance():
+    import torch
+
+    from pyremap_amd.parallel import row_shard_bounds
+    rng = np.random.default_rng(1)
+    lens = rng.integers(0, 9, size=10000)
+    lens[:3000] = 0                              # an empty (land) band
+    rowptr = torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]))
+    for world in (1, 2, 3, 8):
+        b = row_shard_bounds(rowptr, world)
+        assert b[0] == 0 and b[-1] == 10000 and len(b) == world + 1
+        assert all(x <= y for x, y in zip(b, b[1:]))
+        work = [int(rowptr[b[i + 1]] - rowptr[b[i]]) + 2 * (b[i + 1] - b[i])
+                for i in range(world)]
+        assert max(work) <= 1.05 * sum(work) / world + 20
