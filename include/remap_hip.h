@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define REMAP_ABI_VERSION 3
+#define REMAP_ABI_VERSION 6
 
 enum {
     REMAP_OK = 0,
@@ -86,6 +86,10 @@ typedef struct remap_csr {
                               the library pick kernels specialised for short
                               rows; a wrong value only costs speed if too
                               large, but MUST NOT be smaller than the truth) */
+    int64_t csr_pad;       /* readable (don't-care) entries allocated behind
+                              col[nnz-1] and val[nnz-1]; >= 8 enables the
+                              kernels that fetch a row's entries 8 at a time
+                              through the scalar cache                       */
 } remap_csr;
 
 /*
@@ -127,19 +131,47 @@ typedef struct remap_apply_args {
                                2-D destination grid in tiles so neighbouring
                                rows (which share source rows) run together
                                and re-touches hit the XCD's L2.             */
+    /* Optional LDS-staging schedule ("patch plan", all NULL/0 = absent).
+     * Work slots [row_begin + j*patch_rows, +patch_rows) form patch j (with
+     * row_order, a 2-D tile of the destination grid).
+     *   patch_ucol   per patch, the DISTINCT source rows its entries
+     *                reference (ascending); patch_ptr[j] .. patch_ptr[j+1]
+     *                delimits patch j's list;
+     *   patch_rowptr / patch_lidx / patch_val: the weights again, laid out
+     *                in SLOT order (patch-major CSR): slot s owns entries
+     *                patch_rowptr[s - row_begin] .. patch_rowptr[s - row_begin
+     *                + 1], in the row's CSR order; patch_lidx[e] is the
+     *                position of that entry's column in its patch's list and
+     *                patch_val[e] its weight.
+     * The kernel fetches each distinct source row ONCE per patch into LDS
+     * (together with the patch's entries) and serves the patch's
+     * ~nnz/n_a-fold re-touches from there.  Results are unaffected (same
+     * per-row summation order).                                          */
+    const int32_t *patch_ptr;    /* (device) n_patches + 1                  */
+    const int32_t *patch_ucol;   /* (device) patch_ptr[n_patches]           */
+    const int32_t *patch_rowptr; /* (device) row_end - row_begin + 1        */
+    const int32_t *patch_lidx;   /* (device) nnz                            */
+    const double *patch_val;     /* (device) nnz                            */
+    int32_t patch_rows;          /* work slots per patch                    */
+    int32_t patch_umax;          /* longest per-patch list (sizes the LDS)  */
+    int32_t patch_emax;          /* most entries in one patch               */
+    int32_t patch_reserved;
+    int64_t n_patches;
     uint32_t flags;         /* REMAP_FLAG_*                                  */
     /* launch tuning, 0 = choose automatically:
      * tune[0] kernel family   1 = wave per row (lanes across K),
      *                         2 = lane per (row, k) (small K),
-     *                         3 = 1 software-pipelined,
-     *                         4 = 3 with a branch-free buffer-addressed
-     *                             memory stream
+     *                         5 = LDS-staged patches (needs a patch plan),
+     *                         6 = 1 with row metadata through the scalar
+     *                             cache (needs csr_pad >= 8; the default)
      * tune[1] doubles per lane per tile (1 or 2)
      * tune[2] K tiles per wave (1, 2 or 4)
      * tune[3] consecutive rows per wave
      * tune[4] block -> work map: 1 = as dispatched, 2 = XCD-contiguous
-     * tune[5] nnz unroll (loads in flight per lane)
-     * tune[6..7] reserved */
+     * tune[5] reserved
+     * tune[6] diagnostics: 1 = no Y stores, 2 = gather from the first 1024
+     *         source rows (results are wrong; for bottleneck analysis)
+     * tune[7] KiB of unused dynamic LDS per block (occupancy throttle) */
     int32_t tune[8];
 } remap_apply_args;
 

@@ -16,6 +16,11 @@
 //    sequential per lane: no cross-lane reduction, hence the same summation
 //    order as scipy's csr_matvecs and bit-identical results when built with
 //    -ffp-contract=off (REMAP_FLAG_FMA opts out).
+//  * rowscalar family (default): the same decomposition with the row
+//    metadata fetched through the scalar cache (wide s_loads into SGPRs), so
+//    the vector-memory pipeline only carries X loads and Y stores.
+//  * patch family (opt-in): LDS-staged gather of each destination patch's
+//    distinct source rows by LDS-DMA.
 //  * rowlane family (K <= 32): one lane per (row, k); lanes of a wave cover
 //    64 / K consecutive rows, X accesses are contiguous over k.
 //  * Fused epilogue: division by frac_b / by the remapped mask, threshold
@@ -159,6 +164,7 @@ __device__ __forceinline__ void accumulate_entries(
                     xv[uu][t] = load_x<XT, VEC>(xr + xoff[t]);
             }
         }
+        asm volatile("" ::: "memory");  // loads stay ahead of their uses
 #pragma unroll
         for (int uu = 0; uu < UNROLL; ++uu) {
             if (u0 + uu < n) {
@@ -329,304 +335,212 @@ __global__ __launch_bounds__(kBlock) void spmm_rowwave(const KParams p,
 }
 
 // ---------------------------------------------------------------------------
-// rowpipe: the same work decomposition, software-pipelined.  A wave owns R
-// consecutive work slots.
+// patch: LDS-staged gather.  One workgroup owns one PATCH of destination rows
+// (a 2-D tile of the destination grid when a row order is installed) x one
+// 128-column K-chunk:
 //
-//  * It first fetches the row ids, row pointers and frac_b of ALL its rows
-//    with one coalesced load each (lane l <-> its l-th row).
-//  * (col, S) of a row are prefetched two rows ahead.
-//  * Once a row's X data has been consumed into the accumulators, the NEXT
-//    row's X loads are issued BEFORE this row's division and stores.  Vector
-//    memory operations retire in issue order (s_waitcnt vmcnt counts loads
-//    and stores together), so this keeps the stores the youngest outstanding
-//    operations: waiting for X data never waits for a store to drain, and
-//    the fp64 divisions run under the loads' latency.
+//   1. gather   every DISTINCT source row the patch references is fetched
+//               ONCE, straight into LDS, by LDS-DMA (`global_load_lds_dwordx4`:
+//               1 KiB = one row chunk per wave instruction, per-lane source
+//               address, no VGPRs, all of a wave's fetches in flight at once);
+//   2. barrier  (drains the DMA);
+//   3. compute  each wave walks its rows of the patch: (local index, S) pairs
+//               come through the SCALAR cache (s_load, 8 entries at a time,
+//               no vector-memory instructions), source data from LDS with
+//               `ds_read_b128` (lanes across K, sequential sum per lane: the
+//               same order and the same bits as the other families), fused
+//               epilogue, 16-byte non-temporal stores.
 //
-// TAIL = the K range of this launch has a partial last chunk (lanes may be
-// idle); without it the stores are unconditional, which is what lets the
-// compiler keep them outstanding across the next wait.
+// Why: on conservative maps every source row is referenced by nnz/n_a = 3-5
+// neighbouring destination rows.  In the register-gather kernels each of
+// those references is a separate trip through the CU's vector-memory
+// pipeline (texture addresser + L1 miss queue), which is the saturated
+// resource; here only distinct rows take that trip and
+// the re-touches are LDS reads.  Several workgroups per CU overlap one
+// another's gather and compute phases.
+//
+// Metadata pointers are separate __restrict__ kernel arguments (not members
+// of KParams) so hipcc can prove them read-only and use scalar loads.
 // ---------------------------------------------------------------------------
-template <typename XT, int VEC, int TILES, int UNROLL>
-__device__ __forceinline__ void issue_group(
-    const XT *__restrict__ X, int64_t ldx, const int64_t (&xoff)[TILES],
-    int32_t my_col, int n, int debug,
-    typename XVec<XT, VEC>::type (&xv)[UNROLL][TILES])
+constexpr int kPatchBlock = 1024;  // 16 waves
+constexpr int kPatchWaves = kPatchBlock / kWave;
+constexpr int kPatchRowBytes = 128 * 8;  // one 128-column f64 chunk of a row
+
+// LDS image of one workgroup:
+//   [0, umax KiB)          the distinct source-row chunks, 1 KiB each
+//   then                   val  f64[emax]   the patch's weights, slot order
+//                          lidx i32[emax]   their local row indices
+//                          fb   f64[rows]   frac_b of the patch's rows
+//                          lidx i32[emax]   their local row indices
+//                          rptr i32[rows+1] entry offsets of the patch's rows
+//                          rid  i32[rows]   the rows' ids
+__host__ __device__ inline uint32_t patch_lds_bytes(int umax, int emax,
+                                                    int rows)
 {
-#pragma unroll
-    for (int uu = 0; uu < UNROLL; ++uu) {
-        if (uu < n) {
-            int32_t c = __builtin_amdgcn_readlane(my_col, uu);
-            if (debug & 2)
-                c &= 1023;
-            const XT *xr = X + static_cast<int64_t>(c) * ldx;
-#pragma unroll
-            for (int t = 0; t < TILES; ++t)
-                xv[uu][t] = load_x<XT, VEC>(xr + xoff[t]);
-        }
-    }
+    return static_cast<uint32_t>(umax) * kPatchRowBytes +
+           static_cast<uint32_t>(emax) * 12u +
+           static_cast<uint32_t>(rows) * 16u + 32u;
 }
 
-template <typename XT, int VEC, int TILES, int MODE, bool FMA, int UNROLL>
-__device__ __forceinline__ void consume_group(
-    const typename XVec<XT, VEC>::type (&xv)[UNROLL][TILES], double my_val,
-    int n, double (&acc)[TILES][VEC], double (&den)[TILES][VEC])
+template <int MODE, bool FMA>
+__global__ __launch_bounds__(kPatchBlock) void spmm_patch(
+    const KParams p, const uint32_t flags,
+    const int32_t *__restrict__ prow, const double *__restrict__ pval,
+    const int32_t *__restrict__ plidx, const int32_t *__restrict__ pptr,
+    const int32_t *__restrict__ ucol, const int32_t *__restrict__ row_order,
+    const double *__restrict__ frac_b, const int32_t patch_rows,
+    const int32_t umax, const int32_t emax, const int64_t n_patches)
 {
-    typedef typename XVec<XT, VEC>::type xvec_t;
-#pragma unroll
-    for (int uu = 0; uu < UNROLL; ++uu) {
-        if (uu < n) {
-            const double a = readlane_f64(my_val, uu);
-#pragma unroll
-            for (int t = 0; t < TILES; ++t)
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) {
-                    const double x = elem<xvec_t, VEC>(xv[uu][t], v);
-                    if constexpr (MODE == REMAP_MODE_MASKED) {
-                        const bool valid = (x == x);
-                        const double xz = valid ? x : 0.0;
-                        const double mz = valid ? 1.0 : 0.0;
-                        acc[t][v] = mul_add<FMA>(a, xz, acc[t][v]);
-                        den[t][v] = mul_add<FMA>(a, mz, den[t][v]);
-                    } else {
-                        acc[t][v] = mul_add<FMA>(a, x, acc[t][v]);
-                    }
-                }
-        }
-    }
-}
-
-template <typename XT, int VEC, int TILES, int MODE, bool FMA, int UNROLL,
-          bool TAIL>
-__global__ __launch_bounds__(kBlock) void spmm_rowpipe(const KParams p,
-                                                       const uint32_t flags)
-{
-    typedef typename XVec<XT, VEC>::type xvec_t;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t L = logical_block(p);
     if (L >= p.n_blocks)
         return;
-    const int64_t chunk = L / p.n_rowblocks;
-    const int64_t rb = L - chunk * p.n_rowblocks;
+    const int64_t chunk = L / n_patches;  // chunk-major work list
+    const int64_t patch = L - chunk * n_patches;
 
-    const int R = p.rows_per_wave;  // <= 32
-    const int64_t slot0 =
-        p.row_begin + (rb * kWavesPerBlock + wave) * (int64_t)R;
-    if (slot0 >= p.row_end)
-        return;
-    const int nrows = (p.row_end - slot0) < R
-                          ? static_cast<int>(p.row_end - slot0) : R;
+    int64_t xoff[1], yoff[1];
+    bool act[1];
+    tile_offsets<2, 1>(p, chunk, lane, xoff, yoff, act);
 
-    int64_t xoff[TILES], yoff[TILES];
-    bool act[TILES];
-    tile_offsets<VEC, TILES>(p, chunk, lane, xoff, yoff, act);
-    if constexpr (!TAIL) {
-#pragma unroll
-        for (int t = 0; t < TILES; ++t)
-            act[t] = true;
+    double *lds_val = reinterpret_cast<double *>(lds + umax * kPatchRowBytes);
+    double *lds_fb = lds_val + emax;
+    int32_t *lds_lidx = reinterpret_cast<int32_t *>(lds_fb + patch_rows);
+    int32_t *lds_rptr = lds_lidx + emax;
+    int32_t *lds_rid = lds_rptr + patch_rows + 1;
+
+    // 1. gather: distinct source rows by LDS-DMA, the patch's entries by
+    //    plain loads (they are contiguous: patch-major CSR)
+    const int u0 = pptr[patch];
+    const int U = pptr[patch + 1] - u0;
+    const double *__restrict__ X = static_cast<const double *>(p.X);
+    for (int j = wave; j < U; j += kPatchWaves) {
+        int32_t c = ucol[u0 + j];
+        if (p.debug & 2)
+            c &= 1023;
+        const double *g = X + static_cast<int64_t>(c) * p.ldx + xoff[0];
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void *)g,
+            (__attribute__((address_space(3))) void *)(lds +
+                                                       j * kPatchRowBytes),
+            16, 0, 0);
     }
-
-    const XT *__restrict__ X = static_cast<const XT *>(p.X);
-    const bool cached = (flags & REMAP_FLAG_CACHED_STORE) != 0;
-
-    // metadata of all rows of this wave, one row per lane
-    int32_t my_row = 0;
-    int64_t my_s = 0, my_e = 0;
-    double my_fb = 0.0;
-    if (lane < nrows) {
-        my_row = p.row_order ? p.row_order[slot0 + lane]
-                             : static_cast<int32_t>(slot0 + lane);
-        my_s = p.rowptr[my_row];
-        my_e = p.rowptr[my_row + 1];
+    const int64_t slot0 = p.row_begin + patch * patch_rows;
+    const int64_t local0 = patch * patch_rows;  // index into prow
+    int nrows = patch_rows;
+    if (slot0 + nrows > p.row_end)
+        nrows = static_cast<int>(p.row_end - slot0);
+    const int e0 = prow[local0];
+    const int n_e = prow[local0 + nrows] - e0;
+    for (int t = tid; t < n_e; t += kPatchBlock) {
+        lds_val[t] = pval[e0 + t];
+        lds_lidx[t] = plidx[e0 + t];
+    }
+    if (tid <= nrows)
+        lds_rptr[tid] = prow[local0 + tid] - e0;
+    if (tid < nrows) {
+        const int32_t rid = row_order ? row_order[slot0 + tid]
+                                      : static_cast<int32_t>(slot0 + tid);
+        lds_rid[tid] = rid;
         if constexpr (MODE == REMAP_MODE_FRACB)
-            my_fb = p.frac_b[my_row];
+            lds_fb[tid] = frac_b[rid];
     }
+    // 2. everything landed, visible to every wave
+    __syncthreads();
 
-    // entries of rows 0 and 1, X data of row 0
-    int64_t s = readlane_i64(my_s, 0);
-    int64_t e = readlane_i64(my_e, 0);
-    int n_cur = (e - s) < kWave ? static_cast<int>(e - s) : kWave;
-    int32_t col_cur = 0;
-    double val_cur = 0.0;
-    if (lane < n_cur) {
-        col_cur = p.col[s + lane];
-        val_cur = p.val[s + lane];
-    }
-    int64_t s_next = 0, e_next = 0;
-    int n_next = 0;
-    int32_t col_next = 0;
-    double val_next = 0.0;
-    if (nrows > 1) {
-        s_next = readlane_i64(my_s, 1);
-        e_next = readlane_i64(my_e, 1);
-        n_next = (e_next - s_next) < kWave
-                     ? static_cast<int>(e_next - s_next) : kWave;
-        if (lane < n_next) {
-            col_next = p.col[s_next + lane];
-            val_next = p.val[s_next + lane];
-        }
-    }
-    xvec_t xv[UNROLL][TILES];
-    issue_group<XT, VEC, TILES, UNROLL>(X, p.ldx, xoff, col_cur, n_cur,
-                                        p.debug, xv);
-
-    for (int r = 0; r < nrows; ++r) {
-        const int64_t i = __builtin_amdgcn_readlane(my_row, r);
-        double acc[TILES][VEC];
-        double den[TILES][VEC];
+    // 3. compute the patch's rows from LDS
+    const bool cached = (flags & REMAP_FLAG_CACHED_STORE) != 0;
+    const char *mine = lds + lane * 16;
+    for (int r = wave; r < nrows; r += kPatchWaves) {
+        const int64_t i = __builtin_amdgcn_readfirstlane(lds_rid[r]);
+        const int s = __builtin_amdgcn_readfirstlane(lds_rptr[r]);
+        const int e = __builtin_amdgcn_readfirstlane(lds_rptr[r + 1]);
+        double acc[1][2] = {{0.0, 0.0}};
+        double den[1][2] = {{0.0, 0.0}};
+#pragma unroll 8
+        for (int jj = s; jj < e; ++jj) {
+            const int32_t li = lds_lidx[jj];   // same address in every lane:
+            const double a = lds_val[jj];      // LDS broadcast
+            const d2 x = *reinterpret_cast<const d2 *>(mine +
+                                                       li * kPatchRowBytes);
 #pragma unroll
-        for (int t = 0; t < TILES; ++t)
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) {
-                acc[t][v] = 0.0;
-                den[t][v] = 0.0;
-            }
-
-        // first group of the row: its loads are already in flight
-        consume_group<XT, VEC, TILES, MODE, FMA, UNROLL>(xv, val_cur, n_cur,
-                                                          acc, den);
-        // longer rows: remaining groups, then further 64-entry chunks
-        if (n_cur > UNROLL) {
-            for (int u0 = UNROLL; u0 < n_cur; u0 += UNROLL) {
-                const int32_t c_sh = __shfl(col_cur, lane + u0);
-                const double v_sh = __shfl(val_cur, lane + u0);
-                accumulate_entries<XT, VEC, TILES, MODE, FMA, UNROLL>(
-                    X, p.ldx, xoff, c_sh, v_sh,
-                    (n_cur - u0) < UNROLL ? (n_cur - u0) : UNROLL, acc, den,
-                    p.debug);
-            }
-            for (int64_t base = s + kWave; base < e; base += kWave) {
-                const int n = (e - base) < kWave ? static_cast<int>(e - base)
-                                                 : kWave;
-                int32_t my_col = 0;
-                double my_val = 0.0;
-                if (lane < n) {
-                    my_col = p.col[base + lane];
-                    my_val = p.val[base + lane];
+            for (int v = 0; v < 2; ++v) {
+                if constexpr (MODE == REMAP_MODE_MASKED) {
+                    const bool valid = (x[v] == x[v]);
+                    acc[0][v] = mul_add<FMA>(a, valid ? x[v] : 0.0,
+                                             acc[0][v]);
+                    den[0][v] = mul_add<FMA>(a, valid ? 1.0 : 0.0,
+                                             den[0][v]);
+                } else {
+                    acc[0][v] = mul_add<FMA>(a, x[v], acc[0][v]);
                 }
-                accumulate_entries<XT, VEC, TILES, MODE, FMA, UNROLL>(
-                    X, p.ldx, xoff, my_col, my_val, n, acc, den, p.debug);
             }
         }
-
-        // the X registers are free again: start the next row's loads and the
-        // row-after's entries BEFORE this row's division and stores
-        const int32_t col_fin = col_next;
-        if (r + 1 < nrows)
-            issue_group<XT, VEC, TILES, UNROLL>(X, p.ldx, xoff, col_next,
-                                                n_next, p.debug, xv);
-        s = s_next;
-        e = e_next;
-        n_cur = n_next;
-        col_cur = col_fin;
-        val_cur = val_next;
-        n_next = 0;
-        if (r + 2 < nrows) {
-            s_next = readlane_i64(my_s, r + 2);
-            e_next = readlane_i64(my_e, r + 2);
-            n_next = (e_next - s_next) < kWave
-                         ? static_cast<int>(e_next - s_next) : kWave;
-            col_next = 0;
-            val_next = 0.0;
-            if (lane < n_next) {
-                col_next = p.col[s_next + lane];
-                val_next = p.val[s_next + lane];
-            }
-        }
-
         double fb = 0.0;
         if constexpr (MODE == REMAP_MODE_FRACB)
-            fb = readlane_f64(my_fb, r);
-        finish_row<VEC, TILES, MODE>(p, i, fb, act, yoff, acc, den, cached);
+            fb = lds_fb[r];
+        finish_row<2, 1, MODE>(p, i, fb, act, yoff, acc, den, cached);
     }
 }
 
 // ---------------------------------------------------------------------------
-// rowbuf: the pipelined schedule with a BRANCH-FREE memory instruction
-// stream.  Every vector-memory instruction of the row loop is issued
-// unconditionally through a buffer descriptor; what must not happen -- an X
-// load for an entry the row does not have, a (col, S) prefetch past the
-// wave's last row, the byte mask when none was asked for, the K-tail lanes --
-// is switched off by the descriptor's range check (num_records = 0, or a
-// per-lane offset beyond the range): the hardware drops the access, returns
-// zeros, and still counts the instruction.  Because the number of
-// outstanding operations is then the same on every path, hipcc can place
-// exact `s_waitcnt vmcnt(N)`: the next row's X loads and the row-after's
-// entries are in flight under this row's division, and the stores are never
-// waited for.  (With `if (entry exists) load` the compiler has to assume the
-// shortest path and drains with vmcnt(0) after issuing the next loads.)
-//
-// LONG = rows may hold more than UNROLL entries (extra groups are handled
-// inline, correct but not pipelined).
+// rowscalar: the rowwave decomposition with the row metadata taken through
+// the SCALAR cache.  rowptr and the row's first 8 (col, S) pairs arrive with
+// three wide s_loads (dwordx4 / x8 / x16) straight into SGPRs: no vector-
+// memory instruction and no v_readlane is spent on metadata, so the texture
+// addresser -- the saturated unit -- only sees the X
+// loads and the Y stores.  Needs `csr_pad >= 8` readable entries behind
+// col/val (a row's 8-wide fetch may run past its end) and, like the patch
+// kernel, separate __restrict__ pointer arguments so hipcc may use s_load.
 // ---------------------------------------------------------------------------
+// A wave-uniform pointer pinned in SGPRs.  Without this hipcc folds
+// "row base + lane offset" into one 64-bit per-lane address; with it the load
+// takes the `saddr + 32-bit voffset` form and needs no address VGPR pair.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base,
-                                                            uint32_t bytes)
+// X loads through a buffer descriptor built from the (scalar) row base: the
+// per-lane part of the address is ONE loop-invariant 32-bit VGPR (voffset),
+// so no 64-bit address is formed per load -- fewer VALU instructions, and
+// hipcc can no longer recycle a load's destination registers for its address
+// (which forced a vmcnt(0) before every load in the masked variant).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const void *base)
 {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0,
-                                             static_cast<int>(bytes),
-                                             0x00020000);
+                                             0x7fffffff, 0x00020000);
 }
 
 template <typename XT, int VEC>
-struct RawX;
-template <>
-struct RawX<double, 2> {
-    u32x4 v;
-    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, uint32_t o)
-    {
-        v = __builtin_amdgcn_raw_buffer_load_b128(r, o, 0, 0);
-    }
-    __device__ __forceinline__ double get(int e) const
-    {
-        return __hiloint2double(v[2 * e + 1], v[2 * e]);
-    }
-};
-template <>
-struct RawX<double, 1> {
-    u32x2 v;
-    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, uint32_t o)
-    {
-        v = __builtin_amdgcn_raw_buffer_load_b64(r, o, 0, 0);
-    }
-    __device__ __forceinline__ double get(int) const
-    {
-        return __hiloint2double(v[1], v[0]);
-    }
-};
-template <>
-struct RawX<float, 2> {
-    u32x2 v;
-    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, uint32_t o)
-    {
-        v = __builtin_amdgcn_raw_buffer_load_b64(r, o, 0, 0);
-    }
-    __device__ __forceinline__ double get(int e) const
-    {
-        return static_cast<double>(__uint_as_float(v[e]));
-    }
-};
-template <>
-struct RawX<float, 1> {
-    unsigned int v;
-    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, uint32_t o)
-    {
-        v = __builtin_amdgcn_raw_buffer_load_b32(r, o, 0, 0);
-    }
-    __device__ __forceinline__ double get(int) const
-    {
-        return static_cast<double>(__uint_as_float(v));
-    }
-};
-
-template <typename XT, int VEC, int TILES, int MODE, bool FMA, int UNROLL,
-          bool LONG>
-__global__ __launch_bounds__(kBlock) void spmm_rowbuf(const KParams p,
-                                                      const uint32_t flags)
+__device__ __forceinline__ typename XVec<XT, VEC>::type load_x_buf(
+    __amdgpu_buffer_rsrc_t r, uint32_t byte_off)
 {
-    constexpr uint32_t kOff = 0xfffffff0u;  // beyond every range: dropped
+    typedef typename XVec<XT, VEC>::type xvec_t;
+    if constexpr (sizeof(xvec_t) == 16) {
+        return __builtin_bit_cast(
+            xvec_t, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+    } else if constexpr (sizeof(xvec_t) == 8) {
+        return __builtin_bit_cast(
+            xvec_t, __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 0));
+    } else {
+        return __builtin_bit_cast(
+            xvec_t, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+    }
+}
+
+typedef int32_t i32x8 __attribute__((ext_vector_type(8), aligned(4)));
+typedef double f64x8 __attribute__((ext_vector_type(8), aligned(8)));
+
+template <typename XT, int VEC, int TILES, int MODE, bool FMA>
+__global__ __launch_bounds__(kBlock) void spmm_rowscalar(
+    const KParams p, const uint32_t flags,
+    const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const double *__restrict__ val, const int32_t *__restrict__ row_order,
+    const double *__restrict__ frac_b, const XT *__restrict__ X)
+{
+    typedef typename XVec<XT, VEC>::type xvec_t;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t L = logical_block(p);
@@ -635,151 +549,28 @@ __global__ __launch_bounds__(kBlock) void spmm_rowbuf(const KParams p,
     const int64_t chunk = L / p.n_rowblocks;
     const int64_t rb = L - chunk * p.n_rowblocks;
 
-    const int R = p.rows_per_wave;  // <= 32
-    const int64_t slot0 =
-        p.row_begin + (rb * kWavesPerBlock + wave) * (int64_t)R;
-    if (slot0 >= p.row_end)
-        return;
-    const int nrows = (p.row_end - slot0) < R
-                          ? static_cast<int>(p.row_end - slot0) : R;
-
     int64_t xoff[TILES], yoff[TILES];
     bool act[TILES];
     tile_offsets<VEC, TILES>(p, chunk, lane, xoff, yoff, act);
-    // per-lane BYTE offsets; idle lanes (K tail) point beyond every range
-    uint32_t xb[TILES], yb[TILES], mb[TILES];
+    // 32-bit per-lane element offsets (the host checked that they fit): the
+    // loads can then take the scalar row base + 32-bit VGPR offset form and
+    // need no 64-bit address registers
+    uint32_t xo[TILES];  // BYTE offsets
 #pragma unroll
-    for (int t = 0; t < TILES; ++t) {
-        xb[t] = act[t] ? static_cast<uint32_t>(xoff[t] * sizeof(XT)) : kOff;
-        yb[t] = act[t] ? static_cast<uint32_t>(yoff[t] * 8) : kOff;
-        mb[t] = act[t] ? static_cast<uint32_t>(yoff[t]) : kOff;
-    }
+    for (int t = 0; t < TILES; ++t)
+        xo[t] = static_cast<uint32_t>(xoff[t] * sizeof(XT));
+    const bool cached = (flags & REMAP_FLAG_CACHED_STORE) != 0;
+    const int64_t block_row0 =
+        p.row_begin + rb * (int64_t)(kWavesPerBlock * p.rows_per_wave);
 
-    const char *Xb = static_cast<const char *>(p.X);
-    const int64_t ldx_bytes = p.ldx * (int64_t)sizeof(XT);
-    const uint32_t mask_range = p.mask_out ? p.y_range / 8 : 0u;
-    (void)flags;  // stores are always non-temporal here (no runtime branch)
+    for (int r = 0; r < p.rows_per_wave; ++r) {
+        const int64_t slot = block_row0 + (int64_t)r * kWavesPerBlock + wave;
+        if (slot >= p.row_end)
+            break;
+        const int64_t i = row_order ? (int64_t)row_order[slot] : slot;
+        const int64_t s = rowptr[i];
+        const int64_t e = rowptr[i + 1];
 
-    // metadata of all rows of this wave, one row per lane
-    int32_t my_row = 0;
-    int64_t my_s = 0, my_e = 0;
-    double my_fb = 0.0;
-    if (lane < nrows) {
-        my_row = p.row_order ? p.row_order[slot0 + lane]
-                             : static_cast<int32_t>(slot0 + lane);
-        my_s = p.rowptr[my_row];
-        my_e = p.rowptr[my_row + 1];
-        if constexpr (MODE == REMAP_MODE_FRACB)
-            my_fb = p.frac_b[my_row];
-    }
-
-    // (col, S) of a row's first <= 64 entries: lane j <-> entry j; lanes
-    // past the row's end (and rows past the wave's last) read zeros
-    auto load_entries = [&](int r, int64_t &s_out, int64_t &e_out, int &n_out,
-                            int32_t &c_out, double &v_out) {
-        const int rr = r < nrows ? r : 0;
-        s_out = readlane_i64(my_s, rr);
-        e_out = readlane_i64(my_e, rr);
-        int n = (e_out - s_out) < kWave ? static_cast<int>(e_out - s_out)
-                                        : kWave;
-        if (r >= nrows)
-            n = 0;
-        n_out = n;
-        const __amdgpu_buffer_rsrc_t rc =
-            make_rsrc(p.col + s_out, static_cast<uint32_t>(n) * 4u);
-        const __amdgpu_buffer_rsrc_t rv =
-            make_rsrc(p.val + s_out, static_cast<uint32_t>(n) * 8u);
-        c_out = static_cast<int32_t>(
-            __builtin_amdgcn_raw_buffer_load_b32(rc, lane * 4, 0, 0));
-        const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rv, lane * 8, 0, 0);
-        v_out = __hiloint2double(w[1], w[0]);
-    };
-
-    RawX<XT, VEC> xv[UNROLL][TILES];
-    // the first UNROLL entries' X loads, all issued, absent ones dropped
-    auto issue_x = [&](int32_t cols, int n) {
-#pragma unroll
-        for (int uu = 0; uu < UNROLL; ++uu) {
-            int32_t c = __builtin_amdgcn_readlane(cols, uu);
-            if (p.debug & 2)
-                c &= 1023;
-            const __amdgpu_buffer_rsrc_t rx =
-                make_rsrc(Xb + (int64_t)c * ldx_bytes,
-                          uu < n ? p.x_range : 0u);
-#pragma unroll
-            for (int t = 0; t < TILES; ++t)
-                xv[uu][t].load(rx, xb[t]);
-        }
-    };
-
-    // division + stores of one row; `live` = false issues the same stores
-    // through null descriptors (dropped by the range check)
-    auto finish = [&](int64_t i, double fb, const double (&acc)[TILES][VEC],
-                      const double (&den)[TILES][VEC], bool live) {
-        const __amdgpu_buffer_rsrc_t ry = make_rsrc(
-            p.Y + i * p.ldy, (live && !(p.debug & 1)) ? p.y_range : 0u);
-        const __amdgpu_buffer_rsrc_t rm =
-            make_rsrc(p.mask_out + i * p.ldy, live ? mask_range : 0u);
-#pragma unroll
-        for (int t = 0; t < TILES; ++t) {
-            double y[VEC];
-            bool ok[VEC];
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) {
-                if constexpr (MODE == REMAP_MODE_RAW) {
-                    ok[v] = true;
-                    y[v] = acc[t][v];
-                } else if constexpr (MODE == REMAP_MODE_FRACB) {
-                    ok[v] = fb > 0.0;
-                    y[v] = ok[v] ? acc[t][v] / fb : __builtin_nan("");
-                } else {
-                    ok[v] = den[t][v] > p.thr;
-                    y[v] = ok[v] ? acc[t][v] / den[t][v] : __builtin_nan("");
-                }
-            }
-            if constexpr (VEC == 2) {
-                u32x4 w;
-                w[0] = __double2loint(y[0]);
-                w[1] = __double2hiint(y[0]);
-                w[2] = __double2loint(y[1]);
-                w[3] = __double2hiint(y[1]);
-                __builtin_amdgcn_raw_buffer_store_b128(w, ry, yb[t], 0, 2);
-                const unsigned short m =
-                    (ok[0] ? 0 : 1) | ((ok[1] ? 0 : 1) << 8);
-                __builtin_amdgcn_raw_buffer_store_b16(m, rm, mb[t], 0, 0);
-            } else {
-                u32x2 w;
-                w[0] = __double2loint(y[0]);
-                w[1] = __double2hiint(y[0]);
-                __builtin_amdgcn_raw_buffer_store_b64(w, ry, yb[t], 0, 2);
-                const unsigned char m = ok[0] ? 0 : 1;
-                __builtin_amdgcn_raw_buffer_store_b8(m, rm, mb[t], 0, 0);
-            }
-        }
-    };
-
-    int64_t s, e, s_next, e_next;
-    int n_cur, n_next;
-    int32_t col_cur, col_next;
-    double val_cur, val_next;
-    // Prologue shaped like the tail of a loop iteration -- X loads, entry
-    // prefetch, stores (null here) -- so the outstanding-operation count at
-    // the loop head is the same from both predecessors.
-    load_entries(0, s, e, n_cur, col_cur, val_cur);
-    issue_x(col_cur, n_cur);
-    load_entries(1, s_next, e_next, n_next, col_next, val_next);
-    {
-        double zero[TILES][VEC];
-#pragma unroll
-        for (int t = 0; t < TILES; ++t)
-#pragma unroll
-            for (int v = 0; v < VEC; ++v)
-                zero[t][v] = 0.0;
-        finish(0, 1.0, zero, zero, false);
-    }
-
-    for (int r = 0; r < nrows; ++r) {
-        const int64_t i = __builtin_amdgcn_readlane(my_row, r);
         double acc[TILES][VEC];
         double den[TILES][VEC];
 #pragma unroll
@@ -790,69 +581,56 @@ __global__ __launch_bounds__(kBlock) void spmm_rowbuf(const KParams p,
                 den[t][v] = 0.0;
             }
 
-        // consume the first group (VALU only inside the uniform branches)
+        for (int64_t base = s; base < e; base += 8) {
+            const int n = (e - base) < 8 ? static_cast<int>(e - base) : 8;
+            // 8 entries at once through the scalar cache (padded arrays)
+            const i32x8 c8 = *reinterpret_cast<const i32x8 *>(col + base);
+            const f64x8 a8 = *reinterpret_cast<const f64x8 *>(val + base);
+            xvec_t xv[8][TILES];
 #pragma unroll
-        for (int uu = 0; uu < UNROLL; ++uu) {
-            if (uu < n_cur) {
-                const double a = readlane_f64(val_cur, uu);
+            for (int uu = 0; uu < 8; ++uu) {
+                if (uu < n) {
+                    int32_t c = c8[uu];
+                    if (p.debug & 2)
+                        c &= 1023;
+                    const __amdgpu_buffer_rsrc_t xr =
+                        row_rsrc(X + static_cast<int64_t>(c) * p.ldx);
 #pragma unroll
-                for (int t = 0; t < TILES; ++t)
+                    for (int t = 0; t < TILES; ++t)
+                        xv[uu][t] = load_x_buf<XT, VEC>(xr, xo[t]);
+                }
+            }
+            // Keep every load of the group issued BEFORE the first use: with
+            // X known read-only hipcc otherwise sinks each load next to its
+            // use (load, vmcnt(0), compute, load, ...), serialising the row.
+            asm volatile("" ::: "memory");
 #pragma unroll
-                    for (int v = 0; v < VEC; ++v) {
-                        const double x = xv[uu][t].get(v);
-                        if constexpr (MODE == REMAP_MODE_MASKED) {
-                            const bool valid = (x == x);
-                            acc[t][v] = mul_add<FMA>(a, valid ? x : 0.0,
-                                                     acc[t][v]);
-                            den[t][v] = mul_add<FMA>(a, valid ? 1.0 : 0.0,
-                                                     den[t][v]);
-                        } else {
-                            acc[t][v] = mul_add<FMA>(a, x, acc[t][v]);
+            for (int uu = 0; uu < 8; ++uu) {
+                if (uu < n) {
+                    const double a = a8[uu];
+#pragma unroll
+                    for (int t = 0; t < TILES; ++t)
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) {
+                            const double x = elem<xvec_t, VEC>(xv[uu][t], v);
+                            if constexpr (MODE == REMAP_MODE_MASKED) {
+                                const bool valid = (x == x);
+                                acc[t][v] = mul_add<FMA>(
+                                    a, valid ? x : 0.0, acc[t][v]);
+                                den[t][v] = mul_add<FMA>(
+                                    a, valid ? 1.0 : 0.0, den[t][v]);
+                            } else {
+                                acc[t][v] = mul_add<FMA>(a, x, acc[t][v]);
+                            }
                         }
-                    }
-            }
-        }
-        if constexpr (LONG) {
-            if (e - s > UNROLL) {
-                const XT *__restrict__ X = static_cast<const XT *>(p.X);
-                for (int u0 = UNROLL; u0 < n_cur; u0 += UNROLL) {
-                    const int32_t c_sh = __shfl(col_cur, lane + u0);
-                    const double v_sh = __shfl(val_cur, lane + u0);
-                    accumulate_entries<XT, VEC, TILES, MODE, FMA, UNROLL>(
-                        X, p.ldx, xoff, c_sh, v_sh,
-                        (n_cur - u0) < UNROLL ? (n_cur - u0) : UNROLL, acc,
-                        den, p.debug);
-                }
-                for (int64_t base = s + kWave; base < e; base += kWave) {
-                    const int n = (e - base) < kWave
-                                      ? static_cast<int>(e - base) : kWave;
-                    int32_t my_col = 0;
-                    double my_val = 0.0;
-                    if (lane < n) {
-                        my_col = p.col[base + lane];
-                        my_val = p.val[base + lane];
-                    }
-                    accumulate_entries<XT, VEC, TILES, MODE, FMA, UNROLL>(
-                        X, p.ldx, xoff, my_col, my_val, n, acc, den, p.debug);
                 }
             }
         }
 
-        // next row's X loads and the row-after's entries go out BEFORE this
-        // row's division and stores
-        issue_x(col_next, n_next);
-        s = s_next;
-        e = e_next;
-        n_cur = n_next;
-        col_cur = col_next;
-        val_cur = val_next;
-        load_entries(r + 2, s_next, e_next, n_next, col_next, val_next);
-
-        // fused epilogue (remap_numpy.py:266-278)
         double fb = 0.0;
         if constexpr (MODE == REMAP_MODE_FRACB)
-            fb = readlane_f64(my_fb, r);
-        finish(i, fb, acc, den, true);
+            fb = frac_b[i];
+        finish_row<VEC, TILES, MODE>(p, i, fb, act, yoff, acc, den, cached);
     }
 }
 
@@ -944,88 +722,6 @@ kernel_fn pick_rowwave_shape(int vec, int tiles, int mode, bool fma)
     }
 }
 
-template <typename XT, int VEC, int TILES, int UNROLL, bool TAIL>
-kernel_fn pick_rowpipe_mode(int mode, bool fma)
-{
-    switch (mode) {
-    case REMAP_MODE_RAW:
-        return fma ? spmm_rowpipe<XT, VEC, TILES, REMAP_MODE_RAW, true, UNROLL, TAIL>
-                   : spmm_rowpipe<XT, VEC, TILES, REMAP_MODE_RAW, false, UNROLL, TAIL>;
-    case REMAP_MODE_FRACB:
-        return fma ? spmm_rowpipe<XT, VEC, TILES, REMAP_MODE_FRACB, true, UNROLL, TAIL>
-                   : spmm_rowpipe<XT, VEC, TILES, REMAP_MODE_FRACB, false, UNROLL, TAIL>;
-    default:
-        return fma ? spmm_rowpipe<XT, VEC, TILES, REMAP_MODE_MASKED, true, UNROLL, TAIL>
-                   : spmm_rowpipe<XT, VEC, TILES, REMAP_MODE_MASKED, false, UNROLL, TAIL>;
-    }
-}
-
-template <typename XT, int VEC, int TILES, int UNROLL>
-kernel_fn pick_rowpipe(int mode, bool fma, bool tail)
-{
-    return tail ? pick_rowpipe_mode<XT, VEC, TILES, UNROLL, true>(mode, fma)
-                : pick_rowpipe_mode<XT, VEC, TILES, UNROLL, false>(mode, fma);
-}
-
-// tune[5] = entries in flight per group: 0/8 -> 8, 4 -> 4
-template <typename XT>
-kernel_fn pick_rowpipe_shape(int vec, int tiles, int unroll, int mode,
-                             bool fma, bool tail)
-{
-    if (vec == 1)
-        return pick_rowpipe<XT, 1, 1, 8>(mode, fma, tail);
-    switch (tiles) {
-    case 1:
-        return pick_rowpipe<XT, 2, 1, 8>(mode, fma, tail);
-    case 2:
-        return unroll == 4 ? pick_rowpipe<XT, 2, 2, 4>(mode, fma, tail)
-                           : pick_rowpipe<XT, 2, 2, 8>(mode, fma, tail);
-    default:
-        return unroll == 8 ? pick_rowpipe<XT, 2, 4, 8>(mode, fma, tail)
-                           : pick_rowpipe<XT, 2, 4, 4>(mode, fma, tail);
-    }
-}
-
-template <typename XT, int VEC, int TILES, int UNROLL, bool LONG>
-kernel_fn pick_rowbuf_mode(int mode, bool fma)
-{
-    switch (mode) {
-    case REMAP_MODE_RAW:
-        return fma ? spmm_rowbuf<XT, VEC, TILES, REMAP_MODE_RAW, true, UNROLL, LONG>
-                   : spmm_rowbuf<XT, VEC, TILES, REMAP_MODE_RAW, false, UNROLL, LONG>;
-    case REMAP_MODE_FRACB:
-        return fma ? spmm_rowbuf<XT, VEC, TILES, REMAP_MODE_FRACB, true, UNROLL, LONG>
-                   : spmm_rowbuf<XT, VEC, TILES, REMAP_MODE_FRACB, false, UNROLL, LONG>;
-    default:
-        return fma ? spmm_rowbuf<XT, VEC, TILES, REMAP_MODE_MASKED, true, UNROLL, LONG>
-                   : spmm_rowbuf<XT, VEC, TILES, REMAP_MODE_MASKED, false, UNROLL, LONG>;
-    }
-}
-
-template <typename XT, int VEC, int TILES, int UNROLL>
-kernel_fn pick_rowbuf(int mode, bool fma, bool longrows)
-{
-    return longrows ? pick_rowbuf_mode<XT, VEC, TILES, UNROLL, true>(mode, fma)
-                    : pick_rowbuf_mode<XT, VEC, TILES, UNROLL, false>(mode, fma);
-}
-
-template <typename XT>
-kernel_fn pick_rowbuf_shape(int vec, int tiles, int unroll, int mode,
-                            bool fma, bool longrows)
-{
-    if (vec == 1)
-        return pick_rowbuf<XT, 1, 1, 8>(mode, fma, longrows);
-    switch (tiles) {
-    case 1:
-        return pick_rowbuf<XT, 2, 1, 8>(mode, fma, longrows);
-    case 2:
-        return unroll == 4 ? pick_rowbuf<XT, 2, 2, 4>(mode, fma, longrows)
-                           : pick_rowbuf<XT, 2, 2, 8>(mode, fma, longrows);
-    default:
-        return pick_rowbuf<XT, 2, 4, 4>(mode, fma, longrows);
-    }
-}
-
 template <typename XT>
 kernel_fn pick_rowlane(int mode, bool fma)
 {
@@ -1040,6 +736,93 @@ kernel_fn pick_rowlane(int mode, bool fma)
         return fma ? spmm_rowlane<XT, REMAP_MODE_MASKED, true>
                    : spmm_rowlane<XT, REMAP_MODE_MASKED, false>;
     }
+}
+
+typedef void (*patch_fn)(const KParams, const uint32_t, const int32_t *,
+                         const double *, const int32_t *, const int32_t *,
+                         const int32_t *, const int32_t *, const double *,
+                         const int32_t, const int32_t, const int32_t,
+                         const int64_t);
+
+patch_fn pick_patch(int mode, bool fma)
+{
+    switch (mode) {
+    case REMAP_MODE_RAW:
+        return fma ? spmm_patch<REMAP_MODE_RAW, true>
+                   : spmm_patch<REMAP_MODE_RAW, false>;
+    case REMAP_MODE_FRACB:
+        return fma ? spmm_patch<REMAP_MODE_FRACB, true>
+                   : spmm_patch<REMAP_MODE_FRACB, false>;
+    default:
+        return fma ? spmm_patch<REMAP_MODE_MASKED, true>
+                   : spmm_patch<REMAP_MODE_MASKED, false>;
+    }
+}
+
+// LDS a workgroup may ask for and still leave room for a second one per CU
+constexpr uint32_t kPatchLdsMax = 160 * 1024;
+
+bool patch_usable(const remap_apply_args *a, int64_t K64, bool f32,
+                  bool can_vec2)
+{
+    return a->patch_ptr && a->patch_ucol && a->patch_lidx &&
+           a->patch_rowptr && a->patch_val && a->patch_rows > 0 &&
+           a->patch_rows < kPatchBlock && a->n_patches > 0 &&
+           a->patch_umax >= 0 && a->patch_emax >= 0 && !f32 && can_vec2 &&
+           K64 >= 2 &&
+           patch_lds_bytes(a->patch_umax, a->patch_emax, a->patch_rows) <=
+               kPatchLdsMax &&
+           a->row_end - a->row_begin <=
+               a->n_patches * (int64_t)a->patch_rows &&
+           a->row_end - a->row_begin >
+               (a->n_patches - 1) * (int64_t)a->patch_rows;
+}
+
+template <typename XT>
+struct ScalarFn {
+    typedef void (*type)(const KParams, const uint32_t, const int64_t *,
+                         const int32_t *, const double *, const int32_t *,
+                         const double *, const XT *);
+};
+
+template <typename XT, int VEC, int TILES>
+typename ScalarFn<XT>::type pick_rowscalar_mode(int mode, bool fma)
+{
+    switch (mode) {
+    case REMAP_MODE_RAW:
+        return fma ? spmm_rowscalar<XT, VEC, TILES, REMAP_MODE_RAW, true>
+                   : spmm_rowscalar<XT, VEC, TILES, REMAP_MODE_RAW, false>;
+    case REMAP_MODE_FRACB:
+        return fma ? spmm_rowscalar<XT, VEC, TILES, REMAP_MODE_FRACB, true>
+                   : spmm_rowscalar<XT, VEC, TILES, REMAP_MODE_FRACB, false>;
+    default:
+        return fma ? spmm_rowscalar<XT, VEC, TILES, REMAP_MODE_MASKED, true>
+                   : spmm_rowscalar<XT, VEC, TILES, REMAP_MODE_MASKED, false>;
+    }
+}
+
+template <typename XT>
+typename ScalarFn<XT>::type pick_rowscalar(int vec, int tiles, int mode,
+                                           bool fma)
+{
+    if (vec == 1)
+        return pick_rowscalar_mode<XT, 1, 1>(mode, fma);
+    return tiles == 1 ? pick_rowscalar_mode<XT, 2, 1>(mode, fma)
+                      : pick_rowscalar_mode<XT, 2, 2>(mode, fma);
+}
+
+template <typename XT>
+int launch_rowscalar(const remap_apply_args *a, const KParams &p, int vec,
+                     int tiles, bool fma, int64_t grid, hipStream_t stream)
+{
+    typename ScalarFn<XT>::type fn =
+        pick_rowscalar<XT>(vec, tiles, a->mode, fma);
+    hipLaunchKernelGGL(fn, dim3(static_cast<uint32_t>(grid)), dim3(kBlock), 0,
+                       stream, p, a->flags, a->A.rowptr, a->A.col, a->A.val,
+                       a->row_order, a->frac_b,
+                       static_cast<const XT *>(a->X));
+    REMAP_HIP_CHECK(hipGetLastError());
+    return REMAP_OK;
 }
 
 bool aligned(const void *p, size_t a)
@@ -1111,9 +894,61 @@ int apply(const remap_apply_args *a, hipStream_t stream)
     p.K = static_cast<uint32_t>(K64);
     p.k_inner = static_cast<uint32_t>(a->k_inner);
 
+    const bool can_vec2_all =
+        (a->k_inner % 2 == 0) && (p.ldx % 2 == 0) && (p.bsx % 2 == 0) &&
+        (p.ldy % 2 == 0) && (p.bsy % 2 == 0) &&
+        aligned(a->X, 2 * xelem) && aligned(a->Y, 16);
+    const bool patch_ok = patch_usable(a, K64, f32, can_vec2_all);
     int family = a->tune[0];
-    if (family == 0)
-        family = (K64 <= 32) ? 2 : 1;
+    // per-lane element offset of the last flat column, from a row base
+    const bool small_offsets =
+        ((a->n_batch - 1) * p.bsx + a->k_inner) * (int64_t)xelem <
+        (int64_t(1) << 31);
+    if (family == 0) {
+        // measured on config 3: scalar-cache metadata
+        // beats the plain wave-per-row kernel by ~10 %; the LDS patch family
+        // ties it and is opt-in (tune[0] = 5) until its latency floor is gone
+        family = (K64 <= 32) ? 2 : (A.csr_pad >= 8 ? 6 : 1);
+    }
+    if (family == 5) {
+        if (!patch_ok)
+            return fail(REMAP_ERR_ARG,
+                        "remap_apply_f64: the patch kernel needs a patch "
+                        "plan covering [row_begin, row_end), float64 X and "
+                        "even strides");
+        const int64_t n_chunks = (K64 + 127) / 128;
+        p.n_rowblocks = a->n_patches;
+        p.n_blocks = a->n_patches * n_chunks;
+        p.rows_per_wave = 0;
+        int map = a->tune[4];
+        p.xcd_map = (map == 0 || map == 2) ? 1 : 0;
+        p.blocks_per_xcd = (p.n_blocks + kXcds - 1) / kXcds;
+        const int64_t pgrid = p.xcd_map ? p.blocks_per_xcd * kXcds
+                                        : p.n_blocks;
+        if (pgrid <= 0 || pgrid > 0x7fffffffLL)
+            return fail(REMAP_ERR_UNSUPPORTED,
+                        "remap_apply_f64: grid of %lld blocks",
+                        (long long)pgrid);
+        uint32_t lds_bytes = patch_lds_bytes(a->patch_umax, a->patch_emax,
+                                             a->patch_rows);
+        if (a->tune[7] > 0 && (uint32_t)a->tune[7] * 1024u > lds_bytes)
+            lds_bytes = a->tune[7] * 1024u;  // occupancy experiments
+        if (lds_bytes < 1024)
+            lds_bytes = 1024;
+        patch_fn pf = pick_patch(a->mode, fma);
+        if (lds_bytes > 64 * 1024)
+            REMAP_HIP_CHECK(hipFuncSetAttribute(
+                reinterpret_cast<const void *>(pf),
+                hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        hipLaunchKernelGGL(pf, dim3(static_cast<uint32_t>(pgrid)),
+                           dim3(kPatchBlock), lds_bytes, stream, p, a->flags,
+                           a->patch_rowptr, a->patch_val, a->patch_lidx,
+                           a->patch_ptr, a->patch_ucol, a->row_order,
+                           a->frac_b, a->patch_rows, a->patch_umax,
+                           a->patch_emax, a->n_patches);
+        REMAP_HIP_CHECK(hipGetLastError());
+        return REMAP_OK;
+    }
 
     kernel_fn fn = nullptr;
     int64_t grid = 0;
@@ -1125,7 +960,7 @@ int apply(const remap_apply_args *a, hipStream_t stream)
         p.n_rowblocks = p.n_blocks = p.blocks_per_xcd = 0;
         p.rows_per_wave = 0;
         p.xcd_map = 0;
-    } else if (family == 1 || family == 3 || family == 4) {
+    } else if (family == 1 || family == 6) {
         // two elements per lane need even strides and aligned bases
         const bool can_vec2 =
             (a->k_inner % 2 == 0) && (p.ldx % 2 == 0) && (p.bsx % 2 == 0) &&
@@ -1142,20 +977,30 @@ int apply(const remap_apply_args *a, hipStream_t stream)
             return fail(REMAP_ERR_ARG, "remap_apply_f64: tune[1] = %d", vec);
         int tiles = a->tune[2];
         if (tiles == 0)
-            tiles = K64 >= 256 ? 2 : 1;  // measured best on config 3
+            tiles = (family == 1 && K64 >= 256) ? 2 : 1;  // measured best
         if (vec == 1)
             tiles = 1;
         if (tiles != 1 && tiles != 2 && tiles != 4)
             return fail(REMAP_ERR_ARG, "remap_apply_f64: tune[2] = %d",
                         tiles);
+        if (family == 6 && tiles == 4)
+            tiles = 2;
+        if (family == 6 && A.csr_pad < 8)
+            return fail(REMAP_ERR_ARG,
+                        "remap_apply_f64: the rowscalar kernels need "
+                        "csr_pad >= 8 readable entries behind col/val");
+        if (family == 6 && !small_offsets) {
+            if (a->tune[0] == 6)
+                return fail(REMAP_ERR_UNSUPPORTED,
+                            "remap_apply_f64: batch stride beyond the "
+                            "32-bit offsets of the rowscalar kernels");
+            family = 1;
+        }
         int rpw = a->tune[3];
         if (rpw == 0)
-            rpw = family >= 3 ? 8 : 4;
-        if (rpw < 1 || rpw > (family >= 3 ? 32 : 1024))
+            rpw = 4;
+        if (rpw < 1 || rpw > 1024)
             return fail(REMAP_ERR_ARG, "remap_apply_f64: tune[3] = %d", rpw);
-        if (family >= 3 && A.n_rows >= (int64_t(1) << 31))
-            return fail(REMAP_ERR_UNSUPPORTED,
-                        "remap_apply_f64: more than 2^31 rows");
         int map = a->tune[4];
         if (map == 0)
             map = 2;
@@ -1168,35 +1013,18 @@ int apply(const remap_apply_args *a, hipStream_t stream)
         p.xcd_map = (map == 2) ? 1 : 0;
         p.blocks_per_xcd = (p.n_blocks + kXcds - 1) / kXcds;
         grid = p.xcd_map ? p.blocks_per_xcd * kXcds : p.n_blocks;
-        const bool tail = (K64 % chunk_cols) != 0;
-        if (family == 4) {
-            // buffer addressing: 32-bit byte offsets from a row base
-            const int64_t xr = ((a->n_batch - 1) * p.bsx + a->k_inner) *
-                               (int64_t)xelem;
-            const int64_t yr = ((a->n_batch - 1) * p.bsy + a->k_inner) * 8;
-            if (xr >= (int64_t(1) << 31) || yr >= (int64_t(1) << 31))
+        if (family == 6) {
+            if (grid <= 0 || grid > 0x7fffffffLL)
                 return fail(REMAP_ERR_UNSUPPORTED,
-                            "remap_apply_f64: batch stride beyond the 2 GiB "
-                            "buffer range of the rowbuf kernels");
-            p.x_range = static_cast<uint32_t>(xr);
-            p.y_range = static_cast<uint32_t>(yr);
-            const int unroll = (tiles == 4 || a->tune[5] == 4) ? 4 : 8;
-            const bool longrows = A.max_row_nnz <= 0 ||
-                                  A.max_row_nnz > (vec == 1 || tiles != 4
-                                                   ? (a->tune[5] == 4 && tiles == 2 ? 4 : 8) : 4);
-            (void)unroll;
-            fn = f32 ? pick_rowbuf_shape<float>(vec, tiles, a->tune[5],
-                                                a->mode, fma, longrows)
-                     : pick_rowbuf_shape<double>(vec, tiles, a->tune[5],
-                                                 a->mode, fma, longrows);
-        } else if (family == 3)
-            fn = f32 ? pick_rowpipe_shape<float>(vec, tiles, a->tune[5],
-                                                 a->mode, fma, tail)
-                     : pick_rowpipe_shape<double>(vec, tiles, a->tune[5],
-                                                  a->mode, fma, tail);
-        else
-            fn = f32 ? pick_rowwave_shape<float>(vec, tiles, a->mode, fma)
-                     : pick_rowwave_shape<double>(vec, tiles, a->mode, fma);
+                            "remap_apply_f64: grid of %lld blocks",
+                            (long long)grid);
+            return f32 ? launch_rowscalar<float>(a, p, vec, tiles, fma, grid,
+                                                 stream)
+                       : launch_rowscalar<double>(a, p, vec, tiles, fma, grid,
+                                                  stream);
+        }
+        fn = f32 ? pick_rowwave_shape<float>(vec, tiles, a->mode, fma)
+                 : pick_rowwave_shape<double>(vec, tiles, a->mode, fma);
     } else {
         return fail(REMAP_ERR_ARG, "remap_apply_f64: tune[0] = %d", family);
     }

@@ -32,7 +32,10 @@ FLAG_CACHED_STORE = 2
 DTYPE_F64 = 0
 DTYPE_F32 = 1
 
-ABI_VERSION = 3
+ABI_VERSION = 6
+
+#: readable pad entries kept behind col/val (remap_csr.csr_pad)
+CSR_PAD = 8
 
 #: every symbol ``include/remap_hip.h`` declares
 EXPORTS = (
@@ -51,6 +54,7 @@ class _CSR(ctypes.Structure):
         ('col', ctypes.c_void_p),
         ('val', ctypes.c_void_p),
         ('max_row_nnz', ctypes.c_int64),
+        ('csr_pad', ctypes.c_int64),
     ]
 
 
@@ -73,6 +77,16 @@ class _ApplyArgs(ctypes.Structure):
         ('threshold', ctypes.c_double),
         ('mask_out', ctypes.c_void_p),
         ('row_order', ctypes.c_void_p),
+        ('patch_ptr', ctypes.c_void_p),
+        ('patch_ucol', ctypes.c_void_p),
+        ('patch_rowptr', ctypes.c_void_p),
+        ('patch_lidx', ctypes.c_void_p),
+        ('patch_val', ctypes.c_void_p),
+        ('patch_rows', ctypes.c_int32),
+        ('patch_umax', ctypes.c_int32),
+        ('patch_emax', ctypes.c_int32),
+        ('patch_reserved', ctypes.c_int32),
+        ('n_patches', ctypes.c_int64),
         ('flags', ctypes.c_uint32),
         ('tune', ctypes.c_int32 * 8),
     ]
@@ -193,16 +207,30 @@ class RemapPlan:
         self.n_a = int(n_a)
         self.n_b = int(n_b)
         self.rowptr = rowptr
-        self.col = col
-        self.val = val
         self.frac_b = frac_b
         self.row_offset = int(row_offset)
         self.n_b_global = int(n_b if n_b_global is None else n_b_global)
-        self.nnz = int(val.shape[0])
         self.device = val.device
+        torch = _torch()
+        self.nnz = int(rowptr[-1]) if rowptr.numel() else 0
+        #: col/val carry CSR_PAD readable entries behind the last one so a
+        #: row's entries can be fetched 8 at a time (scalar-cache kernels)
+        pad = int(val.shape[0]) - self.nnz
+        if pad < CSR_PAD:
+            col = torch.cat([col[:self.nnz], torch.zeros(
+                CSR_PAD, dtype=col.dtype, device=col.device)])
+            val = torch.cat([val[:self.nnz], torch.zeros(
+                CSR_PAD, dtype=val.dtype, device=val.device)])
+        self.csr_pad = int(val.shape[0]) - self.nnz
+        self._col_padded = col
+        self._val_padded = val
+        self.col = col[:self.nnz]
+        self.val = val[:self.nnz]
         #: entries of the longest row (kernel selection)
         self.max_row_nnz = int((rowptr[1:] - rowptr[:-1]).max()) \
             if self.n_b > 0 else 0
+        #: optional LDS-staging schedule (see build_patches)
+        self.patches = None
         #: optional int32 permutation of the rows: the order in which work
         #: slots visit them (scheduling only; see set_row_order)
         self.row_order = None
@@ -351,6 +379,84 @@ class RemapPlan:
             raise ValueError(f'unknown schedule {kind!r}')
         self.row_order = torch.argsort(key, stable=True).to(torch.int32)
 
+    def build_patches(self, grid_dims=None, tile=(4, 8), lds_budget=80 * 1024,
+                      row_bytes=1024):
+        """
+        Build the LDS-staging schedule (``remap_apply_args.patch_*``):
+        destination rows are walked in ``tile`` order over a 2-D grid (natural
+        order for 1-D destinations), ``tile[0] * tile[1]`` consecutive work
+        slots form a patch, and for every patch the distinct source rows are
+        listed once.  The tile is halved until the longest list fits the LDS
+        budget (``row_bytes`` per staged source-row chunk).  Returns the
+        fraction distinct / entries (small = much reuse), or ``None`` if no
+        patch size fits.
+        """
+        torch = _torch()
+        if self.nnz == 0 or self.n_b == 0:
+            self.patches = None
+            return None
+        ty, tx = (int(t) for t in tile)
+        lens = self.rowptr[1:] - self.rowptr[:-1]
+        entry_row = torch.repeat_interleave(
+            torch.arange(self.n_b, device=self.device), lens)
+        col64 = self.col.to(torch.int64)
+        while True:
+            if grid_dims is not None and len(grid_dims) == 2:
+                self.set_grid_schedule(grid_dims, 'tile', (ty, tx))
+                order = self.row_order
+                slot_of_row = torch.empty(self.n_b, dtype=torch.int64,
+                                          device=self.device)
+                slot_of_row[order.to(torch.int64)] = torch.arange(
+                    self.n_b, device=self.device)
+            else:
+                self.row_order = None
+                order = None
+                slot_of_row = torch.arange(self.n_b, device=self.device)
+            rows = ty * tx
+            n_patches = (self.n_b + rows - 1) // rows
+            patch_of_entry = slot_of_row[entry_row] // rows
+            key = patch_of_entry * self.n_a + col64
+            uniq, inverse = torch.unique(key, sorted=True,
+                                         return_inverse=True)
+            upatch = uniq // self.n_a
+            counts = torch.bincount(upatch, minlength=n_patches)
+            umax = int(counts.max())
+            if umax * row_bytes <= lds_budget:
+                break
+            if rows == 1:
+                self.patches = None
+                return None
+            if tx >= ty and tx > 1:
+                tx //= 2
+            else:
+                ty //= 2
+        ptr = torch.zeros(n_patches + 1, dtype=torch.int64,
+                          device=self.device)
+        ptr[1:] = torch.cumsum(counts, 0)
+        lidx = (inverse - ptr[patch_of_entry]).to(torch.int32)
+        # the weights again in slot order (patch-major CSR)
+        rows_by_slot = order.to(torch.int64) if order is not None else \
+            torch.arange(self.n_b, device=self.device)
+        lens_by_slot = lens[rows_by_slot]
+        prow = torch.zeros(self.n_b + 1, dtype=torch.int64,
+                           device=self.device)
+        prow[1:] = torch.cumsum(lens_by_slot, 0)
+        shift = self.rowptr[:-1][rows_by_slot] - prow[:-1]
+        src = torch.repeat_interleave(shift, lens_by_slot) + \
+            torch.arange(self.nnz, device=self.device)
+        per_patch = prow[torch.arange(0, n_patches * rows + 1, rows,
+                                      device=self.device).clamp(
+                                          max=self.n_b)]
+        emax = int((per_patch[1:] - per_patch[:-1]).max())
+        self.patches = dict(
+            ptr=ptr.to(torch.int32).contiguous(),
+            ucol=(uniq % self.n_a).to(torch.int32).contiguous(),
+            rowptr=prow.to(torch.int32).contiguous(),
+            lidx=lidx[src].contiguous(), val=self.val[src].contiguous(),
+            rows=rows, umax=umax, emax=emax, n=n_patches, order=order,
+            tile=(ty, tx), distinct=int(uniq.shape[0]))
+        return uniq.shape[0] / self.nnz
+
     # -- accounting ---------------------------------------------------------
     def algorithmic_bytes(self, K, x_itemsize=8, mode=MODE_FRACB):
         """
@@ -400,6 +506,7 @@ def apply_strided(plan, X, Y, *, n_batch, k_inner, x_row_stride,
     args.A.col = plan.col.data_ptr()
     args.A.val = plan.val.data_ptr()
     args.A.max_row_nnz = plan.max_row_nnz
+    args.A.csr_pad = plan.csr_pad
     args.row_begin = row_begin
     args.row_end = plan.n_b if row_end is None else row_end
     args.X = X.data_ptr()
@@ -420,6 +527,20 @@ def apply_strided(plan, X, Y, *, n_batch, k_inner, x_row_stride,
                               args.row_end != plan.n_b):
         order = None    # the stored order permutes the whole row range
     args.row_order = order.data_ptr() if order is not None else None
+    patches = plan.patches
+    if patches is not None and row_begin == 0 and args.row_end == plan.n_b \
+            and (plan.row_order is None) == (patches['order'] is None) \
+            and (plan.row_order is None or
+                 plan.row_order.data_ptr() == patches['order'].data_ptr()):
+        args.patch_ptr = patches['ptr'].data_ptr()
+        args.patch_ucol = patches['ucol'].data_ptr()
+        args.patch_rowptr = patches['rowptr'].data_ptr()
+        args.patch_lidx = patches['lidx'].data_ptr()
+        args.patch_val = patches['val'].data_ptr()
+        args.patch_rows = patches['rows']
+        args.patch_umax = patches['umax']
+        args.patch_emax = patches['emax']
+        args.n_patches = patches['n']
     args.flags = flags
     if tune:
         for i, v in enumerate(tune):

@@ -194,14 +194,9 @@ TUNES = [
     (1, 1, 1, 1, 1, 0), (1, 1, 1, 3, 2, 0), (1, 2, 1, 1, 1, 0),
     (1, 2, 1, 4, 2, 0), (1, 2, 2, 2, 2, 0), (1, 2, 4, 1, 2, 0),
     (1, 2, 4, 5, 1, 0), (2, 0, 0, 0, 0, 0),
-    # software-pipelined family: rows per wave 1..32, both unrolls
-    (3, 1, 1, 1, 2, 0), (3, 1, 1, 7, 1, 0), (3, 2, 1, 8, 2, 0),
-    (3, 2, 2, 5, 2, 4), (3, 2, 2, 16, 2, 8), (3, 2, 4, 3, 2, 4),
-    (3, 2, 4, 32, 1, 8), (3, 0, 0, 0, 0, 0),
-    # branch-free buffer-addressed family
-    (4, 1, 1, 1, 2, 0), (4, 1, 1, 9, 1, 0), (4, 2, 1, 8, 2, 0),
-    (4, 2, 2, 5, 2, 4), (4, 2, 2, 16, 2, 8), (4, 2, 4, 3, 2, 4),
-    (4, 2, 4, 32, 1, 0), (4, 0, 0, 0, 0, 0),
+    # scalar-cache metadata family
+    (6, 1, 1, 1, 2, 0), (6, 1, 1, 5, 1, 0), (6, 2, 1, 4, 2, 0),
+    (6, 2, 2, 3, 2, 0), (6, 2, 2, 8, 1, 0), (6, 0, 0, 0, 0, 0),
 ]
 
 
@@ -430,3 +425,91 @@ def test_dataset_level_matches_reference_golden(dev, golden_dir):
         assert list(out2.variables[v['name']].dims) == v['dims']
         assert_bitwise(out2.variables[v['name']].values,
                        g[f'p_out__{v["name"]}'])
+
+
+# ---------------------------------------------------------------------------
+# LDS-staged patch family
+# ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize('tile', [(4, 8), (1, 16), (8, 8), (3, 5)])
+@pytest.mark.parametrize('K', [64, 128, 130, 384, 512])
+def test_patch_kernel_bitwise(dev, tile, K):
+    """The LDS-staged schedule gives the same bits as the oracle."""
+    from oracle import oracle
+    from pyremap_amd import engine, synthetic
+    m = synthetic.conservative_map(1500, (24, 40), 1, 7, seed=13)
+    mm = m.numpy()
+    plan = engine.RemapPlan.from_triplets(mm['row'], mm['col'], mm['S'],
+                                          mm['frac_b'], m.n_a, m.n_b,
+                                          device=dev)
+    ratio = plan.build_patches(m.dst_dims, tile=tile)
+    assert ratio is not None and 0 < ratio <= 1
+    assert 1 <= plan.patches['rows'] <= tile[0] * tile[1]
+    csr = oracle.coo_to_csr(mm['row'] - 1, mm['col'] - 1, mm['S'], m.n_b,
+                            m.n_a)
+    rng = np.random.default_rng(K)
+    x = rng.standard_normal((m.n_a, K))
+    x[rng.random(m.n_a) < 0.2, :] = np.nan
+    xd = torch.from_numpy(x).to(dev)
+    for emode, masked in ((engine.MODE_FRACB, False),
+                          (engine.MODE_MASKED, True),
+                          (engine.MODE_RAW, False)):
+        y = torch.full((m.n_b, K), 3.0, dtype=torch.float64, device=dev)
+        mask = torch.empty((m.n_b, K), dtype=torch.uint8, device=dev)
+        engine.apply_strided(plan, xd, y, n_batch=1, k_inner=K,
+                             x_row_stride=K, x_batch_stride=0,
+                             y_row_stride=K, y_batch_stride=0, mode=emode,
+                             threshold=0.1, mask_out=mask,
+                             tune=[5, 0, 0, 0, 0, 0, 0, 0])
+        if emode == engine.MODE_RAW:
+            ref = oracle.csr_matvecs(csr, np.nan_to_num(x) * 0 + x)
+            ref_mask = np.zeros_like(ref, dtype=bool)
+        else:
+            ref, ref_mask = oracle.remap_flat(csr, mm['frac_b'], x, masked,
+                                              0.1)
+            ref[ref_mask] = np.nan
+        assert np.array_equal(mask.cpu().numpy().astype(bool), ref_mask)
+        assert_bitwise(y.cpu().numpy(), ref, f'tile={tile} K={K}')
+
+
+def test_patch_kernel_layouts_and_fallbacks(dev):
+    """(T, n, L) in place through the patch family; 1-D destinations; the
+    automatic choice falls back where the patch plan does not apply."""
+    from oracle import oracle
+    from pyremap_amd import engine, synthetic
+    m = synthetic.conservative_map(900, (16, 24), 1, 6, seed=2)
+    mm = m.numpy()
+    plan = engine.RemapPlan.from_triplets(mm['row'], mm['col'], mm['S'],
+                                          mm['frac_b'], m.n_a, m.n_b,
+                                          device=dev)
+    plan.build_patches(m.dst_dims, tile=(4, 8))
+    csr = oracle.coo_to_csr(mm['row'] - 1, mm['col'] - 1, mm['S'], m.n_b,
+                            m.n_a)
+    rng = np.random.default_rng(0)
+    f = rng.standard_normal((3, m.n_a, 66))
+    ref = oracle.remap_numpy_array(csr, mm['frac_b'], m.dst_dims, f, [1],
+                                   None).filled(np.nan)
+    y = engine.remap_tensor(plan, m.dst_dims, torch.from_numpy(f).to(dev),
+                            [1], engine.MODE_FRACB)
+    assert_bitwise(y.cpu().numpy(), ref)
+    # float32 input: patch family does not apply, automatic choice still right
+    f32 = f.astype(np.float32)
+    ref32 = oracle.remap_numpy_array(csr, mm['frac_b'], m.dst_dims, f32, [1],
+                                     None).filled(np.nan)
+    y = engine.remap_tensor(plan, m.dst_dims, torch.from_numpy(f32).to(dev),
+                            [1], engine.MODE_FRACB)
+    assert_bitwise(y.cpu().numpy(), ref32)
+    # 1-D destination: consecutive rows form the patches
+    plan.build_patches(None, tile=(1, 32))
+    assert plan.row_order is None and plan.patches['rows'] <= 32
+    x = rng.standard_normal((m.n_a, 256))
+    ref, ref_mask = oracle.remap_flat(csr, mm['frac_b'], x, False, 0.0)
+    ref[ref_mask] = np.nan
+    y = engine.remap_tensor(plan, (m.n_b,), torch.from_numpy(x).to(dev), [0],
+                            engine.MODE_FRACB, tune=[5])
+    assert_bitwise(y.cpu().numpy(), ref)
+    # a budget nothing fits -> no patches, everything still works
+    assert plan.build_patches(m.dst_dims, tile=(4, 8), lds_budget=512) is None
+    y = engine.remap_tensor(plan, (m.n_b,), torch.from_numpy(x).to(dev), [0],
+                            engine.MODE_FRACB)
+    assert_bitwise(y.cpu().numpy(), ref)

@@ -31,6 +31,7 @@ def main():
     ap.add_argument('--reps', type=int, default=10)
     ap.add_argument('--sets', type=int, default=2)
     ap.add_argument('--dtype', default='f64')
+    ap.add_argument('--lds-kb', type=int, default=80)
     ap.add_argument('--pmc', type=int, default=0,
                     help='counter mode: launch each variant N times in '
                          'order, no timing (run under rocprofv3 --pmc)')
@@ -56,7 +57,18 @@ def main():
           for _ in range(args.sets)]
     variants = []
     orders = {}
+    patch_sets = {}
     for o in args.orders.split(';'):
+        if o.startswith('patch:'):
+            ty, tx = o.split(':')[1].split('x')
+            ratio = plan.build_patches(m.dst_dims, tile=(int(ty), int(tx)),
+                                       lds_budget=args.lds_kb * 1024)
+            print(f'{o}: distinct/nnz = {ratio}, '
+                  f'tile {plan.patches["tile"]}, umax '
+                  f'{plan.patches["umax"]}, patches {plan.patches["n"]}')
+            orders[o] = plan.row_order
+            patch_sets[o] = plan.patches
+            continue
         if o == 'none':
             orders[o] = None
         elif o == 'morton':
@@ -78,6 +90,7 @@ def main():
     def launch(v, i):
         fl, tune, o = v
         plan.row_order = orders[o]
+        plan.patches = patch_sets.get(o)
         s = i % args.sets
         engine.apply_strided(plan, xs[s], ys[s], n_batch=1, k_inner=K,
                              x_row_stride=K, x_batch_stride=0,
