@@ -58,6 +58,9 @@ def parse_args():
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-extra', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
+    ap.add_argument('--force-dist', action='store_true',
+                    help='initialise RCCL even with one rank (exercises '
+                         'the N > 1 code path on a 1-GPU box)')
     return ap.parse_args()
 
 
@@ -75,7 +78,7 @@ def init_dist(args):
         raise SystemExit(f'WORLD_SIZE={world} but --gpus {args.gpus}')
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
@@ -170,13 +173,14 @@ def run_workload(name, args, rank, world, dist, K=None, mode=None,
     K_local = K
     plan = full
     bcast_ms = None
-    if world > 1 and args.shard == 'rows':
+    sharded = dist is not None and args.shard == 'rows'
+    if sharded:
         plan = full.shard(rank, world)
-    elif world > 1:
+    elif dist is not None:
         K_local = K // world
     fields = make_fields(m.n_a, K_local, layout, sets, 1234 + 0 * rank,
                          device, nan_frac=0.25 if mode == 'masked' else 0.0)
-    if world > 1 and args.shard == 'rows':
+    if sharded:
         # the ONE exchange step of the path: rank 0's fields go to all ranks
         barrier(dist)
         tb = time.perf_counter()
@@ -459,7 +463,7 @@ def main():
             'frac': achieved / HBM_PEAK_GBPS,
             'traffic': traffic,
             'traffic_source': traffic_src,
-            'kernel': 'spmm_rowwave (remap_apply_f64)',
+            'kernel': 'spmm_rowscalar (remap_apply_f64)',
             'kernel_ms_mean': kernel_ms,
             'kernel_ms_median': res['kernel_ms_median'],
             'kernel_ms_min': res['kernel_ms_min'],

@@ -513,3 +513,95 @@ def test_patch_kernel_layouts_and_fallbacks(dev):
     y = engine.remap_tensor(plan, (m.n_b,), torch.from_numpy(x).to(dev), [0],
                             engine.MODE_FRACB)
     assert_bitwise(y.cpu().numpy(), ref)
+
+
+# ---------------------------------------------------------------------------
+# BASELINE.json's metric configuration at full size
+# ---------------------------------------------------------------------------
+
+def test_config3_full_size_bitwise_and_properties(dev):
+    """
+    EC30to60 -> 0.5 deg, 512 fp64 fields (2.04 GB per launch): bit-for-bit
+    against the oracle, plus size-independent properties of the operator --
+    linearity in the field, a constant field maps to the constant wherever
+    rows are non-empty (rows sum to frac_b), masked rows are exactly the
+    frac_b = 0 rows.
+    """
+    from oracle import oracle
+    from pyremap_amd import engine, synthetic
+    m = synthetic.make_config('config3', device=dev)
+    plan = engine.RemapPlan.from_triplets(m.row, m.col, m.S, m.frac_b,
+                                          m.n_a, m.n_b, device=dev)
+    K = 512
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    x = torch.randn((m.n_a, K), generator=g, device=dev,
+                    dtype=torch.float64)
+    y = engine.remap_tensor(plan, m.dst_dims, x, [0], engine.MODE_FRACB)
+    assert tuple(y.shape) == (360, 720, K)
+    rowptr, col, val = plan.to_host_csr()
+    csr = oracle.OracleCSR(rowptr, col, val, (m.n_b, m.n_a))
+    frac_b = m.frac_b.cpu().numpy()
+    ref, ref_mask = oracle.remap_flat(csr, frac_b, x.cpu().numpy(), False,
+                                      0.0, nthreads=os.cpu_count() or 1)
+    ref[ref_mask] = np.nan
+    assert_bitwise(y.cpu().numpy().reshape(m.n_b, K), ref, 'config3 full')
+    del ref
+    # masked rows <=> frac_b == 0
+    y2 = y.reshape(m.n_b, K)
+    assert torch.equal(torch.isnan(y2[:, 0]), m.frac_b <= 0)
+    # linearity: A(2x + 3z) == 2 A x + 3 A z up to rounding
+    z = torch.randn((m.n_a, K), generator=g, device=dev,
+                    dtype=torch.float64)
+    yz = engine.remap_tensor(plan, m.dst_dims, z, [0], engine.MODE_FRACB)
+    ylin = engine.remap_tensor(plan, m.dst_dims, 2 * x + 3 * z, [0],
+                               engine.MODE_FRACB)
+    ok = ~torch.isnan(ylin)
+    err = (ylin - (2 * y + 3 * yz))[ok].abs().max()
+    assert float(err) < 1e-12
+    # a constant field is reproduced where the row is covered
+    ones = torch.full((m.n_a, 128), 7.25, device=dev, dtype=torch.float64)
+    yc = engine.remap_tensor(plan, m.dst_dims, ones, [0], engine.MODE_FRACB)
+    okc = ~torch.isnan(yc)
+    assert float((yc[okc] - 7.25).abs().max()) < 1e-12
+    # every kernel family agrees bit for bit at this size
+    plan.build_patches(m.dst_dims, tile=(4, 8))
+    for tune in ([1, 2, 2, 4, 2], [1, 2, 1, 4, 1], [6, 2, 2, 4, 2], [5]):
+        yt = engine.remap_tensor(plan, m.dst_dims, x, [0], engine.MODE_FRACB,
+                                 tune=tune)
+        assert torch.equal(torch.nan_to_num(yt, nan=1e300),
+                           torch.nan_to_num(y, nan=1e300)), tune
+
+
+def test_apply_is_graph_capturable(dev):
+    """remap_apply_f64 allocates nothing and never synchronises: it can be
+    captured in a HIP graph and replayed on new field contents."""
+    from pyremap_amd import engine, synthetic
+    m = synthetic.conservative_map(3000, (30, 40), 1, 6, seed=8, device=dev)
+    plan = engine.RemapPlan.from_triplets(m.row, m.col, m.S, m.frac_b,
+                                          m.n_a, m.n_b, device=dev)
+    K = 256
+    x = torch.randn((m.n_a, K), device=dev, dtype=torch.float64)
+    y = torch.empty((m.n_b, K), device=dev, dtype=torch.float64)
+
+    def launch():
+        engine.apply_strided(plan, x, y, n_batch=1, k_inner=K,
+                             x_row_stride=K, x_batch_stride=0,
+                             y_row_stride=K, y_batch_stride=0,
+                             mode=engine.MODE_FRACB)
+    launch()
+    torch.cuda.synchronize()
+    expect1 = y.clone()
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        launch()                               # warm-up on the side stream
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            launch()
+    torch.cuda.synchronize()
+    x.mul_(-2.0)                               # new contents, same buffers
+    y.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(torch.nan_to_num(y, nan=1e300),
+                       torch.nan_to_num(-2.0 * expect1, nan=1e300))

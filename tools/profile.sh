@@ -9,8 +9,11 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
+rm -rf "$OUT"; mkdir -p "$OUT"
+# the trace pass runs the DEFAULT bench (same steps / warm-up as the live
+# number) so its per-kernel average is comparable with roofline.kernel_ms_mean
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/bench.py" --no-cpu --no-extra $* > "$OUT/trace.log" 2>&1
 ARGS="--steps 20 --warmup 3 --no-cpu --no-extra $*"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/trace.log" 2>&1
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
   name=$(echo $grp | tr ' ' '_')
   rocprofv3 --pmc $grp --output-format csv -d "$OUT/pmc_$name" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/pmc_$name.log" 2>&1
