@@ -167,9 +167,6 @@ def run_workload(name, args, rank, world, dist, K=None, mode=None,
     full = engine.RemapPlan.from_triplets(
         m.row, m.col, m.S, m.frac_b, m.n_a, m.n_b, index_base=1,
         device=device)
-    torch.cuda.synchronize()
-    plan_s = time.perf_counter() - t0
-
     K_local = K
     plan = full
     bcast_ms = None
@@ -178,6 +175,14 @@ def run_workload(name, args, rank, world, dist, K=None, mode=None,
         plan = full.shard(rank, world)
     elif dist is not None:
         K_local = K // world
+    # what Remapper does after loading a mapping: pick the schedule for the
+    # rows this rank owns
+    if not args.tune:
+        schedule = plan.auto_schedule(m.dst_dims)
+    else:
+        schedule = {'family': 'explicit tune', 'tune': args.tune}
+    torch.cuda.synchronize()
+    plan_s = time.perf_counter() - t0
     fields = make_fields(m.n_a, K_local, layout, sets, 1234 + 0 * rank,
                          device, nan_frac=0.25 if mode == 'masked' else 0.0)
     if sharded:
@@ -220,7 +225,7 @@ def run_workload(name, args, rank, world, dist, K=None, mode=None,
         bytes_alg=bytes_alg, bytes_alg_read=bytes_alg - plan.n_b * K_local * 8,
         achieved_GBps=bytes_alg / (mean_ms * 1e-3) / 1e9,
         plan_build_s=plan_s, bcast_ms=bcast_ms,
-        rows_this_rank=plan.n_b, nnz_this_rank=plan.nnz,
+        rows_this_rank=plan.n_b, nnz_this_rank=plan.nnz, schedule=schedule,
     )
     return res, full, m, fields, outs
 
@@ -403,6 +408,7 @@ def main():
                     warmup=5, **kw)
                 extra[tag] = {k: r[k] for k in (
                     'title', 'n_a', 'n_b', 'nnz_csr', 'K', 'mode', 'layout',
+                    'schedule',
                     'ms_per_step', 'kernel_ms_mean', 'cell_fields_per_s',
                     'bytes_alg', 'achieved_GBps')}
                 extra[tag]['frac_of_peak'] = r['achieved_GBps'] / \
@@ -453,6 +459,7 @@ def main():
              f'fields over {world} GPUs, no collective'),
             'buffer_sets_rotated': args.sets,
             'bitwise_mode': not (args.flags & 1),
+            'schedule': res['schedule'],
         },
         'dst_cells_per_s_per_512_batch': res['dst_cells_per_s_per_batch'],
         'roofline': {

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define REMAP_ABI_VERSION 6
+#define REMAP_ABI_VERSION 7
 
 enum {
     REMAP_OK = 0,
@@ -155,7 +155,8 @@ typedef struct remap_apply_args {
     int32_t patch_rows;          /* work slots per patch                    */
     int32_t patch_umax;          /* longest per-patch list (sizes the LDS)  */
     int32_t patch_emax;          /* most entries in one patch               */
-    int32_t patch_reserved;
+    int32_t patch_row_bytes;     /* staged bytes per source row and K-chunk:
+                                    1024 (128 columns) or 512 (64 columns)   */
     int64_t n_patches;
     uint32_t flags;         /* REMAP_FLAG_*                                  */
     /* launch tuning, 0 = choose automatically:

@@ -12,7 +12,8 @@ _REPO = os.path.dirname(_PKG)
 CSRC = os.path.join(_PKG, 'csrc')
 INCLUDE = os.path.join(_REPO, 'include')
 LIB_DIR = os.path.join(_PKG, '_lib')
-LIB_PATH = os.path.join(LIB_DIR, 'libremap_hip.so')
+LIB_PATH = os.environ.get('REMAP_HIP_LIB') or \
+    os.path.join(LIB_DIR, 'libremap_hip.so')
 SOURCES = ['remap_spmm.hip', 'remap_csr.hip']
 ARCH = 'gfx950'
 

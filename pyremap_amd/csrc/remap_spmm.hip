@@ -219,11 +219,13 @@ __device__ __forceinline__ void finish_row(
         if ((p.debug & 1) && y[0] != 1.2345e300)
             continue;
         store_y<VEC>(p.Y + o, y, cached);
+#ifndef REMAP_STAMPS
         if (p.mask_out) {
 #pragma unroll
             for (int v = 0; v < VEC; ++v)
                 p.mask_out[o + v] = ok[v] ? 0 : 1;
         }
+#endif
     }
 }
 
@@ -364,25 +366,27 @@ __global__ __launch_bounds__(kBlock) void spmm_rowwave(const KParams p,
 // ---------------------------------------------------------------------------
 constexpr int kPatchBlock = 1024;  // 16 waves
 constexpr int kPatchWaves = kPatchBlock / kWave;
-constexpr int kPatchRowBytes = 128 * 8;  // one 128-column f64 chunk of a row
 
-// LDS image of one workgroup:
-//   [0, umax KiB)          the distinct source-row chunks, 1 KiB each
+// LDS image of one workgroup (row_bytes = 1024 or 512 per staged row chunk):
+//   [0, (umax + 1) * row_bytes)  the distinct source-row chunks
 //   then                   val  f64[emax]   the patch's weights, slot order
-//                          lidx i32[emax]   their local row indices
 //                          fb   f64[rows]   frac_b of the patch's rows
 //                          lidx i32[emax]   their local row indices
 //                          rptr i32[rows+1] entry offsets of the patch's rows
 //                          rid  i32[rows]   the rows' ids
 __host__ __device__ inline uint32_t patch_lds_bytes(int umax, int emax,
-                                                    int rows)
+                                                    int rows, int row_bytes)
 {
-    return static_cast<uint32_t>(umax) * kPatchRowBytes +
+    return (static_cast<uint32_t>(umax) + 1u) * row_bytes +
            static_cast<uint32_t>(emax) * 12u +
            static_cast<uint32_t>(rows) * 16u + 32u;
 }
 
-template <int MODE, bool FMA>
+// WC = columns per K-chunk: 128 (two doubles per lane, 1 KiB per staged row)
+// or 64 (one double per lane, 512 B per staged row: half the LDS per row, so
+// twice the patch area fits -- for mappings whose rows reference many
+// source rows, e.g. 2nd-order conservative stencils)
+template <int MODE, bool FMA, int WC>
 __global__ __launch_bounds__(kPatchBlock) void spmm_patch(
     const KParams p, const uint32_t flags,
     const int32_t *__restrict__ prow, const double *__restrict__ pval,
@@ -391,8 +395,11 @@ __global__ __launch_bounds__(kPatchBlock) void spmm_patch(
     const double *__restrict__ frac_b, const int32_t patch_rows,
     const int32_t umax, const int32_t emax, const int64_t n_patches)
 {
+    constexpr int VEC = WC / kWave;           // doubles per lane
+    constexpr int kRowBytes = WC * 8;         // staged bytes per source row
+    constexpr int kRowsPerDma = 1024 / kRowBytes;  // rows per DMA instruction
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    typedef double d2 __attribute__((ext_vector_type(2)));
+    typedef typename XVec<double, VEC>::type xvec_t;
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -402,11 +409,26 @@ __global__ __launch_bounds__(kPatchBlock) void spmm_patch(
     const int64_t chunk = L / n_patches;  // chunk-major work list
     const int64_t patch = L - chunk * n_patches;
 
+    // compute-phase columns of this lane
     int64_t xoff[1], yoff[1];
     bool act[1];
-    tile_offsets<2, 1>(p, chunk, lane, xoff, yoff, act);
+    tile_offsets<VEC, 1>(p, chunk, lane, xoff, yoff, act);
+    // gather-phase columns: every lane moves 16 B (2 doubles); with 512-byte
+    // rows one instruction carries two source rows (lanes 0-31 / 32-63)
+    int64_t goff;
+    {
+        constexpr int kLanesPerRow = kWave / kRowsPerDma;
+        const uint32_t kf = static_cast<uint32_t>(chunk) * WC +
+                            (lane % kLanesPerRow) * 2;
+        const bool in = kf < p.K;
+        const uint32_t bb = in ? kf / p.k_inner : 0u;
+        const uint32_t kk = in ? kf - bb * p.k_inner : 0u;
+        goff = static_cast<int64_t>(bb) * p.bsx + kk;
+    }
+    const int sub = lane / (kWave / kRowsPerDma);  // which row of the pair
 
-    double *lds_val = reinterpret_cast<double *>(lds + umax * kPatchRowBytes);
+    double *lds_val =
+        reinterpret_cast<double *>(lds + (umax + 1) * kRowBytes);
     double *lds_fb = lds_val + emax;
     int32_t *lds_lidx = reinterpret_cast<int32_t *>(lds_fb + patch_rows);
     int32_t *lds_rptr = lds_lidx + emax;
@@ -417,15 +439,17 @@ __global__ __launch_bounds__(kPatchBlock) void spmm_patch(
     const int u0 = pptr[patch];
     const int U = pptr[patch + 1] - u0;
     const double *__restrict__ X = static_cast<const double *>(p.X);
-    for (int j = wave; j < U; j += kPatchWaves) {
-        int32_t c = ucol[u0 + j];
+    for (int j = wave * kRowsPerDma; j < U; j += kPatchWaves * kRowsPerDma) {
+        // the second row of a pair may not exist: fetch the first again
+        // (lands in the spare slot behind the list)
+        const int jj = (j + sub < U) ? j + sub : j;
+        int32_t c = ucol[u0 + jj];
         if (p.debug & 2)
             c &= 1023;
-        const double *g = X + static_cast<int64_t>(c) * p.ldx + xoff[0];
+        const double *g = X + static_cast<int64_t>(c) * p.ldx + goff;
         __builtin_amdgcn_global_load_lds(
             (const __attribute__((address_space(1))) void *)g,
-            (__attribute__((address_space(3))) void *)(lds +
-                                                       j * kPatchRowBytes),
+            (__attribute__((address_space(3))) void *)(lds + j * kRowBytes),
             16, 0, 0);
     }
     const int64_t slot0 = p.row_begin + patch * patch_rows;
@@ -453,38 +477,91 @@ __global__ __launch_bounds__(kPatchBlock) void spmm_patch(
 
     // 3. compute the patch's rows from LDS
     const bool cached = (flags & REMAP_FLAG_CACHED_STORE) != 0;
-    const char *mine = lds + lane * 16;
+    const char *mine = lds + lane * (VEC * 8);
     for (int r = wave; r < nrows; r += kPatchWaves) {
         const int64_t i = __builtin_amdgcn_readfirstlane(lds_rid[r]);
         const int s = __builtin_amdgcn_readfirstlane(lds_rptr[r]);
         const int e = __builtin_amdgcn_readfirstlane(lds_rptr[r + 1]);
-        double acc[1][2] = {{0.0, 0.0}};
-        double den[1][2] = {{0.0, 0.0}};
+        double acc[1][VEC];
+        double den[1][VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            acc[0][v] = 0.0;
+            den[0][v] = 0.0;
+        }
 #pragma unroll 8
         for (int jj = s; jj < e; ++jj) {
-            const int32_t li = lds_lidx[jj];   // same address in every lane:
-            const double a = lds_val[jj];      // LDS broadcast
-            const d2 x = *reinterpret_cast<const d2 *>(mine +
-                                                       li * kPatchRowBytes);
+            // (index, weight) by LDS broadcast (same address in every lane);
+            // measured faster than one coalesced read + v_readlane
+            const int32_t li = lds_lidx[jj];
+            const double a = lds_val[jj];
+            const xvec_t xq = *reinterpret_cast<const xvec_t *>(
+                mine + li * kRowBytes);
 #pragma unroll
-            for (int v = 0; v < 2; ++v) {
+            for (int v = 0; v < VEC; ++v) {
+                const double x = elem<xvec_t, VEC>(xq, v);
                 if constexpr (MODE == REMAP_MODE_MASKED) {
-                    const bool valid = (x[v] == x[v]);
-                    acc[0][v] = mul_add<FMA>(a, valid ? x[v] : 0.0,
-                                             acc[0][v]);
-                    den[0][v] = mul_add<FMA>(a, valid ? 1.0 : 0.0,
-                                             den[0][v]);
+                    const bool valid = (x == x);
+                    acc[0][v] = mul_add<FMA>(a, valid ? x : 0.0, acc[0][v]);
+                    den[0][v] = mul_add<FMA>(a, valid ? 1.0 : 0.0, den[0][v]);
                 } else {
-                    acc[0][v] = mul_add<FMA>(a, x[v], acc[0][v]);
+                    acc[0][v] = mul_add<FMA>(a, x, acc[0][v]);
                 }
             }
         }
         double fb = 0.0;
         if constexpr (MODE == REMAP_MODE_FRACB)
             fb = lds_fb[r];
-        finish_row<2, 1, MODE>(p, i, fb, act, yoff, acc, den, cached);
+        finish_row<VEC, 1, MODE>(p, i, fb, act, yoff, acc, den, cached);
     }
 }
+
+// ---------------------------------------------------------------------------
+// In-kernel stamps (diagnostic build only: -DREMAP_STAMPS, tools/stamps.sh).
+// Each stamp reads s_memtime and drains the scalar counter (the recipe of
+// cdna_hip_programming.md section 7); the VM flavour first drains vmcnt.  The
+// five phase sums of a wave go to a buffer of their own (the launch passes
+// it in KParams::mask_out, the byte mask being unused then); no output value
+// depends on them.  The product build compiles all of this away.
+// ---------------------------------------------------------------------------
+#ifdef REMAP_STAMPS
+#define REMAP_STAMP_INIT()                                                   \
+    unsigned long long st_prev = 0, st_now = 0;                              \
+    unsigned long long st_sum[5] = {0, 0, 0, 0, 0};                          \
+    unsigned long long st_rows = 0
+#define REMAP_STAMP(k)                                                       \
+    do {                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)"                  \
+                     : "=s"(st_now)::"memory");                              \
+        __builtin_amdgcn_sched_barrier(0);                                   \
+        if ((k) != 0)                                                        \
+            st_sum[k] += st_now - st_prev;                                   \
+        else                                                                 \
+            st_rows += 1;                                                    \
+        st_prev = st_now;                                                    \
+    } while (0)
+#define REMAP_STAMP_VM(k)                                                    \
+    do {                                                                     \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     \
+        REMAP_STAMP(k);                                                      \
+    } while (0)
+#define REMAP_STAMP_FLUSH()                                                  \
+    do {                                                                     \
+        if (lane == 0 && p.mask_out) {                                       \
+            unsigned long long *o =                                          \
+                reinterpret_cast<unsigned long long *>(p.mask_out);          \
+            for (int k = 1; k < 5; ++k)                                      \
+                atomicAdd(o + k, st_sum[k]);                                 \
+            atomicAdd(o, st_rows);                                           \
+        }                                                                    \
+    } while (0)
+#else
+#define REMAP_STAMP_INIT() do { } while (0)
+#define REMAP_STAMP(k) do { } while (0)
+#define REMAP_STAMP_VM(k) do { } while (0)
+#define REMAP_STAMP_FLUSH() do { } while (0)
+#endif
 
 // ---------------------------------------------------------------------------
 // rowscalar: the rowwave decomposition with the row metadata taken through
@@ -562,14 +639,17 @@ __global__ __launch_bounds__(kBlock) void spmm_rowscalar(
     const bool cached = (flags & REMAP_FLAG_CACHED_STORE) != 0;
     const int64_t block_row0 =
         p.row_begin + rb * (int64_t)(kWavesPerBlock * p.rows_per_wave);
+    REMAP_STAMP_INIT();
 
     for (int r = 0; r < p.rows_per_wave; ++r) {
         const int64_t slot = block_row0 + (int64_t)r * kWavesPerBlock + wave;
         if (slot >= p.row_end)
             break;
         const int64_t i = row_order ? (int64_t)row_order[slot] : slot;
+        REMAP_STAMP(0);
         const int64_t s = rowptr[i];
         const int64_t e = rowptr[i + 1];
+        REMAP_STAMP(1);  // row pointers arrived
 
         double acc[TILES][VEC];
         double den[TILES][VEC];
@@ -586,6 +666,7 @@ __global__ __launch_bounds__(kBlock) void spmm_rowscalar(
             // 8 entries at once through the scalar cache (padded arrays)
             const i32x8 c8 = *reinterpret_cast<const i32x8 *>(col + base);
             const f64x8 a8 = *reinterpret_cast<const f64x8 *>(val + base);
+            REMAP_STAMP(2);  // entries arrived
             xvec_t xv[8][TILES];
 #pragma unroll
             for (int uu = 0; uu < 8; ++uu) {
@@ -604,6 +685,7 @@ __global__ __launch_bounds__(kBlock) void spmm_rowscalar(
             // X known read-only hipcc otherwise sinks each load next to its
             // use (load, vmcnt(0), compute, load, ...), serialising the row.
             asm volatile("" ::: "memory");
+            REMAP_STAMP_VM(3);  // X data arrived
 #pragma unroll
             for (int uu = 0; uu < 8; ++uu) {
                 if (uu < n) {
@@ -631,7 +713,9 @@ __global__ __launch_bounds__(kBlock) void spmm_rowscalar(
         if constexpr (MODE == REMAP_MODE_FRACB)
             fb = frac_b[i];
         finish_row<VEC, TILES, MODE>(p, i, fb, act, yoff, acc, den, cached);
+        REMAP_STAMP(4);  // accumulated, divided, stores issued
     }
+    REMAP_STAMP_FLUSH();
 }
 
 // ---------------------------------------------------------------------------
@@ -744,19 +828,26 @@ typedef void (*patch_fn)(const KParams, const uint32_t, const int32_t *,
                          const int32_t, const int32_t, const int32_t,
                          const int64_t);
 
-patch_fn pick_patch(int mode, bool fma)
+template <int WC>
+patch_fn pick_patch_wc(int mode, bool fma)
 {
     switch (mode) {
     case REMAP_MODE_RAW:
-        return fma ? spmm_patch<REMAP_MODE_RAW, true>
-                   : spmm_patch<REMAP_MODE_RAW, false>;
+        return fma ? spmm_patch<REMAP_MODE_RAW, true, WC>
+                   : spmm_patch<REMAP_MODE_RAW, false, WC>;
     case REMAP_MODE_FRACB:
-        return fma ? spmm_patch<REMAP_MODE_FRACB, true>
-                   : spmm_patch<REMAP_MODE_FRACB, false>;
+        return fma ? spmm_patch<REMAP_MODE_FRACB, true, WC>
+                   : spmm_patch<REMAP_MODE_FRACB, false, WC>;
     default:
-        return fma ? spmm_patch<REMAP_MODE_MASKED, true>
-                   : spmm_patch<REMAP_MODE_MASKED, false>;
+        return fma ? spmm_patch<REMAP_MODE_MASKED, true, WC>
+                   : spmm_patch<REMAP_MODE_MASKED, false, WC>;
     }
+}
+
+patch_fn pick_patch(int mode, bool fma, int row_bytes)
+{
+    return row_bytes == 512 ? pick_patch_wc<64>(mode, fma)
+                            : pick_patch_wc<128>(mode, fma);
 }
 
 // LDS a workgroup may ask for and still leave room for a second one per CU
@@ -770,8 +861,9 @@ bool patch_usable(const remap_apply_args *a, int64_t K64, bool f32,
            a->patch_rows < kPatchBlock && a->n_patches > 0 &&
            a->patch_umax >= 0 && a->patch_emax >= 0 && !f32 && can_vec2 &&
            K64 >= 2 &&
-           patch_lds_bytes(a->patch_umax, a->patch_emax, a->patch_rows) <=
-               kPatchLdsMax &&
+           (a->patch_row_bytes == 1024 || a->patch_row_bytes == 512) &&
+           patch_lds_bytes(a->patch_umax, a->patch_emax, a->patch_rows,
+                           a->patch_row_bytes) <= kPatchLdsMax &&
            a->row_end - a->row_begin <=
                a->n_patches * (int64_t)a->patch_rows &&
            a->row_end - a->row_begin >
@@ -906,9 +998,13 @@ int apply(const remap_apply_args *a, hipStream_t stream)
         (int64_t(1) << 31);
     if (family == 0) {
         // measured on config 3: scalar-cache metadata
-        // beats the plain wave-per-row kernel by ~10 %; the LDS patch family
-        // ties it and is opt-in (tune[0] = 5) until its latency floor is gone
-        family = (K64 <= 32) ? 2 : (A.csr_pad >= 8 ? 6 : 1);
+        // beats the plain wave-per-row kernel by ~10 %.  The LDS patch family
+        // wins when source rows are heavily shared (2.2x on config 4) and
+        // ties otherwise: the host attaches a patch plan only in the first
+        // case (RemapPlan.auto_schedule), so its presence decides.
+        family = (K64 <= 32) ? 2
+                 : (patch_ok && K64 >= 64) ? 5
+                 : (A.csr_pad >= 8 ? 6 : 1);
     }
     if (family == 5) {
         if (!patch_ok)
@@ -916,7 +1012,8 @@ int apply(const remap_apply_args *a, hipStream_t stream)
                         "remap_apply_f64: the patch kernel needs a patch "
                         "plan covering [row_begin, row_end), float64 X and "
                         "even strides");
-        const int64_t n_chunks = (K64 + 127) / 128;
+        const int64_t wc = a->patch_row_bytes / 8;
+        const int64_t n_chunks = (K64 + wc - 1) / wc;
         p.n_rowblocks = a->n_patches;
         p.n_blocks = a->n_patches * n_chunks;
         p.rows_per_wave = 0;
@@ -930,12 +1027,13 @@ int apply(const remap_apply_args *a, hipStream_t stream)
                         "remap_apply_f64: grid of %lld blocks",
                         (long long)pgrid);
         uint32_t lds_bytes = patch_lds_bytes(a->patch_umax, a->patch_emax,
-                                             a->patch_rows);
+                                             a->patch_rows,
+                                             a->patch_row_bytes);
         if (a->tune[7] > 0 && (uint32_t)a->tune[7] * 1024u > lds_bytes)
             lds_bytes = a->tune[7] * 1024u;  // occupancy experiments
         if (lds_bytes < 1024)
             lds_bytes = 1024;
-        patch_fn pf = pick_patch(a->mode, fma);
+        patch_fn pf = pick_patch(a->mode, fma, a->patch_row_bytes);
         if (lds_bytes > 64 * 1024)
             REMAP_HIP_CHECK(hipFuncSetAttribute(
                 reinterpret_cast<const void *>(pf),

@@ -32,7 +32,7 @@ FLAG_CACHED_STORE = 2
 DTYPE_F64 = 0
 DTYPE_F32 = 1
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 #: readable pad entries kept behind col/val (remap_csr.csr_pad)
 CSR_PAD = 8
@@ -85,7 +85,7 @@ class _ApplyArgs(ctypes.Structure):
         ('patch_rows', ctypes.c_int32),
         ('patch_umax', ctypes.c_int32),
         ('patch_emax', ctypes.c_int32),
-        ('patch_reserved', ctypes.c_int32),
+        ('patch_row_bytes', ctypes.c_int32),
         ('n_patches', ctypes.c_int64),
         ('flags', ctypes.c_uint32),
         ('tune', ctypes.c_int32 * 8),
@@ -421,7 +421,13 @@ class RemapPlan:
             upatch = uniq // self.n_a
             counts = torch.bincount(upatch, minlength=n_patches)
             umax = int(counts.max())
-            if umax * row_bytes <= lds_budget:
+            # entries staged next to the rows: 12 B each (+16 B per row)
+            epp = torch.zeros(n_patches, dtype=torch.int64,
+                              device=self.device)
+            epp.index_add_(0, slot_of_row // rows, lens)
+            footprint = (umax + 1) * row_bytes + int(epp.max()) * 12 + \
+                rows * 16 + 32
+            if footprint <= lds_budget:
                 break
             if rows == 1:
                 self.patches = None
@@ -454,8 +460,52 @@ class RemapPlan:
             rowptr=prow.to(torch.int32).contiguous(),
             lidx=lidx[src].contiguous(), val=self.val[src].contiguous(),
             rows=rows, umax=umax, emax=emax, n=n_patches, order=order,
-            tile=(ty, tx), distinct=int(uniq.shape[0]))
+            tile=(ty, tx), distinct=int(uniq.shape[0]),
+            row_bytes=int(row_bytes))
         return uniq.shape[0] / self.nnz
+
+    #: tiles tried by auto_schedule, largest first
+    AUTO_TILES = ((24, 24), (16, 16), (8, 16), (8, 8), (6, 8), (4, 8))
+
+    def auto_schedule(self, grid_dims, max_ratio=0.30,
+                      lds_budget=72 * 1024):
+        """
+        Choose the schedule for this mapping.  The LDS-staged patch family
+        pays when neighbouring destination rows share most of their source
+        rows (bilinear or conservative maps onto a much finer grid: measured
+        2.2x on BASELINE config 4) and merely ties the register-gather kernel
+        otherwise (config 3).  So: build the patch plan with the largest tile
+        whose LDS footprint leaves room for two workgroups per CU, and keep
+        it only if distinct source rows / entries <= ``max_ratio``.  Returns
+        the description of what was chosen.
+        """
+        self.patches = None
+        self.row_order = None
+        if grid_dims is None or self.nnz == 0 or self.n_b == 0:
+            return {'family': 'rowscalar', 'reason': 'no destination grid'}
+        dims = tuple(int(d) for d in grid_dims)
+        tiles = self.AUTO_TILES if len(dims) == 2 else ((1, 256), (1, 64))
+        # 1 KiB per staged row first (16-byte lanes in the compute phase);
+        # 512 B lets twice the patch area fit when rows are entry-rich
+        for row_bytes in (1024, 512):
+            fits = False
+            for tile in tiles:
+                ratio = self.build_patches(
+                    dims if len(dims) == 2 else None, tile=tile,
+                    lds_budget=lds_budget, row_bytes=row_bytes)
+                if ratio is None or self.patches['tile'] != tile:
+                    continue  # does not fit as asked: try the next size
+                fits = True
+                if ratio <= max_ratio:
+                    return {'family': 'patch', 'tile': tile, 'ratio': ratio,
+                            'umax': self.patches['umax'],
+                            'row_bytes': row_bytes}
+                break         # fits, too little reuse: smaller is worse
+            if fits:
+                break
+        self.patches = None
+        self.row_order = None
+        return {'family': 'rowscalar', 'reason': 'little source-row reuse'}
 
     # -- accounting ---------------------------------------------------------
     def algorithmic_bytes(self, K, x_itemsize=8, mode=MODE_FRACB):
@@ -540,6 +590,7 @@ def apply_strided(plan, X, Y, *, n_batch, k_inner, x_row_stride,
         args.patch_rows = patches['rows']
         args.patch_umax = patches['umax']
         args.patch_emax = patches['emax']
+        args.patch_row_bytes = patches['row_bytes']
         args.n_patches = patches['n']
     args.flags = flags
     if tune:

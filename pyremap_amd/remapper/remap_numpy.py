@@ -146,6 +146,9 @@ def _load_mapping(remapper):
     remapper._matrix = engine.RemapPlan.from_triplets(
         mapping.row, mapping.col, mapping.S, mapping.frac_b, info.n_a,
         info.n_b, index_base=1, device=remapper.device)
+    # pick the kernel schedule for this mapping (LDS-staged patches when
+    # neighbouring destination rows share their source rows)
+    remapper.schedule = remapper._matrix.auto_schedule(info.dst_grid_dims)
     remapper._ds_map = info
 
 

@@ -65,6 +65,8 @@ class Remapper:
         self.parallel_exec = parallel_exec
         self.device = device
         self.engine_flags = 0
+        #: what RemapPlan.auto_schedule chose for the loaded mapping
+        self.schedule = None
         self._ds_map = None
         self._matrix = None
         self._mapping_override = None

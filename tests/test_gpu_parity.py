@@ -431,9 +431,10 @@ def test_dataset_level_matches_reference_golden(dev, golden_dir):
 # LDS-staged patch family
 # ---------------------------------------------------------------------------
 
+@pytest.mark.parametrize('row_bytes', [1024, 512])
 @pytest.mark.parametrize('tile', [(4, 8), (1, 16), (8, 8), (3, 5)])
 @pytest.mark.parametrize('K', [64, 128, 130, 384, 512])
-def test_patch_kernel_bitwise(dev, tile, K):
+def test_patch_kernel_bitwise(dev, tile, K, row_bytes):
     """The LDS-staged schedule gives the same bits as the oracle."""
     from oracle import oracle
     from pyremap_amd import engine, synthetic
@@ -442,8 +443,9 @@ def test_patch_kernel_bitwise(dev, tile, K):
     plan = engine.RemapPlan.from_triplets(mm['row'], mm['col'], mm['S'],
                                           mm['frac_b'], m.n_a, m.n_b,
                                           device=dev)
-    ratio = plan.build_patches(m.dst_dims, tile=tile)
+    ratio = plan.build_patches(m.dst_dims, tile=tile, row_bytes=row_bytes)
     assert ratio is not None and 0 < ratio <= 1
+    assert plan.patches['row_bytes'] == row_bytes
     assert 1 <= plan.patches['rows'] <= tile[0] * tile[1]
     csr = oracle.coo_to_csr(mm['row'] - 1, mm['col'] - 1, mm['S'], m.n_b,
                             m.n_a)
@@ -605,3 +607,40 @@ def test_apply_is_graph_capturable(dev):
     torch.cuda.synchronize()
     assert torch.equal(torch.nan_to_num(y, nan=1e300),
                        torch.nan_to_num(-2.0 * expect1, nan=1e300))
+
+
+def test_auto_schedule_picks_by_reuse(dev):
+    """Patches for a coarse -> fine bilinear map (heavy source-row reuse),
+    the register-gather kernel for a 1:1 conservative map; both bit-exact,
+    including on a row shard of the patch-scheduled mapping."""
+    from oracle import oracle
+    from pyremap_amd import engine, synthetic
+    cases = [
+        (synthetic.bilinear_map((20, 30), (200, 300), seed=1, device=dev),
+         'patch'),
+        (synthetic.conservative_map(30000, (150, 200), 3, 7, seed=2,
+                                    device=dev), 'rowscalar'),
+    ]
+    rng = np.random.default_rng(0)
+    for m, expect in cases:
+        plan = engine.RemapPlan.from_triplets(m.row, m.col, m.S, m.frac_b,
+                                              m.n_a, m.n_b, device=dev)
+        choice = plan.auto_schedule(m.dst_dims)
+        assert choice['family'] == expect, choice
+        assert (plan.patches is not None) == (expect == 'patch')
+        rowptr, col, val = plan.to_host_csr()
+        csr = oracle.OracleCSR(rowptr, col, val, (m.n_b, m.n_a))
+        frac_b = m.frac_b.cpu().numpy()
+        x = rng.standard_normal((m.n_a, 192))
+        ref, mask = oracle.remap_flat(csr, frac_b, x, False, 0.0, nthreads=4)
+        ref[mask] = np.nan
+        xd = torch.from_numpy(x).to(dev)
+        y = engine.remap_tensor(plan, m.dst_dims, xd, [0], engine.MODE_FRACB)
+        assert_bitwise(y.cpu().numpy().reshape(m.n_b, 192), ref, expect)
+        # a shard schedules itself over its own rows of the global grid
+        shard = plan.shard(1, 3)
+        shard.auto_schedule(m.dst_dims)
+        ys = engine.remap_tensor(shard, None, xd, [0], engine.MODE_FRACB)
+        r0 = shard.row_offset
+        assert_bitwise(ys.cpu().numpy(), ref[r0:r0 + shard.n_b],
+                       f'{expect} shard')

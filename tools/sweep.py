@@ -59,10 +59,12 @@ def main():
     orders = {}
     patch_sets = {}
     for o in args.orders.split(';'):
-        if o.startswith('patch:'):
+        if o.startswith('patch'):
             ty, tx = o.split(':')[1].split('x')
-            ratio = plan.build_patches(m.dst_dims, tile=(int(ty), int(tx)),
-                                       lds_budget=args.lds_kb * 1024)
+            ratio = plan.build_patches(
+                m.dst_dims, tile=(int(ty), int(tx)),
+                lds_budget=args.lds_kb * 1024,
+                row_bytes=512 if o.startswith('patch512') else 1024)
             print(f'{o}: distinct/nnz = {ratio}, '
                   f'tile {plan.patches["tile"]}, umax '
                   f'{plan.patches["umax"]}, patches {plan.patches["n"]}')
