@@ -229,6 +229,8 @@ class RemapPlan:
         #: entries of the longest row (kernel selection)
         self.max_row_nnz = int((rowptr[1:] - rowptr[:-1]).max()) \
             if self.n_b > 0 else 0
+        #: launch tuning used when a call passes none (set by auto_schedule)
+        self.default_tune = None
         #: optional LDS-staging schedule (see build_patches)
         self.patches = None
         #: optional int32 permutation of the rows: the order in which work
@@ -481,10 +483,16 @@ class RemapPlan:
         """
         self.patches = None
         self.row_order = None
+        self.default_tune = None
         if grid_dims is None or self.nnz == 0 or self.n_b == 0:
             return {'family': 'rowscalar', 'reason': 'no destination grid'}
         dims = tuple(int(d) for d in grid_dims)
+        nonempty = int((self.rowptr[1:] > self.rowptr[:-1]).sum())
+        entry_rich = nonempty > 0 and self.nnz / nonempty >= 10.0
         tiles = self.AUTO_TILES if len(dims) == 2 else ((1, 256), (1, 64))
+        if entry_rich:
+            tiles = ()   # patch compute phase is LDS-issue-bound there:
+            #              measured slower than the tiled register kernel
         # 1 KiB per staged row first (16-byte lanes in the compute phase);
         # 512 B lets twice the patch area fit when rows are entry-rich
         for row_bytes in (1024, 512):
@@ -505,6 +513,19 @@ class RemapPlan:
                 break
         self.patches = None
         self.row_order = None
+        # Entry-rich rows (wide stencils, e.g. 2nd-order conservative): the
+        # band of source rows shared by consecutive grid lines outgrows the
+        # 4 MiB L2 of an XCD and every re-touch goes to Infinity Cache
+        # (config 5: 320 GB of fabric reads for 30 GB of X).  Walking the
+        # grid in 32 x 32 tiles with 2 K-tiles per wave keeps the band in L2:
+        # measured -22 % there, neutral or slightly negative on rows with
+        # < 10 entries, hence the threshold.
+        if len(dims) == 2 and entry_rich:
+            self.set_grid_schedule(dims, 'tile', (32, 32))
+            self.default_tune = [6, 0, 2, 4, 2]   # vec stays automatic
+            return {'family': 'rowscalar', 'order': 'tile 32x32',
+                    'tune': self.default_tune,
+                    'reason': 'entry-rich rows: keep the stencil band in L2'}
         return {'family': 'rowscalar', 'reason': 'little source-row reuse'}
 
     # -- accounting ---------------------------------------------------------
@@ -593,6 +614,8 @@ def apply_strided(plan, X, Y, *, n_batch, k_inner, x_row_stride,
         args.patch_row_bytes = patches['row_bytes']
         args.n_patches = patches['n']
     args.flags = flags
+    if not tune:
+        tune = plan.default_tune
     if tune:
         for i, v in enumerate(tune):
             args.tune[i] = int(v)

@@ -23,8 +23,14 @@ def main():
     src = os.path.join(REPO, 'gpurun_out', f'prof_{tag}')
     out = os.path.join(REPO, 'profiles')
     os.makedirs(out, exist_ok=True)
-    lines = [f'# rocprofv3 summary {tag}: bench.py --steps 20 --warmup 3 '
-             f'--no-cpu --no-extra ({workload}, K = {K}, mode {mode})', '']
+    lines = [f'# rocprofv3 summary {tag} ({workload}, K = {K}, mode {mode})',
+             '',
+             'Collected by tools/profile.sh: the kernel-trace pass runs '
+             '`bench.py --no-cpu --no-extra` (default steps / warm-up, so its '
+             'average is comparable with `roofline.kernel_ms_mean` of the '
+             'bench line taken on the same box); each PMC group is its own '
+             '`rocprofv3 --pmc ...` pass over `bench.py --steps 20 --warmup '
+             '3 --no-cpu --no-extra`.', '']
 
     stats = glob.glob(os.path.join(src, 'trace', '*', '*_kernel_stats.csv'))
     kernel_avg_ns = None
