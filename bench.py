@@ -31,6 +31,8 @@ _REPO = os.path.dirname(os.path.abspath(__file__))
 if _REPO not in sys.path:
     sys.path.insert(0, _REPO)
 
+KERNEL_OF_FAMILY = {'rowscalar': 'spmm_rowscalar', 'rowgroup': 'spmm_rowgroup',
+                    'patch': 'spmm_patch'}
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
@@ -470,7 +472,9 @@ def main():
             'frac': achieved / HBM_PEAK_GBPS,
             'traffic': traffic,
             'traffic_source': traffic_src,
-            'kernel': 'spmm_rowscalar (remap_apply_f64)',
+            'kernel': KERNEL_OF_FAMILY.get(
+                res['schedule'].get('family'), 'spmm_*') +
+            ' (remap_apply_f64)',
             'kernel_ms_mean': kernel_ms,
             'kernel_ms_median': res['kernel_ms_median'],
             'kernel_ms_min': res['kernel_ms_min'],

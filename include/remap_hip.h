@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define REMAP_ABI_VERSION 7
+#define REMAP_ABI_VERSION 8
 
 enum {
     REMAP_OK = 0,
@@ -70,7 +70,11 @@ enum {
      * csr_matvecs; FMA is within 1 ulp per term of it, not identical. */
     REMAP_FLAG_FMA = 1u << 0,
     /* plain (cached) stores for Y instead of non-temporal ones */
-    REMAP_FLAG_CACHED_STORE = 1u << 1
+    REMAP_FLAG_CACHED_STORE = 1u << 1,
+    /* `tune` is a preference, not a demand: if the requested kernel family
+     * cannot serve this call (K <= 32, odd strides, a partial row range, a
+     * missing schedule ...) choose automatically instead of failing */
+    REMAP_FLAG_TUNE_HINT = 1u << 2
 };
 
 /* CSR weight matrix of shape (n_rows, n_cols) = (n_b, n_a), or a row shard of
@@ -158,11 +162,27 @@ typedef struct remap_apply_args {
     int32_t patch_row_bytes;     /* staged bytes per source row and K-chunk:
                                     1024 (128 columns) or 512 (64 columns)   */
     int64_t n_patches;
+    /* Optional row-group schedule (all NULL/0 = absent): work slots
+     * [row_begin + 8 g, + 8) form group g (with row_order: a 2 x 4 tile of
+     * the destination grid).  group_col lists, per group, the sorted UNION of
+     * its rows' columns (group_ptr delimits it); group_w[u * 8 + m] is the
+     * weight of union entry u in the group's m-th row (0.0 if that row has no
+     * such entry) and bit m of group_mask[u] says whether it has one.  A wave
+     * then loads every distinct source row of 8 neighbouring destination
+     * rows ONCE and feeds up to 8 accumulators from it; each row still adds
+     * its entries in ascending column order, so results are unchanged.     */
+    const int64_t *group_ptr;   /* (device) n_groups + 1                    */
+    const int32_t *group_col;   /* (device) union entries (+ 8 readable)    */
+    const double *group_w;      /* (device) union entries * 8 (+ 64)        */
+    const int32_t *group_mask;  /* (device) union entries (+ 8)             */
+    int64_t n_groups;
     uint32_t flags;         /* REMAP_FLAG_*                                  */
     /* launch tuning, 0 = choose automatically:
      * tune[0] kernel family   1 = wave per row (lanes across K),
      *                         2 = lane per (row, k) (small K),
      *                         5 = LDS-staged patches (needs a patch plan),
+     *                         10 = 8 rows per wave over the union of their
+     *                              columns (needs the row-group schedule),
      *                         6 = 1 with row metadata through the scalar
      *                             cache (needs csr_pad >= 8; the default)
      * tune[1] doubles per lane per tile (1 or 2)

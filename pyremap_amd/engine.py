@@ -28,11 +28,12 @@ MODE_MASKED = 2
 
 FLAG_FMA = 1
 FLAG_CACHED_STORE = 2
+FLAG_TUNE_HINT = 4
 
 DTYPE_F64 = 0
 DTYPE_F32 = 1
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 #: readable pad entries kept behind col/val (remap_csr.csr_pad)
 CSR_PAD = 8
@@ -87,6 +88,11 @@ class _ApplyArgs(ctypes.Structure):
         ('patch_emax', ctypes.c_int32),
         ('patch_row_bytes', ctypes.c_int32),
         ('n_patches', ctypes.c_int64),
+        ('group_ptr', ctypes.c_void_p),
+        ('group_col', ctypes.c_void_p),
+        ('group_w', ctypes.c_void_p),
+        ('group_mask', ctypes.c_void_p),
+        ('n_groups', ctypes.c_int64),
         ('flags', ctypes.c_uint32),
         ('tune', ctypes.c_int32 * 8),
     ]
@@ -233,6 +239,8 @@ class RemapPlan:
         self.default_tune = None
         #: optional LDS-staging schedule (see build_patches)
         self.patches = None
+        #: optional row-group schedule (see build_groups)
+        self.groups = None
         #: optional int32 permutation of the rows: the order in which work
         #: slots visit them (scheduling only; see set_row_order)
         self.row_order = None
@@ -466,6 +474,70 @@ class RemapPlan:
             row_bytes=int(row_bytes))
         return uniq.shape[0] / self.nnz
 
+    GROUP = 8   # rows per group (remap_apply_args.group_*)
+
+    def build_groups(self, grid_dims=None, super_tile=32):
+        """
+        Build the row-group schedule (``remap_apply_args.group_*``): 8
+        consecutive work slots -- a 2 x 4 tile of a 2-D destination grid --
+        share one sorted list of the distinct source rows they reference.
+        Returns union entries / entries (small = many shared source rows).
+        """
+        torch = _torch()
+        G = self.GROUP
+        self.groups = None
+        if self.nnz == 0 or self.n_b == 0:
+            return None
+        if grid_dims is not None and len(grid_dims) == 2:
+            # 2 x 4 groups, walked row-major INSIDE super_tile x super_tile
+            # blocks of the grid (keeps a group's neighbours -- and the
+            # stencil band they share -- in the XCD's L2)
+            my, mx = (int(d) for d in grid_dims)
+            if my * mx != self.n_b_global:
+                raise ValueError(f'grid {grid_dims} does not hold '
+                                 f'{self.n_b_global} cells')
+            st = int(super_tile)
+            rows = torch.arange(self.row_offset, self.row_offset + self.n_b,
+                                device=self.device, dtype=torch.int64)
+            jy = rows // mx
+            jx = rows - jy * mx
+            nsx = (mx + st - 1) // st
+            key = ((jy // st) * nsx + jx // st) * (st * st) + \
+                (((jy % st) // 2) * (st // 4) + (jx % st) // 4) * 8 + \
+                (jy % 2) * 4 + jx % 4
+            self.row_order = torch.argsort(key, stable=True).to(torch.int32)
+            order = self.row_order
+            slot_of_row = torch.empty(self.n_b, dtype=torch.int64,
+                                      device=self.device)
+            slot_of_row[order.to(torch.int64)] = torch.arange(
+                self.n_b, device=self.device)
+        else:
+            self.row_order = None
+            order = None
+            slot_of_row = torch.arange(self.n_b, device=self.device)
+        lens = self.rowptr[1:] - self.rowptr[:-1]
+        entry_slot = torch.repeat_interleave(slot_of_row, lens)
+        group_of_entry = entry_slot // G
+        member = entry_slot % G
+        n_groups = (self.n_b + G - 1) // G
+        key = group_of_entry * self.n_a + self.col.to(torch.int64)
+        uniq, inverse = torch.unique(key, sorted=True, return_inverse=True)
+        nu = int(uniq.shape[0])
+        ptr = torch.zeros(n_groups + 1, dtype=torch.int64,
+                          device=self.device)
+        ptr[1:] = torch.cumsum(torch.bincount(uniq // self.n_a,
+                                              minlength=n_groups), 0)
+        w = torch.zeros((nu + 8) * G, dtype=torch.float64,
+                        device=self.device)
+        w[inverse * G + member] = self.val
+        mask = torch.zeros(nu + 8, dtype=torch.int32, device=self.device)
+        mask.index_add_(0, inverse, (1 << member).to(torch.int32))
+        col = torch.zeros(nu + 8, dtype=torch.int32, device=self.device)
+        col[:nu] = (uniq % self.n_a).to(torch.int32)
+        self.groups = dict(ptr=ptr, col=col, w=w, mask=mask, n=n_groups,
+                           order=order, union=nu)
+        return nu / self.nnz
+
     #: tiles tried by auto_schedule, largest first
     AUTO_TILES = ((24, 24), (16, 16), (8, 16), (8, 8), (6, 8), (4, 8))
 
@@ -482,6 +554,7 @@ class RemapPlan:
         the description of what was chosen.
         """
         self.patches = None
+        self.groups = None
         self.row_order = None
         self.default_tune = None
         if grid_dims is None or self.nnz == 0 or self.n_b == 0:
@@ -513,14 +586,35 @@ class RemapPlan:
                 break
         self.patches = None
         self.row_order = None
-        # Entry-rich rows (wide stencils, e.g. 2nd-order conservative): the
-        # band of source rows shared by consecutive grid lines outgrows the
-        # 4 MiB L2 of an XCD and every re-touch goes to Infinity Cache
-        # (config 5: 320 GB of fabric reads for 30 GB of X).  Walking the
-        # grid in 32 x 32 tiles with 2 K-tiles per wave keeps the band in L2:
-        # measured -22 % there, neutral or slightly negative on rows with
-        # < 10 entries, hence the threshold.
-        if len(dims) == 2 and entry_rich:
+        # Row groups: 8 neighbouring rows per wave over the union of their
+        # columns (family 10).  Measured:
+        #  * entry-rich rows (>= 10 entries: wide stencils, config 5): groups
+        #    nested in 32 x 32 supertiles so the stencil band stays in the
+        #    XCD's L2 -- 1.9x in frac_b mode (2 K-tiles), 1.2x masked (1);
+        #  * other mappings: groups in row-major order, +3..6 % in frac_b /
+        #    raw mode; masked mode keeps the rowscalar kernel (the group
+        #    kernel's 120 VGPRs cost occupancy there).
+        # Only when rows really share columns (union / entries <= 0.85).
+        two_d = len(dims) == 2
+        ratio = self.build_groups(dims if two_d else None,
+                                  super_tile=32 if entry_rich else 1 << 30)
+        if ratio is not None and ratio <= 0.85:
+            if entry_rich:
+                self.default_tune = {MODE_RAW: [10, 0, 2, 2],
+                                     MODE_FRACB: [10, 0, 2, 2],
+                                     MODE_MASKED: [10, 0, 1, 2]}
+            else:
+                self.default_tune = {MODE_RAW: [10, 0, 1, 1],
+                                     MODE_FRACB: [10, 0, 1, 1],
+                                     MODE_MASKED: None}
+            return {'family': 'rowgroup', 'union_ratio': ratio,
+                    'order': '2x4 groups in 32x32 supertiles' if entry_rich
+                    else '2x4 groups, row-major' if two_d else
+                    '8 consecutive rows', 'tune': self.default_tune}
+        self.groups = None
+        self.row_order = None
+        if two_d and entry_rich:
+            # no sharing to exploit in registers: still keep the band in L2
             self.set_grid_schedule(dims, 'tile', (32, 32))
             self.default_tune = [6, 0, 2, 4, 2]   # vec stays automatic
             return {'family': 'rowscalar', 'order': 'tile 32x32',
@@ -613,9 +707,25 @@ def apply_strided(plan, X, Y, *, n_batch, k_inner, x_row_stride,
         args.patch_emax = patches['emax']
         args.patch_row_bytes = patches['row_bytes']
         args.n_patches = patches['n']
+    groups = plan.groups
+    if groups is not None and row_begin == 0 and args.row_end == plan.n_b \
+            and (plan.row_order is None) == (groups['order'] is None) \
+            and (plan.row_order is None or
+                 plan.row_order.data_ptr() == groups['order'].data_ptr()):
+        args.group_ptr = groups['ptr'].data_ptr()
+        args.group_col = groups['col'].data_ptr()
+        args.group_w = groups['w'].data_ptr()
+        args.group_mask = groups['mask'].data_ptr()
+        args.n_groups = groups['n']
     args.flags = flags
     if not tune:
+        # the plan's preference (auto_schedule); the library falls back to
+        # its own choice where the preferred family cannot serve the call
         tune = plan.default_tune
+        if isinstance(tune, dict):
+            tune = tune.get(mode)
+        if tune:
+            args.flags = flags | FLAG_TUNE_HINT
     if tune:
         for i, v in enumerate(tune):
             args.tune[i] = int(v)

@@ -609,17 +609,37 @@ def test_apply_is_graph_capturable(dev):
                        torch.nan_to_num(-2.0 * expect1, nan=1e300))
 
 
+def _random_map(n_a, dst_dims, per_row, seed, dev):
+    """No structure at all: every destination row draws random source rows."""
+    from types import SimpleNamespace
+    rng = np.random.default_rng(seed)
+    n_b = int(np.prod(dst_dims))
+    row = np.repeat(np.arange(1, n_b + 1, dtype=np.int32), per_row)
+    col = rng.integers(1, n_a + 1, size=row.size).astype(np.int32)
+    S = rng.random(row.size)
+    frac_b = 0.5 + 0.5 * rng.random(n_b)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    return SimpleNamespace(row=t(row), col=t(col), S=t(S), frac_b=t(frac_b),
+                           n_a=n_a, n_b=n_b, dst_dims=dst_dims)
+
+
 def test_auto_schedule_picks_by_reuse(dev):
-    """Patches for a coarse -> fine bilinear map (heavy source-row reuse),
-    the register-gather kernel for a 1:1 conservative map; both bit-exact,
-    including on a row shard of the patch-scheduled mapping."""
+    """Patches for a coarse -> fine bilinear map (heavy source-row reuse), row
+    groups where neighbouring rows share some source rows (in 32 x 32
+    supertiles for entry-rich rows), the plain register-gather kernel when
+    they share nothing.  Whatever is chosen is bit-exact in every mode, for
+    widths the preferred kernel cannot serve (the tune is a hint), and on a
+    row shard that schedules itself."""
     from oracle import oracle
     from pyremap_amd import engine, synthetic
     cases = [
         (synthetic.bilinear_map((20, 30), (200, 300), seed=1, device=dev),
          'patch'),
         (synthetic.conservative_map(30000, (150, 200), 3, 7, seed=2,
-                                    device=dev), 'rowscalar'),
+                                    device=dev), 'rowgroup'),
+        (synthetic.conservative_map(30000, (96, 160), 12, 24, seed=3,
+                                    device=dev), 'rowgroup'),
+        (_random_map(5000, (64, 96), 4, 4, dev), 'rowscalar'),
     ]
     rng = np.random.default_rng(0)
     for m, expect in cases:
@@ -628,15 +648,25 @@ def test_auto_schedule_picks_by_reuse(dev):
         choice = plan.auto_schedule(m.dst_dims)
         assert choice['family'] == expect, choice
         assert (plan.patches is not None) == (expect == 'patch')
+        assert (plan.groups is not None) == (expect == 'rowgroup')
         rowptr, col, val = plan.to_host_csr()
         csr = oracle.OracleCSR(rowptr, col, val, (m.n_b, m.n_a))
         frac_b = m.frac_b.cpu().numpy()
-        x = rng.standard_normal((m.n_a, 192))
-        ref, mask = oracle.remap_flat(csr, frac_b, x, False, 0.0, nthreads=4)
-        ref[mask] = np.nan
-        xd = torch.from_numpy(x).to(dev)
-        y = engine.remap_tensor(plan, m.dst_dims, xd, [0], engine.MODE_FRACB)
-        assert_bitwise(y.cpu().numpy().reshape(m.n_b, 192), ref, expect)
+        for K, masked in ((192, False), (192, True), (24, False),
+                          (129, True), (320, False)):
+            x = rng.standard_normal((m.n_a, K))
+            if masked:
+                x[rng.random(x.shape) < 0.2] = np.nan
+            ref, mask = oracle.remap_flat(csr, frac_b, x, masked, 0.05,
+                                          nthreads=4)
+            ref[mask] = np.nan
+            xd = torch.from_numpy(x).to(dev)
+            y = engine.remap_tensor(
+                plan, m.dst_dims, xd, [0],
+                engine.MODE_MASKED if masked else engine.MODE_FRACB,
+                threshold=0.05)
+            assert_bitwise(y.cpu().numpy().reshape(m.n_b, K), ref,
+                           f'{expect} K={K} masked={masked}')
         # a shard schedules itself over its own rows of the global grid
         shard = plan.shard(1, 3)
         shard.auto_schedule(m.dst_dims)
@@ -644,3 +674,51 @@ def test_auto_schedule_picks_by_reuse(dev):
         r0 = shard.row_offset
         assert_bitwise(ys.cpu().numpy(), ref[r0:r0 + shard.n_b],
                        f'{expect} shard')
+
+
+# ---------------------------------------------------------------------------
+# row-group family: 8 rows per wave over the union of their columns
+# ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize('grid', ['2d', '1d'])
+@pytest.mark.parametrize('K', [64, 128, 130, 320, 512])
+def test_rowgroup_kernel_bitwise(dev, grid, K):
+    from oracle import oracle
+    from pyremap_amd import engine, synthetic
+    # 1502 destination rows: the last group is partial; wide stencils
+    m = synthetic.conservative_map(1500, (23, 40) if grid == '2d' else
+                                   (1, 1502 // 1 if False else 920), 3, 14,
+                                   seed=17, signed=True)
+    mm = m.numpy()
+    plan = engine.RemapPlan.from_triplets(mm['row'], mm['col'], mm['S'],
+                                          mm['frac_b'], m.n_a, m.n_b,
+                                          device=dev)
+    ratio = plan.build_groups(m.dst_dims if grid == '2d' else None)
+    assert 0 < ratio <= 1
+    assert (plan.row_order is not None) == (grid == '2d')
+    csr = oracle.coo_to_csr(mm['row'] - 1, mm['col'] - 1, mm['S'], m.n_b,
+                            m.n_a)
+    rng = np.random.default_rng(K)
+    x = rng.standard_normal((m.n_a, K))
+    x[rng.random(m.n_a) < 0.2, :] = np.nan
+    xd = torch.from_numpy(x).to(dev)
+    for emode, masked in ((engine.MODE_FRACB, False),
+                          (engine.MODE_MASKED, True),
+                          (engine.MODE_RAW, False)):
+        if emode == engine.MODE_RAW:
+            ref = oracle.csr_matvecs(csr, x)
+            ref_mask = np.zeros_like(ref, dtype=bool)
+        else:
+            ref, ref_mask = oracle.remap_flat(csr, mm['frac_b'], x, masked,
+                                              0.1)
+            ref[ref_mask] = np.nan
+        for tune in ([10], [10, 0, 2, 1], [10, 0, 1, 3, 1]):
+            y = torch.full((m.n_b, K), 3.0, dtype=torch.float64, device=dev)
+            mask = torch.full((m.n_b, K), 7, dtype=torch.uint8, device=dev)
+            engine.apply_strided(plan, xd, y, n_batch=1, k_inner=K,
+                                 x_row_stride=K, x_batch_stride=0,
+                                 y_row_stride=K, y_batch_stride=0,
+                                 mode=emode, threshold=0.1, mask_out=mask,
+                                 tune=tune)
+            assert np.array_equal(mask.cpu().numpy().astype(bool), ref_mask)
+            assert_bitwise(y.cpu().numpy(), ref, f'{grid} K={K} {tune}')

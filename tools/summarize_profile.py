@@ -32,8 +32,24 @@ def main():
              '`rocprofv3 --pmc ...` pass over `bench.py --steps 20 --warmup '
              '3 --no-cpu --no-extra`.', '']
 
-    stats = glob.glob(os.path.join(src, 'trace', '*', '*_kernel_stats.csv'))
+    # gpurun MERGES a run's files into gpurun_out/: files of earlier runs
+    # under the same tag may still be there.  tools/profile.sh ends with a
+    # listing of what THIS run wrote -- keep to it when it is available.
+    listing = os.path.join(REPO, 'gpurun_out', f'profile_{tag}.log')
+    current = None
+    if os.path.exists(listing):
+        current = {os.path.basename(line.strip())
+                   for line in open(listing) if line.strip().endswith('.csv')}
+
+    def only_current(paths):
+        if not current:
+            return paths
+        return [q for q in paths if os.path.basename(q) in current]
+
+    stats = only_current(glob.glob(
+        os.path.join(src, 'trace', '*', '*_kernel_stats.csv')))
     kernel_avg_ns = None
+    kernel_name = None
     if stats:
         rows = list(csv.DictReader(open(stats[0])))
         keep = [r for r in rows if 'remap::' in r['Name']][:6]
@@ -54,11 +70,12 @@ def main():
                          f"{r['MaxNs']} |")
             if 'spmm' in r['Name'] and kernel_avg_ns is None:
                 kernel_avg_ns = float(r['AverageNs'])
+                kernel_name = name.split('<')[0].replace('remap::', '')
         lines.append('')
 
     pmc = collections.OrderedDict()
-    for path in sorted(glob.glob(os.path.join(src, 'pmc_*', '*',
-                                              '*_counter_collection.csv'))):
+    for path in only_current(sorted(glob.glob(os.path.join(
+            src, 'pmc_*', '*', '*_counter_collection.csv')))):
         per = collections.defaultdict(list)
         for r in csv.DictReader(open(path)):
             if 'spmm_' in r['Kernel_Name']:
@@ -89,7 +106,7 @@ def main():
             hbm_bytes_per_launch=fetch + write,
             fetch_size_raw_kib=pmc['FETCH_SIZE'][0],
             write_size_raw_kib=pmc['WRITE_SIZE'][0],
-            kernel_avg_ns_rocprof=kernel_avg_ns,
+            kernel_avg_ns_rocprof=kernel_avg_ns, kernel=kernel_name,
             source=f'profiles/{tag}_summary.md: rocprofv3 --pmc FETCH_SIZE '
                    f'and --pmc WRITE_SIZE (separate passes); FETCH_SIZE x '
                    f'1024 x 2 (gfx950 half-count correction for 16 B/lane '

@@ -58,7 +58,17 @@ def main():
     variants = []
     orders = {}
     patch_sets = {}
+    group_sets = {}
     for o in args.orders.split(';'):
+        if o.startswith('group'):
+            st = int(o.split(':')[1]) if ':' in o else 32
+            ratio = plan.build_groups(
+                None if o.startswith('group1d') else m.dst_dims,
+                super_tile=st)
+            print(f'{o}: union/nnz = {ratio}')
+            orders[o] = plan.row_order
+            group_sets[o] = plan.groups
+            continue
         if o.startswith('patch'):
             ty, tx = o.split(':')[1].split('x')
             ratio = plan.build_patches(
@@ -93,6 +103,7 @@ def main():
         fl, tune, o = v
         plan.row_order = orders[o]
         plan.patches = patch_sets.get(o)
+        plan.groups = group_sets.get(o)
         s = i % args.sets
         engine.apply_strided(plan, xs[s], ys[s], n_batch=1, k_inner=K,
                              x_row_stride=K, x_batch_stride=0,
