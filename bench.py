@@ -99,28 +99,45 @@ def barrier(dist):
 
 
 def time_steps(launch, steps, warmup, dist):
-    """warmup untimed, then EXACTLY `steps` timed; returns (wall_s, [ms])."""
+    """
+    warmup untimed, then EXACTLY `steps` timed between barrier + synchronize.
+    Returns (wall_s, mean_ms, [per-launch ms]).
+
+    ``mean_ms`` is the average launch duration over the timed region: ONE pair
+    of HIP events on the launch stream (torch's current stream is the stream
+    handed to the C ABI) around the `steps` back-to-back launches.  An event
+    pair per step costs 7.6 us per step (tools/launch_gap.py) -- 2 % of a
+    full config-3 launch, 12 % of a 1/8 row shard -- so the per-launch
+    spread (median / min) comes from a second, untimed pass.
+    """
     import torch
     for i in range(warmup):
         launch(i)
-    events = [(torch.cuda.Event(enable_timing=True),
-               torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    first = torch.cuda.Event(enable_timing=True)
+    last = torch.cuda.Event(enable_timing=True)
     barrier(dist)
     t0 = time.perf_counter()
+    first.record()
     for i in range(steps):
-        # HIP events on the launch stream (torch's current stream is the
-        # stream handed to the C ABI)
-        events[i][0].record()
         launch(warmup + i)
-        events[i][1].record()
+    last.record()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([wall], device='cuda', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
+    mean_ms = first.elapsed_time(last) / steps
+    n = min(steps, 50)
+    events = [(torch.cuda.Event(enable_timing=True),
+               torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for i in range(n):
+        events[i][0].record()
+        launch(warmup + i)
+        events[i][1].record()
+    torch.cuda.synchronize()
     per_launch = [a.elapsed_time(b) for a, b in events]
-    return wall, per_launch
+    return wall, mean_ms, per_launch
 
 
 def make_fields(n_a, K, layout, sets, seed, device, nan_frac=0.0):
@@ -208,9 +225,8 @@ def run_workload(name, args, rank, world, dist, K=None, mode=None,
 
     launch(0)
     torch.cuda.synchronize()
-    wall, per_launch = time_steps(launch, steps, warmup, dist)
+    wall, mean_ms, per_launch = time_steps(launch, steps, warmup, dist)
     per_launch.sort()
-    mean_ms = sum(per_launch) / len(per_launch)
     # algorithmic bytes of ONE launch on this rank; a row
     # shard reads at most the whole of X
     bytes_alg = plan.algorithmic_bytes(K_local, 8, emode)

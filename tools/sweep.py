@@ -35,6 +35,8 @@ def main():
     ap.add_argument('--pmc', type=int, default=0,
                     help='counter mode: launch each variant N times in '
                          'order, no timing (run under rocprofv3 --pmc)')
+    ap.add_argument('--shard', default=None,
+                    help="R/N: time the rows rank R of N would own")
     ap.add_argument('--orders', default='none',
                     help="';'-separated: none | morton | tile:TYxTX")
     args = ap.parse_args()
@@ -45,6 +47,11 @@ def main():
                               locality=args.locality)
     plan = engine.RemapPlan.from_triplets(m.row, m.col, m.S, m.frac_b, m.n_a,
                                           m.n_b, device=dev)
+    if args.shard:
+        r, n = (int(v) for v in args.shard.split('/'))
+        plan = plan.shard(r, n)
+        print(f'shard {r}/{n}: rows [{plan.row_offset}, '
+              f'{plan.row_offset + plan.n_b}) nnz {plan.nnz}')
     mode = {'fracb': engine.MODE_FRACB, 'masked': engine.MODE_MASKED,
             'raw': engine.MODE_RAW}[args.mode]
     dt = torch.float64 if args.dtype == 'f64' else torch.float32
@@ -53,7 +60,7 @@ def main():
     if args.mode == 'masked':
         for x in xs:
             x[torch.rand(m.n_a, device=dev) < 0.25, :] = float('nan')
-    ys = [torch.empty((m.n_b, K), device=dev, dtype=torch.float64)
+    ys = [torch.empty((plan.n_b, K), device=dev, dtype=torch.float64)
           for _ in range(args.sets)]
     variants = []
     orders = {}
