@@ -17,6 +17,10 @@ from pyremap_amd.descriptor import (  # noqa: F401
     ProjectionGridDescriptor,
     get_lat_lon_descriptor,
 )
+from pyremap_amd.polar import (  # noqa: F401
+    get_polar_descriptor,
+    get_polar_descriptor_from_file,
+)
 from pyremap_amd.remapper import Remapper  # noqa: F401
 from pyremap_amd.xr_lite import DataArray, Dataset  # noqa: F401
 

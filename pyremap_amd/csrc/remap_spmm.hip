@@ -1221,7 +1221,11 @@ int apply(const remap_apply_args *a, hipStream_t stream)
                         "remap_apply_f64: the rowgroup kernel needs the "
                         "row-group schedule for [row_begin, row_end), even "
                         "strides and 32-bit offsets");
-        int tiles = (a->tune[2] == 2 && K64 > 128) ? 2 : 1;
+        // f32 rows are half as long: two K tiles per wave keep the bytes per
+        // wave and row at 1 KiB (measured +7 % on config 3 with f32 fields)
+        int tiles = a->tune[2] == 0 ? (f32 ? 2 : 1) : a->tune[2];
+        if (tiles != 2 || K64 <= 128)
+            tiles = 1;
         int gpw = a->tune[3] > 0 ? a->tune[3] : 2;   // groups per wave
         const int64_t chunk_cols = (int64_t)kWave * 2 * tiles;
         const int64_t n_chunks = (K64 + chunk_cols - 1) / chunk_cols;
@@ -1310,7 +1314,7 @@ int apply(const remap_apply_args *a, hipStream_t stream)
             return fail(REMAP_ERR_ARG, "remap_apply_f64: tune[1] = %d", vec);
         int tiles = a->tune[2];
         if (tiles == 0)
-            tiles = (family == 1 && K64 >= 256) ? 2 : 1;  // measured best
+            tiles = ((family == 1 || f32) && K64 >= 256) ? 2 : 1;  // measured
         if (vec == 1)
             tiles = 1;
         if (tiles != 1 && tiles != 2 && tiles != 4)

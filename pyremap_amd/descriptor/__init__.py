@@ -17,3 +17,6 @@ from pyremap_amd.descriptor.descriptors import (  # noqa: F401
     ProjectionGridDescriptor,
     get_lat_lon_descriptor,
 )
+from pyremap_amd.descriptor.projection import (  # noqa: F401
+    PolarStereographic,
+)

@@ -12,8 +12,31 @@ import sys
 import numpy as np
 
 
-def _history():
-    return ' '.join(sys.argv[:])
+def _history(ds=None):
+    """This command line, appended to the file's own history if it has one
+    (``descriptor/utility.py:342-351``)."""
+    history = ' '.join(sys.argv[:])
+    if ds is not None and 'history' in ds.attrs:
+        prev = ds.attrs['history']
+        if isinstance(prev, np.ndarray):
+            prev = '\n'.join(str(p) for p in prev)
+        history = '\n'.join([str(prev), history])
+    return history
+
+
+def _open(filename):
+    from pyremap_amd.io.netcdf import open_dataset
+    return open_dataset(filename)
+
+
+def _units_of(var):
+    """'degrees' if the variable's units mention degrees, else 'radians'
+    (``lat_lon_grid_descriptor.py:158-161``; a missing attribute is an
+    AttributeError there and an error here as well)."""
+    if 'units' not in var.attrs:
+        raise AttributeError(
+            f"coordinate variable '{var.name}' has no 'units' attribute")
+    return 'degrees' if 'degree' in str(var.attrs['units']) else 'radians'
 
 
 def _round_res(res):
@@ -74,6 +97,30 @@ class LatLonGridDescriptor(MeshDescriptor):
         self.history = None
 
     @classmethod
+    def read(cls, filename=None, ds=None, lat_var_name='lat',
+             lon_var_name='lon', mesh_name=None, regional=None):
+        """
+        From the 1-D lat/lon variables of a file or dataset
+        (``lat_lon_grid_descriptor.py:112-178``): corners from contiguous CF
+        ``bounds`` when present, else extrapolated from the centres; the
+        dimension names are those of the two variables.
+        """
+        from pyremap_amd.descriptor.corners import corners_1d
+        if ds is None:
+            ds = _open(filename)
+        d = cls(mesh_name=mesh_name, regional=regional)
+        d.mesh_name_from_attr(ds)
+        d.lat = np.array(ds[lat_var_name].values, dtype=float)
+        d.lon = np.array(ds[lon_var_name].values, dtype=float)
+        d.units = _units_of(ds[lat_var_name])
+        d.lon_corner = corners_1d(ds, lon_var_name)
+        d.lat_corner = corners_1d(ds, lat_var_name)
+        d._set_coords(lat_var_name, lon_var_name, ds[lat_var_name].dims[0],
+                      ds[lon_var_name].dims[0])
+        d.history = _history(ds)
+        return d
+
+    @classmethod
     def create(cls, lat_corner, lon_corner, units='degrees', mesh_name=None,
                regional=None):
         """From corner arrays (``lat_lon_grid_descriptor.py:180-222``)."""
@@ -125,27 +172,81 @@ def get_lat_lon_descriptor(dlon, dlat, lon_min=-180.0, lon_max=180.0,
 class LatLon2DGridDescriptor(MeshDescriptor):
     """
     A grid with 2-D lat/lon arrays
-    (``lat_lon_2d_grid_descriptor.py:27,251-252``): dims ``[lat_dim, lon_dim]``
-    of the 2-D arrays.
+    (``lat_lon_2d_grid_descriptor.py:27,219-262``): dims ``[lat_dim, lon_dim]``
+    of the 2-D arrays; regional unless told otherwise (:66-67).
     """
+
+    def __init__(self, mesh_name=None, regional=None):
+        super().__init__(mesh_name=mesh_name,
+                         regional=True if regional is None else regional)
+        self.lat = None
+        self.lon = None
+        self.units = None
+        self.lat_corner = None
+        self.lon_corner = None
+        self.history = None
+
+    @classmethod
+    def read(cls, filename=None, ds=None, lat_var_name='lat',
+             lon_var_name='lon', mesh_name=None, regional=None):
+        """
+        From the 2-D lat/lon variables of a file or dataset
+        (``lat_lon_2d_grid_descriptor.py:78-148``); corners from CF bounds of
+        shape ``(ny, nx, 4)`` when neighbouring cells share vertices, else
+        extrapolated from the centres.
+        """
+        from pyremap_amd.descriptor.corners import corners_2d
+        if ds is None:
+            ds = _open(filename)
+        d = cls(mesh_name=mesh_name, regional=regional)
+        d.mesh_name_from_attr(ds)
+        d.lat = np.array(ds[lat_var_name].values, dtype=float)
+        d.lon = np.array(ds[lon_var_name].values, dtype=float)
+        d.units = _units_of(ds[lat_var_name])
+        d.lat_corner, d.lon_corner = corners_2d(ds, lat_var_name,
+                                                lon_var_name)
+        dims = ds[lat_var_name].dims
+        d._set_coords(lat_var_name, lon_var_name, dims[0], dims[1])
+        d.history = _history(ds)
+        return d
 
     @classmethod
     def create(cls, lat, lon, lat_dim='y', lon_dim='x', units='degrees',
                mesh_name=None, regional=True):
+        """From 2-D centre arrays (no reference counterpart: its only
+        constructor reads a file)."""
+        from pyremap_amd.descriptor.corners import extrapolate_corners_2d
         d = cls(mesh_name=mesh_name, regional=regional)
         d.lat = np.asarray(lat, dtype=np.float64)
         d.lon = np.asarray(lon, dtype=np.float64)
         d.units = units
+        d.lat_corner = extrapolate_corners_2d(d.lat)
+        d.lon_corner = extrapolate_corners_2d(d.lon)
         d.history = _history()
-        d.dims = [lat_dim, lon_dim]
-        d.dim_sizes = list(d.lat.shape)
-        d.coords = {
-            'lat': {'dims': (lat_dim, lon_dim), 'data': d.lat,
-                    'attrs': {'units': units}},
-            'lon': {'dims': (lat_dim, lon_dim), 'data': d.lon,
-                    'attrs': {'units': units}},
-        }
+        d._set_coords('lat', 'lon', lat_dim, lon_dim)
         return d
+
+    def _set_coords(self, lat_var, lon_var, lat_dim, lon_dim):
+        self.lat_var_name = lat_var
+        self.lon_var_name = lon_var
+        self.coords = {
+            lat_var: {'dims': (lat_dim, lon_dim), 'data': self.lat,
+                      'attrs': {'units': self.units}},
+            lon_var: {'dims': (lat_dim, lon_dim), 'data': self.lon,
+                      'attrs': {'units': self.units}},
+        }
+        self.dims = [lat_dim, lon_dim]
+        self.dim_sizes = self.lat.shape
+        if 'degree' in self.units:
+            unit = 'degree'
+        elif 'rad' in self.units:
+            unit = 'radian'
+        else:
+            raise ValueError(f'Could not figure out units {self.units}')
+        if self.mesh_name is None:
+            dlat = abs(self.lat[1, 0] - self.lat[0, 0])
+            dlon = abs(self.lon[0, 1] - self.lon[0, 0])
+            self.mesh_name = f'{_round_res(dlat)}x{_round_res(dlon)}{unit}'
 
 
 class MpasMeshDescriptor(MeshDescriptor):
@@ -243,10 +344,10 @@ class PointCollectionDescriptor(MeshDescriptor):
 class ProjectionGridDescriptor(MeshDescriptor):
     """
     A regular grid on a map projection
-    (``projection_grid_descriptor.py:28,286-321``): dims ``[y, x]``.  The
-    reference also attaches 2-D ``lat``/``lon`` coordinates computed with
-    pyproj; they are added here when pyproj is importable or when they are
-    passed in.
+    (``projection_grid_descriptor.py:28,286-321``): dims ``[y, x]``; coords
+    ``x, y`` (metres) and 2-D ``lat, lon`` (degrees) computed through the
+    projection -- a ``pyproj.Proj`` when pyproj is importable, or this
+    package's :class:`~pyremap_amd.descriptor.projection.PolarStereographic`.
     """
 
     def __init__(self, projection=None, mesh_name=None):
@@ -257,49 +358,70 @@ class ProjectionGridDescriptor(MeshDescriptor):
         self.x_corner = None
         self.y_corner = None
         self.history = None
+        self.x_var_name = None
+        self.y_var_name = None
+
+    @classmethod
+    def read(cls, projection, filename=None, mesh_name=None, x_var_name='x',
+             y_var_name='y', ds=None):
+        """
+        From the 1-D x/y variables (metres) of a grid file
+        (``projection_grid_descriptor.py:91-148``); the name comes from the
+        argument or the file's ``mesh_name`` / ``meshName`` attribute.
+        """
+        from pyremap_amd.descriptor.corners import corners_1d
+        if ds is None:
+            ds = _open(filename)
+        d = cls(projection, mesh_name=mesh_name)
+        d.mesh_name_from_attr(ds)
+        if d.mesh_name is None:
+            raise ValueError('No mesh_name provided or found in file.')
+        d.x = np.array(ds[x_var_name].values, dtype=float)
+        d.y = np.array(ds[y_var_name].values, dtype=float)
+        d._set_coords(x_var_name, y_var_name, ds[x_var_name].dims[0],
+                      ds[y_var_name].dims[0])
+        d.x_corner = corners_1d(ds, x_var_name)
+        d.y_corner = corners_1d(ds, y_var_name)
+        d.history = _history(ds)
+        return d
 
     @classmethod
     def create(cls, projection, x, y, mesh_name, lat=None, lon=None):
+        """From centre axes (``projection_grid_descriptor.py:150-185``).
+        ``lat``/``lon`` may be passed when no projection object is at hand."""
+        from pyremap_amd.descriptor.corners import extrapolate_corners_1d
         d = cls(projection, mesh_name=mesh_name)
         d.x = np.asarray(x, dtype=np.float64)
         d.y = np.asarray(y, dtype=np.float64)
-        d.x_corner = _corners_1d(d.x)
-        d.y_corner = _corners_1d(d.y)
+        d._set_coords('x', 'y', 'x', 'y', lat=lat, lon=lon)
+        d.x_corner = extrapolate_corners_1d(d.x)
+        d.y_corner = extrapolate_corners_1d(d.y)
         d.history = _history()
-        d.x_var_name, d.y_var_name = 'x', 'y'
-        d.coords = {
-            'x': {'dims': 'x', 'data': d.x, 'attrs': {'units': 'meters'}},
-            'y': {'dims': 'y', 'data': d.y, 'attrs': {'units': 'meters'}},
-        }
-        if lat is None and projection is not None:
-            lat, lon = _project_to_lat_lon(projection, d.x, d.y)
-        if lat is not None:
-            d.coords['lat'] = {'dims': ('y', 'x'), 'data': np.asarray(lat),
-                               'attrs': {'units': 'degrees'}}
-            d.coords['lon'] = {'dims': ('y', 'x'), 'data': np.asarray(lon),
-                               'attrs': {'units': 'degrees'}}
-        d.dims = ['y', 'x']
-        d.dim_sizes = [len(d.y), len(d.x)]
         return d
 
+    def project_to_lat_lon(self, x, y):
+        """``projection_grid_descriptor.py:258-284``: (lat, lon) in degrees."""
+        from pyremap_amd.descriptor.projection import project_to_lat_lon
+        return project_to_lat_lon(self.projection, x, y)
 
-def _corners_1d(centres):
-    """Extrapolated cell edges of a 1-D axis (``utility.py:220-228``)."""
-    c = np.asarray(centres, dtype=np.float64)
-    out = np.zeros(len(c) + 1)
-    out[1:-1] = 0.5 * (c[:-1] + c[1:])
-    out[0] = 1.5 * c[0] - 0.5 * c[1]
-    out[-1] = 1.5 * c[-1] - 0.5 * c[-2]
-    return out
-
-
-def _project_to_lat_lon(projection, x, y):
-    try:
-        import pyproj
-    except ImportError:
-        return None, None
-    lat_lon = pyproj.Proj(proj='latlong', datum='WGS84')
-    xx, yy = np.meshgrid(x, y)
-    transformer = pyproj.Transformer.from_proj(projection, lat_lon)
-    lon, lat = transformer.transform(xx, yy)
-    return lat, lon
+    def _set_coords(self, x_var, y_var, x_dim, y_dim, lat=None, lon=None):
+        self.x_var_name = x_var
+        self.y_var_name = y_var
+        self.coords = {
+            x_var: {'dims': x_dim, 'data': self.x,
+                    'attrs': {'units': 'meters'}},
+            y_var: {'dims': y_dim, 'data': self.y,
+                    'attrs': {'units': 'meters'}},
+        }
+        if lat is None:
+            xx, yy = np.meshgrid(self.x, self.y)
+            lat, lon = self.project_to_lat_lon(xx, yy)
+        if lat is not None:
+            self.coords['lat'] = {'dims': (y_dim, x_dim),
+                                  'data': np.asarray(lat),
+                                  'attrs': {'units': 'degrees'}}
+            self.coords['lon'] = {'dims': (y_dim, x_dim),
+                                  'data': np.asarray(lon),
+                                  'attrs': {'units': 'degrees'}}
+        self.dims = [y_dim, x_dim]
+        self.dim_sizes = [len(self.y), len(self.x)]

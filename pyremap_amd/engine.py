@@ -604,8 +604,8 @@ class RemapPlan:
                                      MODE_FRACB: [10, 0, 2, 2],
                                      MODE_MASKED: [10, 0, 1, 2]}
             else:
-                self.default_tune = {MODE_RAW: [10, 0, 1, 1],
-                                     MODE_FRACB: [10, 0, 1, 1],
+                self.default_tune = {MODE_RAW: [10, 0, 0, 1],
+                                     MODE_FRACB: [10, 0, 0, 1],
                                      MODE_MASKED: None}
             return {'family': 'rowgroup', 'union_ratio': ratio,
                     'order': '2x4 groups in 32x32 supertiles' if entry_rich

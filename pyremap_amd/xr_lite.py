@@ -61,6 +61,19 @@ class DataArray:
             for cname, cval in coords.items():
                 self.coords[cname] = _as_coord(cname, cval)
 
+    def __getattr__(self, name):
+        # ``da.units`` / ``da.lat``: attributes first, then coordinates
+        if name.startswith('_'):
+            raise AttributeError(name)
+        attrs = self.__dict__.get('attrs', {})
+        if name in attrs:
+            return attrs[name]
+        coords = self.__dict__.get('coords', {})
+        if name in coords:
+            return coords[name]
+        raise AttributeError(
+            f"'DataArray' object has no attribute '{name}'")
+
     # -- array-like members ------------------------------------------------
     @property
     def values(self):
@@ -273,8 +286,24 @@ class Dataset:
                     coords[cname] = cvar
         if name in self._coord_names and var.dims == (name,):
             coords[name] = var
-        return DataArray(var.values, coords=coords, dims=var.dims,
-                         name=name, attrs=var.attrs)
+        da = DataArray(var.values, coords=coords, dims=var.dims, name=name)
+        # as in xarray, the variable's attrs / encoding are shared, so
+        # ``ds['lat'].attrs['units'] = ...`` sticks
+        da.attrs = var.attrs
+        da.encoding = var.encoding
+        return da
+
+    def __getattr__(self, name):
+        # ``ds.x`` / ``ds.title``: variables first, then global attributes
+        if name.startswith('_'):
+            raise AttributeError(name)
+        if name in self.__dict__.get('_vars', ()):
+            return self[name]
+        attrs = self.__dict__.get('attrs', {})
+        if name in attrs:
+            return attrs[name]
+        raise AttributeError(
+            f"'Dataset' object has no attribute '{name}'")
 
     def __repr__(self):
         lines = [f'<pyremap_amd.Dataset {dict(self.sizes)}>']

@@ -1,0 +1,240 @@
+"""
+Descriptor constructors against goldens captured
+from the reference's own classes (oracle/make_descriptor_goldens.py), plus the
+polar-stereographic pieces that stand in for pyproj.  CPU only.
+"""
+import json
+import os
+import sys
+import warnings
+
+import numpy as np
+import pytest
+
+import pyremap_amd
+from pyremap_amd import xr_lite
+from pyremap_amd.descriptor import (
+    LatLon2DGridDescriptor,
+    LatLonGridDescriptor,
+    PolarStereographic,
+    ProjectionGridDescriptor,
+    get_lat_lon_descriptor,
+)
+from pyremap_amd.io.netcdf import write_netcdf
+
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden',
+                      'g4_descriptors.npz')
+
+
+@pytest.fixture(scope='module')
+def golden():
+    return np.load(GOLDEN)
+
+
+def _index(golden):
+    return json.loads(str(golden['index']))
+
+
+def _dataset(golden, name, meta):
+    ds = xr_lite.Dataset()
+    two_d = meta['two_d']
+    lat_dims = (meta['lat_dim'], meta['lon_dim']) if two_d else \
+        (meta['lat_dim'],)
+    lon_dims = lat_dims if two_d else (meta['lon_dim'],)
+    lat = golden[f'{name}/in/lat']
+    lon = golden[f'{name}/in/lon']
+    ds[meta['lat_var']] = (lat_dims, lat)
+    ds[meta['lon_var']] = (lon_dims, lon)
+    for which, var, dims, centres in (
+            ('lat', meta['lat_var'], lat_dims, lat),
+            ('lon', meta['lon_var'], lon_dims, lon)):
+        ds[var].attrs['units'] = meta['units_attr']
+        key = f'{name}/in/{which}_bnds'
+        if key in golden.files:
+            b = golden[key]
+            fits = b.shape[:-1] == centres.shape
+            bdims = dims if fits else tuple(f'{d}_odd' for d in dims)
+            ds[f'{which}_bnds'] = (bdims + ('nv',), b)
+        if meta[f'{which}_bounds_attr'] is not None:
+            ds[var].attrs['bounds'] = meta[f'{which}_bounds_attr']
+    for k, v in meta['ds_attrs'].items():
+        ds.attrs[k] = v
+    return ds
+
+
+def _read_cases():
+    g = np.load(GOLDEN)
+    return json.loads(str(g['index']))['read']
+
+
+@pytest.mark.parametrize('name', _read_cases())
+def test_read_matches_reference(golden, name, monkeypatch):
+    meta = json.loads(str(golden[f'{name}/meta']))
+    ds = _dataset(golden, name, meta)
+    cls = LatLon2DGridDescriptor if meta['two_d'] else LatLonGridDescriptor
+    monkeypatch.setattr(sys, 'argv', ['golden'])
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter('always')
+        d = cls.read(ds=ds, lat_var_name=meta['lat_var'],
+                     lon_var_name=meta['lon_var'],
+                     mesh_name=meta['arg_mesh_name'],
+                     regional=meta['arg_regional'])
+    for k in ('lat', 'lon', 'lat_corner', 'lon_corner'):
+        np.testing.assert_array_equal(np.asarray(getattr(d, k)),
+                                      golden[f'{name}/out/{k}'], err_msg=k)
+    assert d.mesh_name == meta['mesh_name']
+    assert bool(d.regional) == meta['regional']
+    assert list(d.dims) == meta['dims']
+    assert [int(v) for v in d.dim_sizes] == meta['dim_sizes']
+    assert d.units == meta['units']
+    assert d.history == meta['history']
+    assert sorted(d.coords.keys()) == meta['coords_keys']
+    assert [str(w.message) for w in caught] == meta['warnings']
+    for w in caught:
+        # raised on behalf of the caller, not deep inside the package
+        assert w.category is UserWarning
+
+
+def test_read_from_file_equals_read_from_dataset(golden, tmp_path):
+    """filename= goes through this package's own NetCDF reader."""
+    for name in ('bounds_contiguous', '2d_bounds_clockwise_from_ur'):
+        meta = json.loads(str(golden[f'{name}/meta']))
+        ds = _dataset(golden, name, meta)
+        path = str(tmp_path / f'{name}.nc')
+        write_netcdf(ds, path)
+        cls = LatLon2DGridDescriptor if meta['two_d'] else \
+            LatLonGridDescriptor
+        d = cls.read(filename=path, lat_var_name=meta['lat_var'],
+                     lon_var_name=meta['lon_var'])
+        for k in ('lat', 'lon', 'lat_corner', 'lon_corner'):
+            np.testing.assert_array_equal(np.asarray(getattr(d, k)),
+                                          golden[f'{name}/out/{k}'])
+        assert d.mesh_name == meta['mesh_name']
+        assert list(d.dims) == meta['dims']
+
+
+def test_get_lat_lon_descriptor_matches_reference(golden):
+    for tag in _index(golden)['create']:
+        args = [float(v) for v in golden[f'create/{tag}/args']]
+        d = get_lat_lon_descriptor(*args)
+        meta = json.loads(str(golden[f'create/{tag}/meta']))
+        for k in ('lat', 'lon', 'lat_corner', 'lon_corner'):
+            np.testing.assert_array_equal(getattr(d, k),
+                                          golden[f'create/{tag}/{k}'])
+        assert d.mesh_name == meta['mesh_name']
+        assert bool(d.regional) == meta['regional']
+        assert list(d.dims) == meta['dims']
+        assert [int(v) for v in d.dim_sizes] == meta['dim_sizes']
+        assert d.units == meta['units']
+
+
+def test_missing_units_is_an_error():
+    ds = xr_lite.Dataset()
+    ds['lat'] = (('lat',), np.linspace(-10, 10, 5))
+    ds['lon'] = (('lon',), np.linspace(0, 40, 5))
+    with pytest.raises(AttributeError):
+        LatLonGridDescriptor.read(ds=ds)
+
+
+# ---------------------------------------------------------------------------
+# polar stereographic (stands in for pyproj, absent from the image)
+# ---------------------------------------------------------------------------
+
+def test_polar_stereographic_known_values():
+    """EPSG:3031 (lat_ts -71, lon_0 0): published values of the projection --
+    the standard parallel maps to a * m(71 deg) and 60 S on the Greenwich
+    meridian to y = 3 333 134.03 m."""
+    p = PolarStereographic(lat_ts=-71.0, lat_0=-90.0)
+    e2 = 0.00669437999014
+    m71 = np.cos(np.radians(71.0)) / np.sqrt(
+        1.0 - e2 * np.sin(np.radians(71.0)) ** 2)
+    x, y = p.forward(0.0, -71.0)
+    assert abs(x) < 1e-6 and abs(y - 6378137.0 * m71) < 1e-5
+    x, y = p.forward(0.0, -60.0)
+    assert abs(y - 3333134.03) < 0.01
+    x, y = p.forward(90.0, -71.0)            # 90 E is +x in EPSG:3031
+    assert abs(x - 6378137.0 * m71) < 1e-5 and abs(y) < 1e-6
+    lon, lat = p.inverse(0.0, 0.0)
+    assert lat == -90.0
+
+
+@pytest.mark.parametrize('south', [True, False])
+def test_polar_stereographic_round_trip(south):
+    rng = np.random.default_rng(5)
+    p = PolarStereographic(lat_ts=-71.0 if south else 75.0,
+                           lat_0=-90.0 if south else 90.0, lon_0=0.0)
+    lon = rng.uniform(-180.0, 180.0, 2000)
+    lat = rng.uniform(35.0, 89.999, 2000) * (-1.0 if south else 1.0)
+    x, y = p.forward(lon, lat)
+    lon2, lat2 = p.inverse(x, y)
+    assert np.abs(lat2 - lat).max() < 1e-11
+    assert np.abs((lon2 - lon + 180.0) % 360.0 - 180.0).max() < 1e-10
+    # conformal: local scale equal along meridian and parallel
+    eps = 1e-6
+    x1, y1 = p.forward(lon + eps, lat)
+    x2, y2 = p.forward(lon, lat + eps)
+    e2 = 0.00669437999014
+    s = np.sin(np.radians(lat))
+    n_radius = 6378137.0 / np.sqrt(1 - e2 * s * s)
+    m_radius = 6378137.0 * (1 - e2) / (1 - e2 * s * s) ** 1.5
+    k_par = np.hypot(x1 - x, y1 - y) / (
+        np.radians(eps) * n_radius * np.cos(np.radians(lat)))
+    k_mer = np.hypot(x2 - x, y2 - y) / (np.radians(eps) * m_radius)
+    assert np.abs(k_par / k_mer - 1.0).max() < 1e-5
+
+
+def test_get_polar_descriptor():
+    """``polar.py:86-124`` / the reference's Antarctic comparison grid
+    (6000 x 5000 km, examples/make_mpas_to_antarctic_stereo_mapping.py)."""
+    d = pyremap_amd.get_polar_descriptor(6000.0, 5000.0, 10.0, 10.0)
+    assert d.mesh_name == '6000.0x5000.0km_10.0km_Antarctic_stereo'
+    assert d.dims == ['y', 'x'] and d.dim_sizes == [501, 601]
+    assert d.regional is True
+    assert d.x[0] == -3.0e6 and d.x[-1] == 3.0e6 and d.y[0] == -2.5e6
+    assert d.x_corner[0] == -3.005e6 and len(d.y_corner) == 502
+    lat = d.coords['lat']['data']
+    lon = d.coords['lon']['data']
+    assert lat.shape == (501, 601)
+    j, i = 250, 300                      # the pole
+    assert abs(lat[j, i] + 90.0) < 1e-9
+    assert abs(lon[250, 600] - 90.0) < 1e-9      # +x axis is 90 E
+    assert abs(lon[500, 300]) < 1e-9             # +y axis is 0 E
+    assert d.coords['x']['attrs'] == {'units': 'meters'}
+    with pytest.raises(ValueError, match='Bad projection name'):
+        pyremap_amd.get_polar_descriptor(100, 100, 10, 10, projection='x')
+
+
+def test_projection_descriptor_read(tmp_path):
+    ds = xr_lite.Dataset()
+    x = np.linspace(-2.0e5, 2.0e5, 9)
+    y = np.linspace(-1.0e5, 1.0e5, 5)
+    ds['x'] = (('x',), x)
+    ds['y'] = (('y',), y)
+    xe = np.linspace(-2.25e5, 2.25e5, 10)
+    ds['x_bnds'] = (('x', 'nv'), np.stack([xe[:-1], xe[1:]], axis=1))
+    ds['x'].attrs['bounds'] = 'x_bnds'
+    ds.attrs['mesh_name'] = 'tiny_stereo'
+    path = str(tmp_path / 'grid.nc')
+    write_netcdf(ds, path)
+    proj = pyremap_amd.polar.get_antarctic_stereographic_projection()
+    d = ProjectionGridDescriptor.read(proj, path)
+    assert d.mesh_name == 'tiny_stereo'
+    assert d.dims == ['y', 'x'] and d.dim_sizes == [5, 9]
+    np.testing.assert_array_equal(d.x_corner, xe)
+    np.testing.assert_allclose(d.y_corner, np.linspace(-1.25e5, 1.25e5, 6))
+    assert d.coords['lat']['dims'] == ('y', 'x')
+    ds2 = xr_lite.Dataset()
+    ds2['x'] = (('x',), x)
+    ds2['y'] = (('y',), y)
+    with pytest.raises(ValueError, match='No mesh_name provided'):
+        ProjectionGridDescriptor.read(proj, ds=ds2)
+    d3 = pyremap_amd.get_polar_descriptor_from_file(path)
+    assert d3.mesh_name == '400x200km_50km_antarctic_stereo'
+
+
+def test_to_from_polar_round_trip():
+    from pyremap_amd.polar import from_polar, to_polar
+    pts = np.array([[0.0, -75.0], [120.0, -80.0], [-45.0, -66.5]])
+    xy = to_polar(pts.copy())
+    back = from_polar(xy.copy())
+    np.testing.assert_allclose(back, pts, atol=1e-10)
