@@ -1,0 +1,904 @@
+"""
+A small read-only HDF5 reader (numpy + zlib only), enough for NetCDF-4 files:
+mapping files written by ESMF / ``ncremap`` (``build_map.py:166`` passes
+``--netcdf4``) and model output written through netCDF4 / xarray.  The images
+this package runs on have neither netCDF4 nor h5py.
+
+Supported (HDF5 File Format Specification 3.0): superblock v0-v3; object
+headers v1 and v2 with continuation blocks; old-style groups (symbol table:
+v1 B-tree + local heap) and new-style groups (compact link messages or dense
+storage: fractal heap + v2 B-tree); datasets with compact, contiguous or
+chunked (v1 B-tree index; v4 single-chunk / implicit / fixed-array indexes)
+layout; deflate, shuffle and fletcher32 filters; fixed-point, floating-point,
+fixed and variable-length string, enum (as its integer base), object-reference
+and variable-length-sequence datatypes; attributes in the header or in dense
+storage; the global heap.  Anything else raises ``NotImplementedError`` with
+the name of the feature.
+"""
+import mmap
+import struct
+import zlib
+from collections import OrderedDict
+
+import numpy as np
+
+SIGNATURE = b'\x89HDF\r\n\x1a\n'
+
+MSG_DATASPACE = 0x01
+MSG_LINK_INFO = 0x02
+MSG_DATATYPE = 0x03
+MSG_FILL_OLD = 0x04
+MSG_FILL = 0x05
+MSG_LINK = 0x06
+MSG_LAYOUT = 0x08
+MSG_FILTERS = 0x0B
+MSG_ATTRIBUTE = 0x0C
+MSG_CONTINUATION = 0x10
+MSG_SYMBOL_TABLE = 0x11
+MSG_ATTR_INFO = 0x15
+
+
+def _pad8(n):
+    return (n + 7) & ~7
+
+
+def _enc_size(n):
+    """Bytes needed to store the unsigned value n."""
+    return max((int(n).bit_length() + 7) // 8, 1)
+
+
+class Reference:
+    """An object reference (the address of an object header)."""
+
+    __slots__ = ('address',)
+
+    def __init__(self, address):
+        self.address = int(address)
+
+    def __repr__(self):
+        return f'<HDF5 object reference {self.address:#x}>'
+
+    def __eq__(self, other):
+        return isinstance(other, Reference) and other.address == self.address
+
+    def __hash__(self):
+        return hash(self.address)
+
+
+class _Type:
+    """A parsed datatype message."""
+
+    def __init__(self, kind, size, dtype=None, base=None, strpad=0):
+        self.kind = kind      # 'numeric' 'string' 'vlen_str' 'vlen' 'ref'
+        #                       'opaque'
+        self.size = size      # bytes per element in the file
+        self.dtype = dtype    # numpy dtype for numeric / string / opaque
+        self.base = base      # element type of a vlen sequence
+        self.strpad = strpad
+
+
+class File:
+    """``File(path).root`` is the root :class:`Group`."""
+
+    def __init__(self, filename):
+        self.filename = filename
+        self._fh = open(filename, 'rb')
+        try:
+            self.mm = mmap.mmap(self._fh.fileno(), 0, access=mmap.ACCESS_READ)
+        except ValueError:
+            self._fh.close()
+            raise ValueError(f'{filename}: empty file')
+        self._gheaps = {}
+        self._read_superblock()
+        self.root = Group(self, self._root_address, '/')
+
+    def close(self):
+        try:
+            self.mm.close()
+        finally:
+            self._fh.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- primitives ---------------------------------------------------------
+    def uint(self, pos, size):
+        return int.from_bytes(self.mm[pos:pos + size], 'little')
+
+    def addr(self, pos):
+        """An address field: None if undefined, else absolute position."""
+        raw = self.mm[pos:pos + self.O]
+        if raw == b'\xff' * self.O:
+            return None
+        return int.from_bytes(raw, 'little') + self.base
+
+    def _check(self, pos, signature, what):
+        if self.mm[pos:pos + len(signature)] != signature:
+            raise ValueError(f'{self.filename}: bad {what} signature at '
+                             f'{pos:#x}')
+
+    # -- superblock ---------------------------------------------------------
+    def _read_superblock(self):
+        mm = self.mm
+        pos = 0
+        while mm[pos:pos + 8] != SIGNATURE:
+            pos = 512 if pos == 0 else pos * 2
+            if pos + 8 > len(mm):
+                raise ValueError(f'{self.filename}: not an HDF5 file')
+        version = mm[pos + 8]
+        self.base = 0
+        if version in (0, 1):
+            self.O = mm[pos + 13]
+            self.L = mm[pos + 14]
+            p = pos + 24 + (4 if version == 1 else 0)
+            self.base = self.uint(p, self.O)
+            p += 4 * self.O           # base, free space, eof, driver info
+            p += self.O               # root entry: link name offset
+            self._root_address = self.uint(p, self.O) + self.base
+        elif version in (2, 3):
+            self.O = mm[pos + 9]
+            self.L = mm[pos + 10]
+            p = pos + 12
+            self.base = self.uint(p, self.O)
+            self._root_address = self.uint(p + 3 * self.O, self.O) + \
+                self.base
+        else:
+            raise NotImplementedError(f'HDF5 superblock version {version}')
+        self.superblock_version = version
+
+    # -- object headers -----------------------------------------------------
+    def messages(self, address):
+        """[(type, flags, data position, data size)] of an object header."""
+        mm = self.mm
+        out = []
+        if mm[address:address + 4] == b'OHDR':
+            if mm[address + 4] != 2:
+                raise NotImplementedError('object header version '
+                                          f'{mm[address + 4]}')
+            hflags = mm[address + 5]
+            p = address + 6
+            if hflags & 0x20:
+                p += 16
+            if hflags & 0x10:
+                p += 4
+            n = 1 << (hflags & 3)
+            size0 = self.uint(p, n)
+            p += n
+            blocks = [(p, size0)]
+            hdr = 4 + (2 if hflags & 0x04 else 0)
+            while blocks:
+                start, size = blocks.pop(0)
+                p, end = start, start + size
+                while p + hdr <= end:
+                    mtype = mm[p]
+                    msize = self.uint(p + 1, 2)
+                    mflags = mm[p + 3]
+                    data = p + hdr
+                    if mtype == MSG_CONTINUATION:
+                        coff = self.addr(data)
+                        clen = self.uint(data + self.O, self.L)
+                        self._check(coff, b'OCHK', 'continuation block')
+                        blocks.append((coff + 4, clen - 8))
+                    elif mtype != 0:
+                        out.append((mtype, mflags, data, msize))
+                    p = data + msize
+            return out
+        if mm[address] != 1:
+            raise ValueError(f'{self.filename}: no object header at '
+                             f'{address:#x}')
+        nmsgs = self.uint(address + 2, 2)
+        size0 = self.uint(address + 8, 4)
+        blocks = [(address + 16, size0)]
+        seen = 0
+        while blocks and seen < nmsgs:
+            start, size = blocks.pop(0)
+            p, end = start, start + size
+            while p + 8 <= end and seen < nmsgs:
+                mtype = self.uint(p, 2)
+                msize = self.uint(p + 2, 2)
+                mflags = mm[p + 4]
+                data = p + 8
+                seen += 1
+                if mtype == MSG_CONTINUATION:
+                    blocks.append((self.addr(data),
+                                   self.uint(data + self.O, self.L)))
+                elif mtype != 0:
+                    out.append((mtype, mflags, data, msize))
+                p = data + msize
+        return out
+
+    def _shared(self, pos, want):
+        """Follow a shared-message reference to the real message."""
+        version = self.mm[pos]
+        if version == 1:
+            target = self.addr(pos + 8)
+        elif version == 2:
+            target = self.addr(pos + 2)
+        elif version == 3 and self.mm[pos + 1] == 2:
+            target = self.addr(pos + 2)
+        else:
+            raise NotImplementedError('shared message in the SOHM heap')
+        for mtype, mflags, data, _ in self.messages(target):
+            if mtype == want:
+                return data
+        raise ValueError('shared message target holds no such message')
+
+    # -- datatype / dataspace -----------------------------------------------
+    def datatype(self, pos):
+        mm = self.mm
+        cls = mm[pos] & 0x0f
+        bits0 = mm[pos + 1]
+        size = self.uint(pos + 4, 4)
+        props = pos + 8
+        if cls == 0:
+            order = '>' if bits0 & 1 else '<'
+            kind = 'i' if bits0 & 8 else 'u'
+            return _Type('numeric', size, np.dtype(f'{order}{kind}{size}'))
+        if cls == 1:
+            order = '>' if bits0 & 1 else '<'
+            return _Type('numeric', size, np.dtype(f'{order}f{size}'))
+        if cls == 3:
+            return _Type('string', size, np.dtype(f'S{size}'),
+                         strpad=bits0 & 0x0f)
+        if cls == 7:
+            if (bits0 & 0x0f) != 0:
+                return _Type('opaque', size, np.dtype(f'V{size}'))
+            return _Type('ref', size)
+        if cls == 8:
+            base = self.datatype(props)
+            return _Type(base.kind, size, base.dtype)
+        if cls == 9:
+            base = self.datatype(props)
+            if (bits0 & 0x0f) == 1:
+                return _Type('vlen_str', size)
+            return _Type('vlen', size, base=base)
+        # time, bitfield, opaque, compound, array: carried as raw bytes
+        return _Type('opaque', size, np.dtype(f'V{size}'))
+
+    def dataspace(self, pos):
+        """(shape or None for a null dataspace, maxshape or None)."""
+        mm = self.mm
+        version = mm[pos]
+        rank = mm[pos + 1]
+        flags = mm[pos + 2]
+        if version == 1:
+            p = pos + 8
+        elif version == 2:
+            if mm[pos + 3] == 2:
+                return None, None
+            p = pos + 4
+        else:
+            raise NotImplementedError(f'dataspace version {version}')
+        L = self.L
+        shape = tuple(self.uint(p + i * L, L) for i in range(rank))
+        maxshape = None
+        if flags & 1:
+            p += rank * L
+            maxshape = tuple(self.uint(p + i * L, L) for i in range(rank))
+        return shape, maxshape
+
+    # -- heaps --------------------------------------------------------------
+    def global_heap_object(self, address, index):
+        heap = self._gheaps.get(address)
+        if heap is None:
+            self._check(address, b'GCOL', 'global heap')
+            size = self.uint(address + 8, self.L)
+            heap = {}
+            p = address + 8 + self.L
+            end = address + size
+            while p + 8 + self.L <= end:
+                idx = self.uint(p, 2)
+                osize = self.uint(p + 8, self.L)
+                if idx == 0:
+                    break
+                heap[idx] = (p + 8 + self.L, osize)
+                p += 8 + self.L + _pad8(osize)
+            self._gheaps[address] = heap
+        start, osize = heap[index]
+        return self.mm[start:start + osize]
+
+    # -- values -------------------------------------------------------------
+    def decode(self, typ, raw, count):
+        """`count` elements of type `typ` from the bytes `raw`."""
+        if typ.kind in ('numeric', 'opaque'):
+            return np.frombuffer(raw, dtype=typ.dtype, count=count).copy()
+        if typ.kind == 'string':
+            arr = np.frombuffer(raw, dtype=typ.dtype, count=count).copy()
+            if typ.strpad == 2:
+                arr = np.char.rstrip(arr, b' ')
+            return arr
+        if typ.kind == 'ref':
+            a = np.frombuffer(raw, dtype='<u8', count=count)
+            return [Reference(v + self.base) for v in a.tolist()]
+        step = 4 + self.O + 4
+        out = []
+        for i in range(count):
+            item = raw[i * step:(i + 1) * step]
+            n = int.from_bytes(item[:4], 'little')
+            haddr = int.from_bytes(item[4:4 + self.O], 'little')
+            index = int.from_bytes(item[4 + self.O:], 'little')
+            if n == 0 or haddr == 0:
+                blob = b''
+            else:
+                blob = self.global_heap_object(haddr + self.base, index)
+            if typ.kind == 'vlen_str':
+                out.append(blob[:n].decode('utf-8', 'replace'))
+            else:
+                out.append(self.decode(typ.base, blob, n))
+        return out
+
+
+class _FractalHeap:
+    def __init__(self, f, address):
+        self.f = f
+        f._check(address, b'FRHP', 'fractal heap')
+        O, L = f.O, f.L
+        p = address + 5
+        self.id_len = f.uint(p, 2)
+        self.filter_len = f.uint(p + 2, 2)
+        self.flags = f.mm[p + 4]
+        self.max_managed = f.uint(p + 5, 4)
+        p += 9
+        p += L + O + L + O + 8 * L
+        self.width = f.uint(p, 2)
+        self.start_size = f.uint(p + 2, L)
+        self.max_direct = f.uint(p + 2 + L, L)
+        p += 2 + 2 * L
+        self.max_heap_bits = f.uint(p, 2)
+        root = f.addr(p + 4)
+        cur_rows = f.uint(p + 4 + O, 2)
+        if self.filter_len:
+            raise NotImplementedError('filtered fractal heap')
+        self.off_size = (self.max_heap_bits + 7) // 8
+        self.len_size = _enc_size(min(self.max_direct, self.max_managed))
+        self.max_direct_rows = (self.max_direct.bit_length() -
+                                self.start_size.bit_length()) + 2
+        self.blocks = []          # (heap offset, file address, size)
+        if root is not None:
+            if cur_rows == 0:
+                self._direct(root, self.start_size)
+            else:
+                self._indirect(root, cur_rows)
+        self.blocks.sort()
+
+    def _row_size(self, row):
+        return self.start_size << max(row - 1, 0)
+
+    def _direct(self, address, size):
+        f = self.f
+        f._check(address, b'FHDB', 'fractal heap direct block')
+        offset = f.uint(address + 5 + f.O, self.off_size)
+        self.blocks.append((offset, address, size))
+
+    def _indirect(self, address, nrows):
+        f = self.f
+        f._check(address, b'FHIB', 'fractal heap indirect block')
+        p = address + 5 + f.O + self.off_size
+        for row in range(nrows):
+            size = self._row_size(row)
+            for _ in range(self.width):
+                child = f.addr(p)
+                p += f.O
+                if child is None:
+                    continue
+                if row < self.max_direct_rows:
+                    self._direct(child, size)
+                else:
+                    rows = size.bit_length() - \
+                        (self.start_size * self.width).bit_length() + 1
+                    self._indirect(child, rows)
+
+    def get(self, heap_id):
+        kind = (heap_id[0] >> 4) & 3
+        if kind == 0:
+            off = int.from_bytes(heap_id[1:1 + self.off_size], 'little')
+            n = int.from_bytes(
+                heap_id[1 + self.off_size:1 + self.off_size + self.len_size],
+                'little')
+            for boff, baddr, bsize in self.blocks:
+                if boff <= off < boff + bsize:
+                    start = baddr + (off - boff)
+                    return start, n
+            raise ValueError('fractal heap object outside every block')
+        if kind == 2:
+            raise NotImplementedError('tiny fractal-heap objects')
+        raise NotImplementedError('huge fractal-heap objects')
+
+
+def _btree2_records(f, address):
+    """All records (bytes) of a version-2 B-tree, in tree order."""
+    f._check(address, b'BTHD', 'v2 B-tree header')
+    node_size = f.uint(address + 6, 4)
+    rec_size = f.uint(address + 10, 2)
+    depth = f.uint(address + 12, 2)
+    root = f.addr(address + 16)
+    root_nrec = f.uint(address + 16 + f.O, 2)
+    if root is None or root_nrec == 0:
+        return []
+    max_leaf = (node_size - 10) // rec_size
+    nrec_size = _enc_size(max_leaf)
+    cum = [max_leaf]
+    cum_size = [0]
+    for level in range(1, depth + 1):
+        ptr = f.O + nrec_size + cum_size[level - 1]
+        max_here = (node_size - 10 - ptr) // (rec_size + ptr)
+        cum.append((max_here + 1) * cum[level - 1] + max_here)
+        cum_size.append(_enc_size(cum[level]))
+    out = []
+
+    def walk(addr, nrec, level):
+        if level == 0:
+            f._check(addr, b'BTLF', 'v2 B-tree leaf')
+            p = addr + 6
+            for i in range(nrec):
+                out.append(bytes(f.mm[p + i * rec_size:
+                                      p + (i + 1) * rec_size]))
+            return
+        f._check(addr, b'BTIN', 'v2 B-tree internal node')
+        p = addr + 6
+        recs = [bytes(f.mm[p + i * rec_size:p + (i + 1) * rec_size])
+                for i in range(nrec)]
+        p += nrec * rec_size
+        for i in range(nrec + 1):
+            child = f.addr(p)
+            cn = f.uint(p + f.O, nrec_size)
+            p += f.O + nrec_size + cum_size[level - 1]
+            walk(child, cn, level - 1)
+            if i < nrec:
+                out.append(recs[i])
+
+    walk(root, root_nrec, depth)
+    return out
+
+
+class _Object:
+    def __init__(self, f, address, name):
+        self.file = f
+        self.address = address
+        self.name = name
+        self._msgs = f.messages(address)
+        self._attrs = None
+
+    def _find(self, mtype):
+        for t, flags, data, size in self._msgs:
+            if t == mtype:
+                if flags & 0x02:
+                    return self.file._shared(data, mtype), size
+                return data, size
+        return None, None
+
+    # -- attributes ---------------------------------------------------------
+    def _parse_attribute(self, pos):
+        f = self.file
+        mm = f.mm
+        version = mm[pos]
+        name_size = f.uint(pos + 2, 2)
+        dt_size = f.uint(pos + 4, 2)
+        ds_size = f.uint(pos + 6, 2)
+        if version == 1:
+            p = pos + 8
+            name = mm[p:p + name_size]
+            p += _pad8(name_size)
+            dt_pos = p
+            p += _pad8(dt_size)
+            ds_pos = p
+            p += _pad8(ds_size)
+        elif version in (2, 3):
+            flags = mm[pos + 1]
+            p = pos + (9 if version == 3 else 8)
+            name = mm[p:p + name_size]
+            p += name_size
+            dt_pos = p
+            p += dt_size
+            ds_pos = p
+            p += ds_size
+            if flags & 1:
+                dt_pos = f._shared(dt_pos, MSG_DATATYPE)
+            if flags & 2:
+                ds_pos = f._shared(ds_pos, MSG_DATASPACE)
+        else:
+            raise NotImplementedError(f'attribute message version {version}')
+        name = bytes(name).split(b'\x00')[0].decode('utf-8', 'replace')
+        typ = f.datatype(dt_pos)
+        shape, _ = f.dataspace(ds_pos)
+        if shape is None:
+            return name, None
+        count = int(np.prod(shape, dtype=np.int64)) if shape else 1
+        raw = mm[p:p + count * typ.size]
+        value = f.decode(typ, raw, count)
+        if isinstance(value, np.ndarray):
+            value = value.reshape(shape) if shape else value.reshape(())[()]
+        elif not shape:
+            value = value[0]
+        return name, value
+
+    @property
+    def attrs(self):
+        if self._attrs is None:
+            f = self.file
+            attrs = OrderedDict()
+            for t, flags, data, size in self._msgs:
+                if t == MSG_ATTRIBUTE:
+                    name, value = self._parse_attribute(data)
+                    attrs[name] = value
+            info, _ = self._find(MSG_ATTR_INFO)
+            if info is not None:
+                flags = f.mm[info + 1]
+                p = info + 2 + (2 if flags & 1 else 0)
+                heap_addr = f.addr(p)
+                tree_addr = f.addr(p + f.O)
+                if heap_addr is not None and tree_addr is not None:
+                    heap = _FractalHeap(f, heap_addr)
+                    dense = []
+                    for rec in _btree2_records(f, tree_addr):
+                        start, _n = heap.get(rec[:heap.id_len])
+                        order = int.from_bytes(rec[9:13], 'little')
+                        dense.append((order,
+                                      self._parse_attribute(start)))
+                    for _o, (name, value) in sorted(dense,
+                                                    key=lambda kv: kv[0]):
+                        attrs[name] = value
+            self._attrs = attrs
+        return self._attrs
+
+
+class Group(_Object):
+    def __init__(self, f, address, name):
+        super().__init__(f, address, name)
+        self._links = None
+
+    def _parse_link(self, pos):
+        f = self.file
+        mm = f.mm
+        flags = mm[pos + 1]
+        p = pos + 2
+        ltype = 0
+        if flags & 0x08:
+            ltype = mm[p]
+            p += 1
+        order = None
+        if flags & 0x04:
+            order = f.uint(p, 8)
+            p += 8
+        if flags & 0x10:
+            p += 1
+        n = 1 << (flags & 3)
+        name_len = f.uint(p, n)
+        p += n
+        name = bytes(mm[p:p + name_len]).decode('utf-8', 'replace')
+        p += name_len
+        target = f.addr(p) if ltype == 0 else None
+        return name, target, order
+
+    def _load(self):
+        f = self.file
+        links = []
+        for t, flags, data, size in self._msgs:
+            if t == MSG_LINK:
+                links.append(self._parse_link(data))
+        info, _ = self._find(MSG_LINK_INFO)
+        if info is not None:
+            flags = f.mm[info + 1]
+            p = info + 2 + (8 if flags & 1 else 0)
+            heap_addr = f.addr(p)
+            tree_addr = f.addr(p + f.O)
+            if heap_addr is not None and tree_addr is not None:
+                heap = _FractalHeap(f, heap_addr)
+                for rec in _btree2_records(f, tree_addr):
+                    start, _n = heap.get(rec[4:4 + heap.id_len])
+                    links.append(self._parse_link(start))
+        table, _ = self._find(MSG_SYMBOL_TABLE)
+        if table is not None:
+            tree = f.addr(table)
+            heap = f.addr(table + f.O)
+            f._check(heap, b'HEAP', 'local heap')
+            seg = f.addr(heap + 8 + 2 * f.L)
+            self._walk_symbols(tree, seg, links)
+        if any(order is not None for _, _, order in links):
+            links.sort(key=lambda l: (l[2] is None, l[2]))
+        self._links = OrderedDict((name, target)
+                                  for name, target, _ in links)
+
+    def _walk_symbols(self, node, seg, links):
+        f = self.file
+        mm = f.mm
+        f._check(node, b'TREE', 'v1 B-tree node')
+        level = mm[node + 5]
+        n = f.uint(node + 6, 2)
+        p = node + 8 + 2 * f.O + f.L          # first child pointer
+        for _ in range(n):
+            child = f.addr(p)
+            p += f.O + f.L
+            if level > 0:
+                self._walk_symbols(child, seg, links)
+                continue
+            f._check(child, b'SNOD', 'symbol table node')
+            count = f.uint(child + 6, 2)
+            q = child + 8
+            for _e in range(count):
+                name_off = f.uint(q, f.O)
+                target = f.addr(q + f.O)
+                end = mm.find(b'\x00', seg + name_off)
+                name = bytes(mm[seg + name_off:end]).decode('utf-8',
+                                                            'replace')
+                links.append((name, target, None))
+                q += 2 * f.O + 24
+
+    def keys(self):
+        if self._links is None:
+            self._load()
+        return list(self._links)
+
+    def __contains__(self, name):
+        return name in self.keys()
+
+    def __iter__(self):
+        return iter(self.keys())
+
+    def __getitem__(self, name):
+        if self._links is None:
+            self._load()
+        target = self._links[name]
+        if target is None:
+            raise NotImplementedError(f'{name}: soft / external link')
+        return self.file_object(target, name)
+
+    def file_object(self, address, name):
+        msgs = self.file.messages(address)
+        if any(t == MSG_LAYOUT for t, _, _, _ in msgs):
+            return Dataset(self.file, address, name)
+        return Group(self.file, address, name)
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+
+class Dataset(_Object):
+    def __init__(self, f, address, name):
+        super().__init__(f, address, name)
+        pos, _ = self._find(MSG_DATATYPE)
+        self.type = f.datatype(pos)
+        pos, _ = self._find(MSG_DATASPACE)
+        self.shape, self.maxshape = f.dataspace(pos)
+        self.dtype = self.type.dtype if self.type.dtype is not None \
+            else np.dtype(object)
+
+    # -- layout -------------------------------------------------------------
+    def _filters(self):
+        f = self.file
+        pos, _ = self._find(MSG_FILTERS)
+        if pos is None:
+            return []
+        mm = f.mm
+        version = mm[pos]
+        n = mm[pos + 1]
+        p = pos + (8 if version == 1 else 2)
+        out = []
+        for _ in range(n):
+            fid = f.uint(p, 2)
+            p += 2
+            name_len = 0
+            if version == 1 or fid >= 256:
+                name_len = f.uint(p, 2)
+                p += 2
+            p += 2                           # flags
+            ncd = f.uint(p, 2)
+            p += 2
+            p += _pad8(name_len) if version == 1 else name_len
+            cd = [f.uint(p + 4 * i, 4) for i in range(ncd)]
+            p += 4 * ncd
+            if version == 1 and ncd % 2:
+                p += 4
+            out.append((fid, cd))
+        return out
+
+    def _fill_value(self):
+        f = self.file
+        pos, _ = self._find(MSG_FILL)
+        if pos is None or self.type.dtype is None:
+            return None
+        mm = f.mm
+        version = mm[pos]
+        if version in (1, 2):
+            defined = mm[pos + 3]
+            if version == 2 and not defined:
+                return None
+            size = f.uint(pos + 4, 4)
+            data = pos + 8
+        elif version == 3:
+            if not mm[pos + 1] & 0x20:
+                return None
+            size = f.uint(pos + 2, 4)
+            data = pos + 6
+        else:
+            return None
+        if size != self.type.size:
+            return None
+        return np.frombuffer(mm[data:data + size], dtype=self.type.dtype)[0]
+
+    def _unfilter(self, blob, filters, mask):
+        for i in range(len(filters) - 1, -1, -1):
+            if mask & (1 << i):
+                continue
+            fid, cd = filters[i]
+            if fid == 1:
+                blob = zlib.decompress(blob)
+            elif fid == 2:
+                width = cd[0] if cd else self.type.size
+                a = np.frombuffer(blob, dtype=np.uint8)
+                n = a.size // width
+                body = a[:n * width].reshape(width, n).T.reshape(-1)
+                blob = body.tobytes() + a[n * width:].tobytes()
+            elif fid == 3:
+                blob = blob[:-4]
+            else:
+                raise NotImplementedError(f'HDF5 filter {fid} on '
+                                          f'{self.name}')
+        return blob
+
+    def _chunks_btree1(self, node, rank, out):
+        f = self.file
+        f._check(node, b'TREE', 'v1 B-tree node')
+        level = f.mm[node + 5]
+        n = f.uint(node + 6, 2)
+        key = 8 + 8 * (rank + 1)
+        p = node + 8 + 2 * f.O
+        for _ in range(n):
+            size = f.uint(p, 4)
+            mask = f.uint(p + 4, 4)
+            offs = struct.unpack_from(f'<{rank}Q', f.mm, p + 8)
+            child = f.addr(p + key)
+            p += key + f.O
+            if level > 0:
+                self._chunks_btree1(child, rank, out)
+            else:
+                out.append((offs, child, size, mask))
+
+    def read(self):
+        """The whole dataset as a numpy array (or a list for vlen types)."""
+        f = self.file
+        mm = f.mm
+        typ = self.type
+        if self.shape is None:
+            return None
+        shape = self.shape
+        count = int(np.prod(shape, dtype=np.int64)) if shape else 1
+        pos, _ = self._find(MSG_LAYOUT)
+        version = mm[pos]
+        if version < 3:
+            raise NotImplementedError(f'data layout version {version}')
+        cls = mm[pos + 1]
+        if cls == 0:
+            size = f.uint(pos + 2, 2)
+            return self._finish(mm[pos + 4:pos + 4 + size], count)
+        if cls == 1:
+            address = f.addr(pos + 2)
+            if address is None:
+                filled = self._filled(count)
+                return filled.reshape(shape) if typ.dtype is not None \
+                    else filled
+            return self._finish(mm[address:address + count * typ.size],
+                                count)
+        if cls != 2:
+            raise NotImplementedError(f'data layout class {cls}')
+        if typ.dtype is None:
+            raise NotImplementedError('chunked variable-length data')
+        filters = self._filters()
+        chunks = []
+        if version == 3:
+            ndim = mm[pos + 2]
+            rank = ndim - 1
+            tree = f.addr(pos + 3)
+            cdims = tuple(f.uint(pos + 3 + f.O + 4 * i, 4)
+                          for i in range(rank))
+            if tree is not None:
+                self._chunks_btree1(tree, rank, chunks)
+        else:
+            flags = mm[pos + 2]
+            ndim = mm[pos + 3]
+            rank = ndim - 1
+            enc = mm[pos + 4]
+            cdims = tuple(f.uint(pos + 5 + enc * i, enc)
+                          for i in range(rank))
+            p = pos + 5 + enc * ndim
+            index = mm[p]
+            p += 1
+            nbytes = int(np.prod(cdims, dtype=np.int64)) * typ.size
+            if index == 1:                       # single chunk
+                size, mask = nbytes, 0
+                if flags & 2:
+                    size = f.uint(p, f.L)
+                    mask = f.uint(p + f.L, 4)
+                    p += f.L + 4
+                address = f.addr(p)
+                if address is not None:
+                    chunks.append(((0,) * rank, address, size, mask))
+            elif index in (2, 3):                # implicit / fixed array
+                if index == 3:
+                    p += 1
+                address = f.addr(p)
+                grid = [-(-s // c) for s, c in zip(shape, cdims)]
+                total = int(np.prod(grid, dtype=np.int64))
+                entries = []
+                if address is not None and index == 2:
+                    entries = [(address + i * nbytes, nbytes, 0)
+                               for i in range(total)]
+                elif address is not None:
+                    entries = self._fixed_array(address, total, nbytes,
+                                                bool(filters))
+                for i, (caddr, size, mask) in enumerate(entries):
+                    if caddr is None:
+                        continue
+                    idx = np.unravel_index(i, grid)
+                    offs = tuple(int(a) * c for a, c in zip(idx, cdims))
+                    chunks.append((offs, caddr, size, mask))
+            else:
+                raise NotImplementedError(
+                    f'chunk index type {index} (extensible array / v2 '
+                    f'B-tree) on {self.name}')
+        out = self._filled(count).reshape(shape)
+        for offs, address, size, mask in chunks:
+            blob = mm[address:address + size]
+            if filters:
+                blob = self._unfilter(blob, filters, mask)
+            block = np.frombuffer(blob, dtype=typ.dtype,
+                                  count=int(np.prod(cdims, dtype=np.int64)))
+            block = block.reshape(cdims)
+            sel_out = tuple(slice(o, min(o + c, s))
+                            for o, c, s in zip(offs, cdims, shape))
+            sel_in = tuple(slice(0, s.stop - s.start) for s in sel_out)
+            out[sel_out] = block[sel_in]
+        return self._strip(out)
+
+    def _fixed_array(self, address, total, nbytes, filtered):
+        f = self.file
+        f._check(address, b'FAHD', 'fixed array header')
+        entry_size = f.mm[address + 6]
+        page_bits = f.mm[address + 7]
+        nent = f.uint(address + 8, f.L)
+        data = f.addr(address + 8 + f.L)
+        if data is None:
+            return []
+        f._check(data, b'FADB', 'fixed array data block')
+        p = data + 6 + f.O
+        page = 1 << page_bits
+        if nent > page:
+            raise NotImplementedError('paged fixed-array chunk index')
+        out = []
+        for i in range(min(nent, total)):
+            q = p + i * entry_size
+            caddr = f.addr(q)
+            if filtered:
+                n = entry_size - f.O - 4
+                size = f.uint(q + f.O, n)
+                mask = f.uint(q + f.O + n, 4)
+            else:
+                size, mask = nbytes, 0
+            out.append((caddr, size, mask))
+        return out
+
+    def _filled(self, count):
+        typ = self.type
+        if typ.dtype is None:
+            return [None] * count
+        fill = self._fill_value()
+        out = np.zeros(count, dtype=typ.dtype)
+        if fill is not None:
+            out[...] = fill
+        return out
+
+    def _strip(self, arr):
+        if self.type.kind == 'string' and self.type.strpad == 2:
+            return np.char.rstrip(arr, b' ')
+        return arr
+
+    def _finish(self, raw, count):
+        value = self.file.decode(self.type, raw, count)
+        if isinstance(value, np.ndarray):
+            return value.reshape(self.shape)
+        if not self.shape:
+            return value[0]
+        return value

@@ -102,32 +102,18 @@ def _read_netcdf3(filename):
 
 
 def _read_hdf5(filename):
-    try:
-        import h5py
-    except ImportError:
-        h5py = None
-    if h5py is not None:
-        with h5py.File(filename, 'r') as h5:
-            missing = [k for k in REQUIRED if k not in h5]
-            if missing:
-                raise ValueError(f'{filename}: missing variables {missing}')
-            get = {k: np.array(h5[k][...]) for k in REQUIRED}
-            n_b = get['frac_b'].shape[0]
-            n_a = h5['n_a'].shape[0] if 'n_a' in h5 else \
-                int(np.prod(get['src_grid_dims']))
-        return MappingFile(n_a, n_b, get['src_grid_dims'],
-                           get['dst_grid_dims'], get['row'], get['col'],
-                           get['S'], get['frac_b'])
-    try:
-        import netCDF4
-    except ImportError as exc:
-        raise ImportError(
-            f'{filename} is NetCDF-4/HDF5; reading it needs h5py or '
-            f'netCDF4, neither of which is installed') from exc
-    with netCDF4.Dataset(filename) as nc:
-        get = {k: np.array(nc.variables[k][:]) for k in REQUIRED}
-        n_a = len(nc.dimensions['n_a'])
-        n_b = len(nc.dimensions['n_b'])
+    """NetCDF-4 mapping files (ESMF with ``--netcdf4``, ``build_map.py:166``)
+    through this package's own HDF5 reader."""
+    from pyremap_amd.io.netcdf4_lite import NetCDF4File
+    with NetCDF4File(filename) as nc:
+        missing = [k for k in REQUIRED if k not in nc.variables]
+        if missing:
+            raise ValueError(f'{filename}: missing variables {missing}')
+        get = {k: _native(nc.variables[k].read()) for k in REQUIRED}
+        n_b = nc.dimensions.get('n_b', get['frac_b'].shape[0])
+        n_a = nc.dimensions.get('n_a')
+        if n_a is None:
+            n_a = int(np.prod(get['src_grid_dims']))
     return MappingFile(n_a, n_b, get['src_grid_dims'], get['dst_grid_dims'],
                        get['row'], get['col'], get['S'], get['frac_b'])
 

@@ -8,8 +8,9 @@ decoding: ``_FillValue`` / ``missing_value`` become NaN, ``scale_factor`` /
 written only for numeric variables that actually hold NaNs, with netCDF4's
 default fill value for the dtype (:38-51).
 
-Classic formats (CDF-1/2/5) are handled by :mod:`pyremap_amd.io.netcdf3`;
-NetCDF-4/HDF5 input is read when ``h5py`` is importable.
+Classic formats (CDF-1/2/5) are handled by :mod:`pyremap_amd.io.netcdf3`,
+NetCDF-4/HDF5 input by :mod:`pyremap_amd.io.netcdf4_lite` (this package's own
+read-only HDF5 reader); classic formats are written.
 """
 import os
 from collections import OrderedDict
@@ -105,56 +106,25 @@ def open_dataset(filename, mask_and_scale=True):
 
 
 def _open_hdf5(filename, mask_and_scale):
-    try:
-        import h5py
-    except ImportError as exc:
-        raise ImportError(
-            f'{filename} is NetCDF-4/HDF5: reading it needs h5py, which is '
-            f'not installed; convert it to a classic format (nccopy -k '
-            f'cdf5) or install h5py') from exc
-    ds = xr_lite.Dataset()
-    ds.encoding = {'format': 'NETCDF4', 'unlimited_dims': [],
-                   'dim_order': []}
-    with h5py.File(filename, 'r') as h5:
-        for key, value in h5.attrs.items():
-            if not key.startswith('_'):
-                ds.attrs[key] = value.decode() if isinstance(value, bytes) \
-                    else value
-        scales = {}
-        for name, obj in h5.items():
-            if isinstance(obj, h5py.Dataset) and obj.attrs.get(
-                    'CLASS', b'') == b'DIMENSION_SCALE':
-                scales[obj.id.__hash__()] = name
-        for name, obj in h5.items():
-            if not isinstance(obj, h5py.Dataset):
-                continue
-            is_scale = obj.attrs.get('CLASS', b'') == b'DIMENSION_SCALE'
-            pure_dim = is_scale and b'This is a netCDF dimension' in \
-                obj.attrs.get('NAME', b'')
-            if pure_dim:
-                continue
-            dims = []
-            for axis, dim in enumerate(obj.dims):
-                dims.append(os.path.basename(dim[0].name) if len(dim)
-                            else f'{name}_dim{axis}')
-            if is_scale and not dims:
-                dims = [name]
-            attrs = OrderedDict()
-            for key, value in obj.attrs.items():
-                if key in ('DIMENSION_LIST', 'REFERENCE_LIST', 'CLASS',
-                           'NAME', '_Netcdf4Dimid', '_Netcdf4Coordinates'):
-                    continue
-                if isinstance(value, bytes):
-                    value = value.decode()
-                elif isinstance(value, np.ndarray) and value.size == 1:
-                    value = value.reshape(-1)[0]
-                attrs[key] = value
-            data = np.array(obj[...])
-            enc = {}
+    """NetCDF-4 through this package's own HDF5 reader (no h5py/netCDF4)."""
+    from pyremap_amd.io.netcdf4_lite import NetCDF4File
+    with NetCDF4File(filename) as nc:
+        ds = xr_lite.Dataset(attrs=nc.attrs)
+        ds.encoding = {'format': 'NETCDF4',
+                       'unlimited_dims': list(nc.unlimited),
+                       'dim_order': list(nc.dimensions)}
+        for name, var in nc.variables.items():
+            data = var.read()
+            if isinstance(data, list):
+                # variable-length strings: an object array of str
+                data = np.array(data, dtype=object).reshape(var.shape)
+            attrs, enc = OrderedDict(var.attrs), {}
             if mask_and_scale:
                 data, attrs, enc = _decode(data, attrs)
-            da = xr_lite.DataArray(data, dims=dims, name=name, attrs=attrs)
-            if tuple(dims) == (name,):
+            da = xr_lite.DataArray(data, dims=var.dims, name=name,
+                                   attrs=attrs)
+            da.encoding = enc
+            if var.dims == (name,):
                 ds._set_coord(name, da)
             else:
                 ds[name] = da

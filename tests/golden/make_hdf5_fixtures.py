@@ -1,0 +1,208 @@
+#!/opt/conda/bin/python3.9
+"""
+Small HDF5 files that exercise the features pyremap_amd/io/hdf5_lite.py
+implements, written with h5py (the image's conda interpreter has it; the
+interpreter the package runs on does not), plus ``expected.npz``: every
+dataset and numeric/string attribute as h5py reads it back.
+
+    /opt/conda/bin/python3.9 tests/golden/make_hdf5_fixtures.py
+
+The two ``nc4_*.nc`` files beside them are data files of the reference's own
+test suite (tests/test_interpolate/), real NetCDF-4 written by netCDF4-python
+and NCO; their expected contents are stored the same way.
+"""
+import os
+import shutil
+
+import h5py
+import numpy as np
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'hdf5')
+REF = '/root/reference/tests/test_interpolate'
+rng = np.random.default_rng(7)
+expected = {}
+
+
+def record(tag, path):
+    def visit(group, prefix):
+        for k, v in group.attrs.items():
+            note(f'{tag}:{prefix}@{k}', v)
+        for name, obj in group.items():
+            if isinstance(obj, h5py.Group):
+                visit(obj, f'{prefix}{name}/')
+                continue
+            for k, v in obj.attrs.items():
+                note(f'{tag}:{prefix}{name}@{k}', v)
+            if obj.shape is not None:
+                note(f'{tag}:{prefix}{name}', obj[()])
+
+    def note(key, value):
+        if isinstance(value, (bytes, str)):
+            value = np.array(value if isinstance(value, str)
+                             else value.decode())
+        value = np.asarray(value)
+        if value.dtype.kind == 'O':
+            if value.size and isinstance(value.reshape(-1)[0], (bytes, str)):
+                value = np.array([v.decode() if isinstance(v, bytes) else v
+                                  for v in value.reshape(-1)]).reshape(
+                                      value.shape)
+            else:
+                return           # references: checked structurally
+        if value.dtype.kind == 'V':
+            return
+        expected[key] = value
+
+    with h5py.File(path, 'r') as h5:
+        visit(h5, '/')
+
+
+def classic():
+    """Default (earliest) format: v0 superblock, v1 headers, symbol tables."""
+    path = os.path.join(OUT, 'classic.h5')
+    with h5py.File(path, 'w') as f:
+        f.attrs['title'] = 'classic layout'
+        f.attrs['numbers'] = np.arange(5, dtype='i2')
+        f.attrs['pi'] = np.float32(3.14159)
+        f.create_dataset('contig_f8', data=rng.standard_normal((7, 5)))
+        f.create_dataset('contig_be_i4',
+                         data=np.arange(12, dtype='>i4').reshape(3, 4))
+        f.create_dataset('u8', data=np.arange(6, dtype='u8') * 2 ** 60)
+        f.create_dataset('scalar', data=np.float64(2.5))
+        d = f.create_dataset('chunked_gzip_shuffle',
+                             data=rng.integers(0, 50, (37, 23)).astype('i4'),
+                             chunks=(8, 10), compression='gzip',
+                             shuffle=True, fletcher32=True)
+        d.attrs['units'] = 'counts'
+        d.attrs['_FillValue'] = np.int32(-1)
+        f.create_dataset('chunked_plain', data=rng.random((20, 3)),
+                         chunks=(6, 2))
+        e = f.create_dataset('partly_written', shape=(10, 10), dtype='f4',
+                             chunks=(5, 5), fillvalue=np.float32(-7.5))
+        e[0:5, 5:10] = 1.25
+        f.create_dataset('fixed_strings',
+                         data=np.array([b'alpha', b'be', b'gamma__'],
+                                       dtype='S8'))
+        f.create_dataset('vlen_strings', data=['one', 'three', ''],
+                         dtype=h5py.string_dtype())
+        f.attrs['vlen_attr'] = 'a variable-length string'
+        g = f.create_group('sub')
+        g.attrs['level'] = np.int64(1)
+        g.create_dataset('x', data=np.linspace(0, 1, 11))
+        g.create_group('deeper').create_dataset('y', data=np.arange(3))
+        big = f.create_group('many')            # multi-level group B-tree
+        for i in range(300):
+            big.create_dataset(f'v{i:03d}', data=np.int16(i))
+        f.create_dataset('empty', shape=(0, 4), dtype='f8')
+    record('classic', path)
+
+
+def latest():
+    """libver='latest': v3 superblock, v2 headers, dense links/attributes,
+    version-4 chunk indexes."""
+    path = os.path.join(OUT, 'latest.h5')
+    with h5py.File(path, 'w', libver='latest') as f:
+        for i in range(40):                      # dense link storage
+            f.create_dataset(f'var{i:02d}', data=rng.random(3))
+        d = f.create_dataset('many_attrs', data=np.arange(4.0))
+        for i in range(30):                      # dense attribute storage
+            d.attrs[f'attr{i:02d}'] = np.float64(i) / 3
+        d.attrs['text'] = 'dense text attribute'
+        f.create_dataset('single_chunk', data=rng.random((6, 6)),
+                         chunks=(6, 6), compression='gzip')
+        f.create_dataset('implicit', data=rng.random((9, 4)), chunks=(3, 2))
+        f.create_dataset('fixed_array_filtered',
+                         data=rng.integers(0, 9, (25, 7)).astype('i8'),
+                         chunks=(4, 3), compression='gzip', shuffle=True)
+        f.create_dataset('fixed_array_plain',
+                         data=rng.random((10, 10)).astype('f4'),
+                         chunks=(4, 4), fillvalue=np.float32(9.0))
+        f.create_dataset('compact', data=np.arange(8, dtype='i1'))
+        wide = f.create_group('wide')            # deeper v2 B-tree
+        for i in range(400):
+            wide.create_dataset(f'dataset_with_a_long_name_{i:04d}',
+                                data=np.int32(i))
+    record('latest', path)
+
+
+def scales():
+    """Dimension scales the way netCDF-4 attaches them, plus a user block."""
+    path = os.path.join(OUT, 'scales.h5')
+    with h5py.File(path, 'w', userblock_size=512) as f:
+        f.create_dataset('n_s', data=np.zeros(6, dtype='f4'))
+        f['n_s'].make_scale('This is a netCDF dimension but not a netCDF '
+                            'variable.         6')
+        f.create_dataset('lat', data=np.linspace(-60, 60, 5))
+        f['lat'].make_scale('lat')
+        f.create_dataset('lon', data=np.linspace(0, 300, 6))
+        f['lon'].make_scale('lon')
+        t = f.create_dataset('temp', data=rng.random((5, 6)).astype('f4'))
+        t.dims[0].attach_scale(f['lat'])
+        t.dims[1].attach_scale(f['lon'])
+        s = f.create_dataset('S', data=rng.random(6))
+        s.dims[0].attach_scale(f['n_s'])
+        f.create_dataset('loose', data=np.arange(6, dtype='i4'))
+    record('scales', path)
+
+
+def mapping():
+    """A mapping file laid out as ESMF_RegridWeightGen --netcdf4 writes it
+    (SURVEY.md Appendix A): dimensions without coordinate variables, 1-based
+    unsorted triplets with a duplicate, Fortran-ordered grid dims."""
+    path = os.path.join(OUT, 'map_nc4.nc')
+    n_a, n_b, n_s = 12, 8, 20
+    with h5py.File(path, 'w') as f:
+        dims = {}
+        for i, (name, size) in enumerate((('n_a', n_a), ('n_b', n_b),
+                                          ('n_s', n_s),
+                                          ('src_grid_rank', 2),
+                                          ('dst_grid_rank', 2))):
+            d = f.create_dataset(name, data=np.zeros(size, dtype='>f4'))
+            d.make_scale('This is a netCDF dimension but not a netCDF '
+                         f'variable.{size:10d}')
+            d.attrs['_Netcdf4Dimid'] = np.int32(i)
+            dims[name] = d
+        row = rng.integers(1, n_b + 1, n_s).astype('i4')
+        col = rng.integers(1, n_a + 1, n_s).astype('i4')
+        row[5], col[5] = row[2], col[2]
+        for name, data, dim in (
+                ('src_grid_dims', np.array([4, 3], dtype='i4'),
+                 'src_grid_rank'),
+                ('dst_grid_dims', np.array([4, 2], dtype='i4'),
+                 'dst_grid_rank'),
+                ('row', row, 'n_s'), ('col', col, 'n_s'),
+                ('S', rng.random(n_s), 'n_s'),
+                ('frac_b', rng.random(n_b), 'n_b'),
+                ('area_a', rng.random(n_a), 'n_a')):
+            kw = dict(chunks=(len(data),), compression='gzip') \
+                if name == 'S' else {}
+            v = f.create_dataset(name, data=data, **kw)
+            v.dims[0].attach_scale(dims[dim])
+        f.attrs['title'] = 'synthetic ESMF-style weights'
+        f.attrs['normalization'] = 'destarea'
+    record('map_nc4', path)
+
+
+def reference_files():
+    for src, dst in (('mpasAreaVertex.nc', 'nc4_mpasAreaVertex.nc'),
+                     ('ref_latlon_to_mpas_cell.nc',
+                      'nc4_ref_latlon_to_mpas_cell.nc')):
+        path = os.path.join(OUT, dst)
+        shutil.copyfile(os.path.join(REF, src), path)
+        record(dst[:-3], path)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    classic()
+    latest()
+    scales()
+    mapping()
+    reference_files()
+    np.savez_compressed(os.path.join(OUT, 'expected.npz'), **expected)
+    for name in sorted(os.listdir(OUT)):
+        print(name, os.path.getsize(os.path.join(OUT, name)))
+    print(len(expected), 'expected entries')
+
+
+if __name__ == '__main__':
+    main()
