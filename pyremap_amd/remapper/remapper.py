@@ -119,14 +119,30 @@ class Remapper:
     def build_map(self, logger=None):
         """
         The reference shells out to ``ESMF_RegridWeightGen`` / ``mbtempest``
-        here (``build_map.py:8-91``).  Weight GENERATION is outside this
-        engine's scope: it applies existing weights.  Mapping files written
-        by those tools (or by ``pyremap_amd.synthetic``) are used as they are.
+        here (``build_map.py:8-91``); neither exists on the GPU images and
+        weight generation for unstructured meshes is outside this engine's
+        scope.  ``map_tool='analytic'`` (an addition) covers what has a closed
+        form: ``conserve`` / ``bilinear`` / ``neareststod`` between two
+        lat-lon grids, or two grids of one projection
+        (:mod:`pyremap_amd.weights`).  The file is written to
+        ``map_filename`` (default name as in ``setup.py:29-42``).
         """
-        raise NotImplementedError(
-            'pyremap_amd applies existing mapping files on the GPU; build '
-            'the mapping file with ESMF_RegridWeightGen / mbtempest (e.g. '
-            'through pyremap) and pass it as map_filename')
+        from pyremap_amd.remapper.setup import _setup_remapper
+        if self.map_tool != 'analytic':
+            raise NotImplementedError(
+                'pyremap_amd applies existing mapping files on the GPU; '
+                'build the mapping file with ESMF_RegridWeightGen / mbtempest '
+                '(e.g. through pyremap) and pass it as map_filename, or use '
+                "map_tool='analytic' for lat-lon / projection grid pairs")
+        _setup_remapper(self)
+        from pyremap_amd.weights import write_weights
+        if logger is not None:
+            logger.info(f'analytic {self.method} weights -> '
+                        f'{self.map_filename}')
+        write_weights(self.map_filename, self.src_descriptor,
+                      self.dst_descriptor, self.method)
+        self._ds_map = None
+        self._matrix = None
 
     @classmethod
     def from_triplets(cls, row, col, S, frac_b, src_descriptor,

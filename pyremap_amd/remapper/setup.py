@@ -16,7 +16,7 @@ from pyremap_amd.descriptor import (
     get_lat_lon_descriptor,
 )
 
-_TOOL_PREFIX = {'esmf': 'esmf', 'moab': 'mbtr'}
+_TOOL_PREFIX = {'esmf': 'esmf', 'moab': 'mbtr', 'analytic': 'analytic'}
 _METHOD_SUFFIX = {'conserve': 'aave', 'bilinear': 'bilin',
                   'neareststod': 'neareststod'}
 
@@ -44,7 +44,7 @@ def _setup_remapper(remapper):
         remapper.map_filename = (
             f'map_{src_descriptor.mesh_name}_to_{dst_descriptor.mesh_name}'
             f'_{suffix}.nc')
-    if map_tool not in ('moab', 'esmf'):
+    if map_tool not in ('moab', 'esmf', 'analytic'):
         raise ValueError(
             f'Unexpected map_tool {map_tool}. Valid '
             f'values are "esmf" or "moab".')

@@ -1,0 +1,239 @@
+"""
+Analytic mapping weights for logically rectangular grids (SURVEY.md section 8
+f-4): users without ESMF / MOAB can build the simple maps themselves.
+
+The reference generates weights only by shelling out to
+``ESMF_RegridWeightGen`` or ``mbtempest`` (``pyremap/remapper/build_map.py``),
+neither of which exists here.  For grids whose cells are products of two 1-D
+axes the common methods have closed forms:
+
+* ``conserve``  -- first-order conservative: S[i, j] = area(dst i n src j) /
+  area(dst i).  For lat-lon boxes on the sphere the area factorises into
+  (overlap in longitude) x (overlap in sin latitude), for x-y boxes of one
+  projection into (overlap in x) x (overlap in y).  ``frac_b`` = covered
+  fraction of the destination cell (ESMF's ``destarea`` normalisation: weights
+  of a fully covered cell sum to 1).
+* ``bilinear``  -- tensor-product linear interpolation between source cell
+  centres; periodic in longitude when the source grid is global; destination
+  points beyond the first / last centre of a non-periodic axis (e.g. poleward
+  of the last latitude row) take the nearest row.
+* ``neareststod`` -- nearest source centre per axis.
+
+The result is a :class:`pyremap_amd.io.mapfile.MappingFile` with exactly the
+schema ESMF writes (1-based ``row``/``col``, Fortran-ordered grid dims), so it
+goes through the same ``_load_mapping`` as any other mapping file.
+"""
+import numpy as np
+
+from pyremap_amd.descriptor import (
+    LatLonGridDescriptor,
+    ProjectionGridDescriptor,
+)
+from pyremap_amd.io.mapfile import MappingFile
+
+METHODS = ('conserve', 'bilinear', 'neareststod')
+
+
+# ---------------------------------------------------------------------------
+# one axis at a time: sparse (dst index, src index, weight) triplets
+# ---------------------------------------------------------------------------
+
+def _ascending(edges):
+    """(edges in ascending order, permutation of the cells)"""
+    edges = np.asarray(edges, dtype=np.float64)
+    n = len(edges) - 1
+    if edges[-1] >= edges[0]:
+        return edges, np.arange(n)
+    return edges[::-1].copy(), np.arange(n)[::-1].copy()
+
+
+def overlap_1d(src_edges, dst_edges, period=None):
+    """
+    Lengths of the pairwise overlaps of two sets of consecutive intervals.
+    Returns (j, i, length): destination cell, source cell, overlap > 0.
+    With ``period`` the source intervals repeat every ``period`` (longitude).
+    """
+    se, sperm = _ascending(src_edges)
+    de, dperm = _ascending(dst_edges)
+    ns = len(se) - 1
+    if period is not None:
+        # enough copies of the source axis to cover the destination extent
+        lo = int(np.floor((de[0] - se[-1]) / period))
+        hi = int(np.ceil((de[-1] - se[0]) / period))
+        shifts = np.arange(lo, hi + 1) * period
+    else:
+        shifts = np.zeros(1)
+    out_j, out_i, out_len = [], [], []
+    for shift in shifts:
+        lo_e = se[:-1] + shift
+        hi_e = se[1:] + shift
+        # destination cells a source interval can touch
+        first = np.searchsorted(de, lo_e, side='right') - 1
+        last = np.searchsorted(de, hi_e, side='left') - 1
+        first = np.clip(first, 0, len(de) - 2)
+        last = np.clip(last, -1, len(de) - 2)
+        count = np.maximum(last - first + 1, 0)
+        i = np.repeat(np.arange(ns), count)
+        start = np.repeat(first, count)
+        offs = np.arange(count.sum()) - np.repeat(
+            np.cumsum(count) - count, count)
+        j = start + offs
+        length = np.minimum(hi_e[i], de[j + 1]) - np.maximum(lo_e[i], de[j])
+        keep = length > 0.0
+        out_j.append(dperm[j[keep]])
+        out_i.append(sperm[i[keep]])
+        out_len.append(length[keep])
+    j = np.concatenate(out_j)
+    i = np.concatenate(out_i)
+    length = np.concatenate(out_len)
+    order = np.lexsort((i, j))
+    return j[order], i[order], length[order]
+
+
+def linear_1d(src_centres, dst_points, period=None):
+    """
+    Linear interpolation along one axis.  Returns (j, i, w) with up to two
+    entries per destination point; weights of a point sum to 1.
+    """
+    sc = np.asarray(src_centres, dtype=np.float64)
+    dp = np.asarray(dst_points, dtype=np.float64)
+    n = len(sc)
+    perm = np.arange(n)
+    if n > 1 and sc[-1] < sc[0]:
+        sc, perm = sc[::-1].copy(), perm[::-1].copy()
+    if n == 1:
+        j = np.arange(len(dp))
+        return j, np.zeros_like(j), np.ones(len(dp))
+    if period is not None:
+        # bring the points into [sc[0], sc[0] + period) and close the circle
+        t = sc[0] + np.mod(dp - sc[0], period)
+        ext = np.append(sc, sc[0] + period)
+        k = np.clip(np.searchsorted(ext, t, side='right') - 1, 0, n - 1)
+        w1 = (t - ext[k]) / (ext[k + 1] - ext[k])
+        i0, i1 = k, (k + 1) % n
+    else:
+        t = np.clip(dp, sc[0], sc[-1])
+        k = np.clip(np.searchsorted(sc, t, side='right') - 1, 0, n - 2)
+        w1 = (t - sc[k]) / (sc[k + 1] - sc[k])
+        i0, i1 = k, k + 1
+    jj = np.arange(len(dp))
+    j = np.concatenate([jj, jj])
+    i = perm[np.concatenate([i0, i1])]
+    w = np.concatenate([1.0 - w1, w1])
+    keep = w != 0.0
+    j, i, w = j[keep], i[keep], w[keep]
+    order = np.lexsort((i, j))
+    return j[order], i[order], w[order]
+
+
+def nearest_1d(src_centres, dst_points, period=None):
+    sc = np.asarray(src_centres, dtype=np.float64)
+    dp = np.asarray(dst_points, dtype=np.float64)
+    diff = dp[:, None] - sc[None, :]
+    if period is not None:
+        diff = np.mod(diff + 0.5 * period, period) - 0.5 * period
+    i = np.abs(diff).argmin(axis=1)
+    j = np.arange(len(dp))
+    return j, i, np.ones(len(dp))
+
+
+def _tensor(ay, ax, ny_src, nx_src, ny_dst, nx_dst):
+    """Kronecker product of the per-axis triplets -> 2-D (row, col, S)."""
+    jy, iy, wy = ay
+    jx, ix, wx = ax
+    row = (jy[:, None] * nx_dst + jx[None, :]).reshape(-1)
+    col = (iy[:, None] * nx_src + ix[None, :]).reshape(-1)
+    S = (wy[:, None] * wx[None, :]).reshape(-1)
+    order = np.lexsort((col, row))
+    return row[order], col[order], S[order]
+
+
+# ---------------------------------------------------------------------------
+# descriptors -> axes
+# ---------------------------------------------------------------------------
+
+def _axes(descriptor):
+    """(y centres, x centres, y edges, x edges, periodic period or None,
+    'sphere' | 'plane') of a rectangular descriptor."""
+    if isinstance(descriptor, LatLonGridDescriptor):
+        scale = 1.0 if 'rad' in descriptor.units else np.pi / 180.0
+        lat = np.asarray(descriptor.lat) * scale
+        lon = np.asarray(descriptor.lon) * scale
+        lat_e = np.clip(np.asarray(descriptor.lat_corner) * scale,
+                        -0.5 * np.pi, 0.5 * np.pi)
+        lon_e = np.asarray(descriptor.lon_corner) * scale
+        period = None if descriptor.regional else 2.0 * np.pi
+        return lat, lon, lat_e, lon_e, period, 'sphere'
+    if isinstance(descriptor, ProjectionGridDescriptor):
+        return (np.asarray(descriptor.y), np.asarray(descriptor.x),
+                np.asarray(descriptor.y_corner),
+                np.asarray(descriptor.x_corner), None, 'plane')
+    raise TypeError(
+        f'analytic weights need a LatLonGridDescriptor or a '
+        f'ProjectionGridDescriptor, not {type(descriptor).__name__}')
+
+
+def build_weights(src_descriptor, dst_descriptor, method='conserve'):
+    """
+    The mapping between two rectangular grids of the same kind (both lat-lon,
+    or both on the same map projection) as a :class:`MappingFile`.
+    """
+    if method not in METHODS:
+        raise ValueError(f'method {method!r}: expected one of {METHODS}')
+    sy, sx, sye, sxe, period, kind = _axes(src_descriptor)
+    dy, dx, dye, dxe, _, dkind = _axes(dst_descriptor)
+    if kind != dkind:
+        raise TypeError('source and destination must both be lat-lon grids '
+                        'or both be grids of one projection')
+    if kind == 'plane':
+        ps, pd = src_descriptor.projection, dst_descriptor.projection
+        if ps is not pd and getattr(ps, 'srs', ps) != getattr(pd, 'srs', pd):
+            raise ValueError('source and destination grids are on different '
+                             'projections')
+    ny_s, nx_s, ny_d, nx_d = len(sy), len(sx), len(dy), len(dx)
+    if method == 'conserve':
+        if kind == 'sphere':
+            sye, dye = np.sin(sye), np.sin(dye)     # area ~ dlon * dsin(lat)
+        jy, iy, ly = overlap_1d(sye, dye)
+        jx, ix, lx = overlap_1d(sxe, dxe, period)
+        wy = ly / np.abs(np.diff(dye))[jy]
+        wx = lx / np.abs(np.diff(dxe))[jx]
+        row, col, S = _tensor((jy, iy, wy), (jx, ix, wx), ny_s, nx_s, ny_d,
+                              nx_d)
+        frac_b = np.bincount(row, weights=S, minlength=ny_d * nx_d)
+        frac_b = np.minimum(frac_b, 1.0)
+    else:
+        axis = linear_1d if method == 'bilinear' else nearest_1d
+        row, col, S = _tensor(axis(sy, dy), axis(sx, dx, period), ny_s, nx_s,
+                              ny_d, nx_d)
+        frac_b = np.ones(ny_d * nx_d)
+        if period is None:
+            # destination points outside the source box are not mapped
+            inside_y = (dy >= min(sye[0], sye[-1])) & \
+                (dy <= max(sye[0], sye[-1]))
+            inside_x = (dx >= min(sxe[0], sxe[-1])) & \
+                (dx <= max(sxe[0], sxe[-1]))
+            inside = (inside_y[:, None] & inside_x[None, :]).reshape(-1)
+            keep = inside[row]
+            row, col, S = row[keep], col[keep], S[keep]
+            frac_b = inside.astype(np.float64)
+    return MappingFile(
+        ny_s * nx_s, ny_d * nx_d,
+        np.array([nx_s, ny_s], dtype=np.int32),
+        np.array([nx_d, ny_d], dtype=np.int32),
+        (row + 1).astype(np.int32), (col + 1).astype(np.int32), S, frac_b)
+
+
+def write_weights(filename, src_descriptor, dst_descriptor,
+                  method='conserve'):
+    """Build the weights and write them as a mapping file."""
+    from pyremap_amd.io.mapfile import write_mapping
+    m = build_weights(src_descriptor, dst_descriptor, method)
+    write_mapping(filename, m.n_a, m.n_b, m.src_grid_dims, m.dst_grid_dims,
+                  m.row, m.col, m.S, m.frac_b,
+                  attrs={'map_method': method,
+                         'weight_generator': 'pyremap_amd.weights (analytic)',
+                         'normalization': 'destarea',
+                         'domain_a': str(src_descriptor.mesh_name),
+                         'domain_b': str(dst_descriptor.mesh_name)})
+    return m

@@ -207,3 +207,49 @@ def test_netcdf4_mapping_and_field_files(tmp_path):
     assert_bitwise(np.asarray(out2['SST'].values),
                    np.ma.filled(ref2, np.nan), 'netcdf4 field')
     assert np.array_equal(out2['date'].values, ds['date'].values)
+
+
+def test_build_map_analytic_then_remap(tmp_path):
+    """``Remapper(map_tool='analytic').build_map()`` writes the mapping file
+    under the reference's default name and the GPU applies it: a conservative
+    1 deg -> 2.5 deg remap keeps the area integral of the field; the result
+    equals the oracle's bit for bit."""
+    from oracle import oracle
+    from pyremap_amd import DataArray, Remapper, get_lat_lon_descriptor
+    from pyremap_amd.io import mapfile
+    src = get_lat_lon_descriptor(1.0, 1.0)
+    dst = get_lat_lon_descriptor(2.5, 2.5)
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        r = Remapper(method='conserve', map_tool='analytic',
+                     src_descriptor=src, dst_descriptor=dst)
+        r.build_map()
+        assert r.map_filename == \
+            'map_1.0x1.0degree_to_2.5x2.5degree_analyticaave.nc'
+        assert os.path.exists(r.map_filename)
+        lat, lon = np.meshgrid(src.lat, src.lon, indexing='ij')
+        rng = np.random.default_rng(3)
+        field = np.cos(np.radians(lat))[None] * (
+            1.0 + 0.3 * np.sin(np.radians(3 * lon))[None] +
+            0.01 * rng.standard_normal((6,) + lat.shape))
+        out = r.remap_numpy(DataArray(field, dims=('t', 'lat', 'lon')))
+        m = mapfile.read_mapping(r.map_filename)
+    finally:
+        os.chdir(cwd)
+    csr = oracle.coo_to_csr(m.row - 1, m.col - 1, m.S, m.n_b, m.n_a)
+    ref = oracle.remap_numpy_array(csr, m.frac_b, (len(dst.lat),
+                                                   len(dst.lon)),
+                                   field, [1, 2], None)
+    got = np.asarray(out.values)
+    assert_bitwise(got, np.ma.filled(ref, np.nan), 'analytic conserve')
+
+    def areas(d):
+        dsin = np.diff(np.sin(np.radians(d.lat_corner)))
+        return dsin[:, None] * np.radians(np.diff(d.lon_corner))[None, :]
+
+    before = (field * areas(src)[None]).sum(axis=(1, 2))
+    after = (got * areas(dst)[None]).sum(axis=(1, 2))
+    assert np.allclose(after, before, rtol=1e-12)
+    with pytest.raises(NotImplementedError, match='analytic'):
+        Remapper(src_descriptor=src, dst_descriptor=dst).build_map()

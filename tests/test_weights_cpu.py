@@ -1,0 +1,184 @@
+"""
+Analytic weight generation against brute-force
+quadrature and the invariants a conservative / bilinear map must satisfy.
+CPU only; the weights are applied on the GPU in tests/test_gpu_file_path.py.
+"""
+import numpy as np
+import pytest
+
+from pyremap_amd import (
+    LatLonGridDescriptor,
+    get_lat_lon_descriptor,
+    get_polar_descriptor,
+)
+from pyremap_amd.io import mapfile
+from pyremap_amd.weights import (
+    build_weights,
+    linear_1d,
+    overlap_1d,
+    write_weights,
+)
+
+
+def _dense(m):
+    A = np.zeros((m.n_b, m.n_a))
+    np.add.at(A, (m.row - 1, m.col - 1), m.S)
+    return A
+
+
+def _areas(d):
+    scale = np.pi / 180.0 if 'deg' in d.units else 1.0
+    dlon = np.abs(np.diff(d.lon_corner)) * scale
+    dsin = np.abs(np.diff(np.sin(np.clip(d.lat_corner * scale,
+                                         -np.pi / 2, np.pi / 2))))
+    return (dsin[:, None] * dlon[None, :]).reshape(-1)
+
+
+def test_overlap_1d_against_brute_force():
+    rng = np.random.default_rng(0)
+    for trial in range(20):
+        se = np.sort(rng.uniform(0, 10, rng.integers(2, 12)))
+        de = np.sort(rng.uniform(-2, 12, rng.integers(2, 12)))
+        if trial % 3 == 0:
+            se = se[::-1].copy()
+        if trial % 4 == 0:
+            de = de[::-1].copy()
+        j, i, length = overlap_1d(se, de)
+        got = np.zeros((len(de) - 1, len(se) - 1))
+        got[j, i] = length
+        for a in range(len(de) - 1):
+            for b in range(len(se) - 1):
+                lo = max(min(de[a], de[a + 1]), min(se[b], se[b + 1]))
+                hi = min(max(de[a], de[a + 1]), max(se[b], se[b + 1]))
+                assert abs(got[a, b] - max(hi - lo, 0.0)) < 1e-14
+
+
+def test_overlap_1d_periodic():
+    se = np.linspace(-180.0, 180.0, 13)          # 30 degree cells
+    de = np.linspace(0.0, 360.0, 9)              # 45 degree cells, shifted
+    j, i, length = overlap_1d(se, de, period=360.0)
+    got = np.zeros((8, 12))
+    np.add.at(got, (j, i), length)
+    assert np.allclose(got.sum(axis=1), 45.0)    # every dst cell covered
+    assert np.allclose(got.sum(axis=0), 30.0)    # every src cell used up
+
+
+def test_linear_1d_reproduces_linear_functions():
+    rng = np.random.default_rng(1)
+    sc = np.sort(rng.uniform(0, 10, 9))
+    dp = rng.uniform(sc[0], sc[-1], 50)
+    for src in (sc, sc[::-1].copy()):
+        j, i, w = linear_1d(src, dp)
+        val = np.zeros(50)
+        np.add.at(val, j, w * (3.0 * src[i] - 2.0))
+        assert np.allclose(val, 3.0 * dp - 2.0)
+    # periodic: a point between the last and the first centre
+    lon = np.arange(-175.0, 180.0, 10.0)
+    j, i, w = linear_1d(lon, np.array([178.0, -179.0]), period=360.0)
+    assert sorted(i[j == 0].tolist()) == [0, 35]
+    assert np.isclose(w[(j == 0) & (i == 35)][0], 0.7)
+    assert np.isclose(w[(j == 1) & (i == 0)][0], 0.6)
+
+
+@pytest.mark.parametrize('src_res, dst_res', [((10.0, 5.0), (4.0, 3.0)),
+                                              ((3.0, 2.0), (7.5, 6.0))])
+def test_conservative_global_lat_lon(src_res, dst_res):
+    src = get_lat_lon_descriptor(*src_res)
+    dst = get_lat_lon_descriptor(*dst_res, lon_min=0.0, lon_max=360.0)
+    m = build_weights(src, dst, 'conserve')
+    A = _dense(m)
+    area_a, area_b = _areas(src), _areas(dst)
+    assert np.allclose(m.frac_b, 1.0, atol=1e-12)
+    assert np.allclose(A.sum(axis=1), 1.0, atol=1e-12)     # constants kept
+    # conservation: every source cell's area is handed out exactly once
+    assert np.allclose(area_b @ A, area_a, rtol=1e-12, atol=1e-15)
+    # against quadrature of one destination cell
+    scale = np.pi / 180.0
+    row = (len(dst.lat) // 3) * len(dst.lon) + 5
+    jy, jx = divmod(row, len(dst.lon))
+    n = 400
+    lat = np.linspace(dst.lat_corner[jy], dst.lat_corner[jy + 1], n + 1)
+    lon = np.linspace(dst.lon_corner[jx], dst.lon_corner[jx + 1], n + 1)
+    latc = 0.5 * (lat[:-1] + lat[1:])
+    lonc = (0.5 * (lon[:-1] + lon[1:]) + 180.0) % 360.0 - 180.0
+    w = np.diff(np.sin(lat * scale))[:, None] * np.ones(n)[None, :]
+    iy = np.searchsorted(src.lat_corner, latc) - 1
+    ix = np.searchsorted(src.lon_corner, lonc) - 1
+    quad = np.zeros(m.n_a)
+    np.add.at(quad, (iy[:, None] * len(src.lon) + ix[None, :]).reshape(-1),
+              w.reshape(-1))
+    quad /= quad.sum()
+    assert np.abs(A[row] - quad).max() < 2e-3
+
+
+def test_conservative_regional_source_gives_frac_b():
+    src = LatLonGridDescriptor.create(np.linspace(-30, 30, 13),
+                                      np.linspace(10, 100, 19))
+    dst = get_lat_lon_descriptor(20.0, 20.0)
+    assert src.regional and not dst.regional
+    m = build_weights(src, dst, 'conserve')
+    A = _dense(m)
+    assert np.allclose(A.sum(axis=1), m.frac_b)
+    fb = m.frac_b.reshape(len(dst.lat), len(dst.lon))
+    assert fb.max() <= 1.0 and fb.min() == 0.0
+    assert np.isclose(fb[4, 10], 1.0)          # 0..20 N, 20..40 E: inside
+    assert 0.0 < fb[4, 9] < 1.0                # 0..20 E: half covered
+    assert np.allclose(_areas(dst) @ A, _areas(src), rtol=1e-12)
+
+
+def test_bilinear_lat_lon_is_exact_for_bilinear_fields():
+    src = get_lat_lon_descriptor(10.0, 10.0)
+    dst = get_lat_lon_descriptor(2.5, 2.5)
+    m = build_weights(src, dst, 'bilinear')
+    A = _dense(m)
+    assert np.allclose(A.sum(axis=1), 1.0)
+    assert (np.diff(np.sort(m.row)) >= 0).all() and m.S.min() > 0.0
+    assert np.bincount(m.row - 1).max() <= 4
+    lat_s, lon_s = np.meshgrid(src.lat, src.lon, indexing='ij')
+    lat_d, lon_d = np.meshgrid(dst.lat, dst.lon, indexing='ij')
+    f = lambda la, lo: 2.0 + 0.1 * la + 3.0 * np.cos(np.radians(lo))
+    got = (A @ f(lat_s, lon_s).reshape(-1)).reshape(lat_d.shape)
+    inner = (np.abs(lat_d) <= 85.0)
+    # linear in latitude is reproduced exactly; cos(lon) to O(dlon^2)
+    assert np.abs(got - f(lat_d, lon_d))[inner].max() < 3.0 * (
+        np.radians(10.0) ** 2) / 8 * 1.01
+    g = lambda la, lo: 5.0 - 0.25 * la
+    got = (A @ g(lat_s, lon_s).reshape(-1)).reshape(lat_d.shape)
+    assert np.abs(got - g(lat_d, lon_d))[inner].max() < 1e-12
+
+
+def test_nearest_and_projection_grids():
+    src = get_polar_descriptor(600.0, 400.0, 100.0, 100.0)
+    dst = get_polar_descriptor(500.0, 300.0, 25.0, 25.0)
+    for method in ('bilinear', 'neareststod', 'conserve'):
+        m = build_weights(src, dst, method)
+        A = _dense(m)
+        assert np.allclose(A.sum(axis=1), m.frac_b, atol=1e-12), method
+        assert np.allclose(m.frac_b, 1.0, atol=1e-12), method
+        assert list(m.src_grid_dims) == [7, 5]
+        assert list(m.dst_grid_dims) == [21, 13]
+        xs, ys = np.meshgrid(src.x, src.y)
+        xd, yd = np.meshgrid(dst.x, dst.y)
+        if method == 'bilinear':
+            got = A @ (1.0 + 2e-5 * xs - 1e-5 * ys).reshape(-1)
+            assert np.allclose(got, (1.0 + 2e-5 * xd - 1e-5 * yd).reshape(-1))
+        if method == 'neareststod':
+            assert np.bincount(m.row - 1, minlength=m.n_b).max() == 1
+    with pytest.raises(TypeError, match='both be lat-lon'):
+        build_weights(src, get_lat_lon_descriptor(10.0, 10.0))
+    with pytest.raises(ValueError, match='expected one of'):
+        build_weights(src, dst, 'patch')
+
+
+def test_write_weights_round_trip(tmp_path):
+    src = get_lat_lon_descriptor(20.0, 20.0)
+    dst = get_lat_lon_descriptor(15.0, 10.0)
+    path = str(tmp_path / 'map.nc')
+    m = write_weights(path, src, dst, 'conserve')
+    back = mapfile.read_mapping(path)
+    for name in ('row', 'col', 'S', 'frac_b', 'src_grid_dims',
+                 'dst_grid_dims'):
+        np.testing.assert_array_equal(getattr(back, name), getattr(m, name))
+    assert (back.n_a, back.n_b) == (m.n_a, m.n_b)
+    # Fortran order in the file: [nlon, nlat]
+    assert list(back.src_grid_dims) == [len(src.lon), len(src.lat)]
