@@ -208,8 +208,11 @@ __device__ __forceinline__ void finish_row(
                 ok[v] = true;
                 y[v] = acc[t][v];
             } else if constexpr (MODE == REMAP_MODE_FRACB) {
+                // x / 1.0 == x exactly: bilinear maps (frac_b == 1) skip
+                // the 11-instruction f64 division; fb is wave-uniform
                 ok[v] = fb > 0.0;
-                y[v] = ok[v] ? acc[t][v] / fb : __builtin_nan("");
+                y[v] = !ok[v] ? __builtin_nan("")
+                       : (fb == 1.0) ? acc[t][v] : acc[t][v] / fb;
             } else {
                 ok[v] = den[t][v] > p.thr;
                 y[v] = ok[v] ? acc[t][v] / den[t][v] : __builtin_nan("");
@@ -435,9 +438,45 @@ __global__ __launch_bounds__(kPatchBlock) void spmm_patch(
     int32_t *lds_rid = lds_rptr + patch_rows + 1;
 
     // 1. gather: distinct source rows by LDS-DMA, the patch's entries by
-    //    plain loads (they are contiguous: patch-major CSR)
+    //    plain loads (they are contiguous: patch-major CSR).  The phase is a
+    //    chain of dependent memory trips with every wave of the workgroup
+    //    waiting at the barrier behind it, so loads are issued level by
+    //    level: everything addressed by the patch id alone first, then what
+    //    those values address, LDS writes last (3 trips instead of 5).
     const int u0 = pptr[patch];
     const int U = pptr[patch + 1] - u0;
+    const int64_t slot0 = p.row_begin + patch * patch_rows;
+    const int64_t local0 = patch * patch_rows;  // index into prow
+    int nrows = patch_rows;
+    if (slot0 + nrows > p.row_end)
+        nrows = static_cast<int>(p.row_end - slot0);
+    const int e0 = prow[local0];
+    const int n_e = prow[local0 + nrows] - e0;
+    // branch-free (clamped) loads: a load inside a divergent branch makes
+    // hipcc wait for it on the spot
+    const int tc = tid < nrows ? tid : nrows - 1;
+    const int32_t *ro = row_order ? row_order + slot0 : prow + local0;
+    const int32_t rid_ld = ro[tc];
+    const int32_t my_rid =
+        row_order ? rid_ld : static_cast<int32_t>(slot0 + tc);
+    const int32_t my_rp = prow[local0 + (tid <= nrows ? tid : nrows)];
+    constexpr int kPre = 2;  // entry batches held in registers meanwhile
+    double ev[kPre];
+    int32_t el[kPre];
+#pragma unroll
+    for (int k = 0; k < kPre; ++k) {
+        const int t = tid + k * kPatchBlock;
+        ev[k] = 0.0;
+        el[k] = 0;
+        if (t < n_e) {
+            ev[k] = pval[e0 + t];
+            el[k] = plidx[e0 + t];
+        }
+    }
+    // before the DMA loop: behind it the wait for my_rid would be vmcnt(0)
+    double my_fb = 0.0;
+    if constexpr (MODE == REMAP_MODE_FRACB)
+        my_fb = frac_b[my_rid];
     const double *__restrict__ X = static_cast<const double *>(p.X);
     for (int j = wave * kRowsPerDma; j < U; j += kPatchWaves * kRowsPerDma) {
         // the second row of a pair may not exist: fetch the first again
@@ -452,25 +491,24 @@ __global__ __launch_bounds__(kPatchBlock) void spmm_patch(
             (__attribute__((address_space(3))) void *)(lds + j * kRowBytes),
             16, 0, 0);
     }
-    const int64_t slot0 = p.row_begin + patch * patch_rows;
-    const int64_t local0 = patch * patch_rows;  // index into prow
-    int nrows = patch_rows;
-    if (slot0 + nrows > p.row_end)
-        nrows = static_cast<int>(p.row_end - slot0);
-    const int e0 = prow[local0];
-    const int n_e = prow[local0 + nrows] - e0;
-    for (int t = tid; t < n_e; t += kPatchBlock) {
+#pragma unroll
+    for (int k = 0; k < kPre; ++k) {
+        const int t = tid + k * kPatchBlock;
+        if (t < n_e) {
+            lds_val[t] = ev[k];
+            lds_lidx[t] = el[k];
+        }
+    }
+    for (int t = tid + kPre * kPatchBlock; t < n_e; t += kPatchBlock) {
         lds_val[t] = pval[e0 + t];
         lds_lidx[t] = plidx[e0 + t];
     }
     if (tid <= nrows)
-        lds_rptr[tid] = prow[local0 + tid] - e0;
+        lds_rptr[tid] = my_rp - e0;
     if (tid < nrows) {
-        const int32_t rid = row_order ? row_order[slot0 + tid]
-                                      : static_cast<int32_t>(slot0 + tid);
-        lds_rid[tid] = rid;
+        lds_rid[tid] = my_rid;
         if constexpr (MODE == REMAP_MODE_FRACB)
-            lds_fb[tid] = frac_b[rid];
+            lds_fb[tid] = my_fb;
     }
     // 2. everything landed, visible to every wave
     __syncthreads();
@@ -478,10 +516,30 @@ __global__ __launch_bounds__(kPatchBlock) void spmm_patch(
     // 3. compute the patch's rows from LDS
     const bool cached = (flags & REMAP_FLAG_CACHED_STORE) != 0;
     const char *mine = lds + lane * (VEC * 8);
+    // the next row's header (id, entry range, frac_b) is read while this
+    // row is being computed: short rows (4 entries of a bilinear map) are a
+    // chain of LDS round trips otherwise
+    int32_t nx_rid = 0, nx_s = 0, nx_e = 0;
+    double nx_fb = 0.0;
+    if (wave < nrows) {
+        nx_rid = lds_rid[wave];
+        nx_s = lds_rptr[wave];
+        nx_e = lds_rptr[wave + 1];
+        if constexpr (MODE == REMAP_MODE_FRACB)
+            nx_fb = lds_fb[wave];
+    }
     for (int r = wave; r < nrows; r += kPatchWaves) {
-        const int64_t i = __builtin_amdgcn_readfirstlane(lds_rid[r]);
-        const int s = __builtin_amdgcn_readfirstlane(lds_rptr[r]);
-        const int e = __builtin_amdgcn_readfirstlane(lds_rptr[r + 1]);
+        const int64_t i = __builtin_amdgcn_readfirstlane(nx_rid);
+        const int s = __builtin_amdgcn_readfirstlane(nx_s);
+        const int e = __builtin_amdgcn_readfirstlane(nx_e);
+        const double fb_row = nx_fb;
+        if (r + kPatchWaves < nrows) {
+            nx_rid = lds_rid[r + kPatchWaves];
+            nx_s = lds_rptr[r + kPatchWaves];
+            nx_e = lds_rptr[r + kPatchWaves + 1];
+            if constexpr (MODE == REMAP_MODE_FRACB)
+                nx_fb = lds_fb[r + kPatchWaves];
+        }
         double acc[1][VEC];
         double den[1][VEC];
 #pragma unroll
@@ -489,7 +547,7 @@ __global__ __launch_bounds__(kPatchBlock) void spmm_patch(
             acc[0][v] = 0.0;
             den[0][v] = 0.0;
         }
-#pragma unroll 8
+#pragma unroll 4
         for (int jj = s; jj < e; ++jj) {
             // (index, weight) by LDS broadcast (same address in every lane);
             // measured faster than one coalesced read + v_readlane
@@ -509,10 +567,7 @@ __global__ __launch_bounds__(kPatchBlock) void spmm_patch(
                 }
             }
         }
-        double fb = 0.0;
-        if constexpr (MODE == REMAP_MODE_FRACB)
-            fb = lds_fb[r];
-        finish_row<VEC, 1, MODE>(p, i, fb, act, yoff, acc, den, cached);
+        finish_row<VEC, 1, MODE>(p, i, fb_row, act, yoff, acc, den, cached);
     }
 }
 

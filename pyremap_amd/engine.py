@@ -539,19 +539,22 @@ class RemapPlan:
         return nu / self.nnz
 
     #: tiles tried by auto_schedule, largest first
-    AUTO_TILES = ((24, 24), (16, 16), (8, 16), (8, 8), (6, 8), (4, 8))
+    AUTO_TILES = ((24, 24), (32, 16), (24, 16), (16, 16), (8, 16), (8, 8),
+                  (6, 8), (4, 8))
 
     def auto_schedule(self, grid_dims, max_ratio=0.30,
-                      lds_budget=72 * 1024):
+                      lds_budget=100 * 1024):
         """
         Choose the schedule for this mapping.  The LDS-staged patch family
         pays when neighbouring destination rows share most of their source
         rows (bilinear or conservative maps onto a much finer grid: measured
         2.2x on BASELINE config 4) and merely ties the register-gather kernel
         otherwise (config 3).  So: build the patch plan with the largest tile
-        whose LDS footprint leaves room for two workgroups per CU, and keep
-        it only if distinct source rows / entries <= ``max_ratio``.  Returns
-        the description of what was chosen.
+        whose LDS footprint stays under ``lds_budget`` -- fewer, larger
+        gather phases beat a second resident workgroup: 24 x 24 at one
+        workgroup per CU measured 5.36 ms on config 4, 16 x 24 at two 5.64 ms
+        -- and keep it only if distinct source rows / entries <=
+        ``max_ratio``.  Returns the description of what was chosen.
         """
         self.patches = None
         self.groups = None

@@ -80,6 +80,18 @@ __global__ __launch_bounds__(256) void k_read(const u4 *__restrict__ src,
         *sink = acc;
 }
 
+// non-persistent read: one block per 16 KiB (4 x 16 B per thread)
+__global__ __launch_bounds__(256) void k_read_flat(const u4 *__restrict__ src,
+                                                   size_t n, u4 *sink)
+{
+    const size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    if (i + 768 >= n)
+        return;
+    u4 acc = src[i] ^ src[i + 256] ^ src[i + 512] ^ src[i + 768];
+    if (acc[0] == 0x12345678u && acc[1] == 0x9abcdef0u)
+        *sink = acc;
+}
+
 template <bool NT>
 __global__ __launch_bounds__(256) void k_write(u4 *__restrict__ dst, size_t n)
 {
@@ -162,6 +174,10 @@ int main(int argc, char **argv)
             printf("grid %8u read         %7.1f GB/s\n", grid, gb / (t * 1e-3));
             t = time_ms([&] { hipLaunchKernelGGL(k_rowcopy, dim3(grid), dim3(256), 0, 0, dst, src, n / 256); }, 10);
             printf("grid %8u rowcopy 4KiB %7.1f GB/s (r+w)\n", grid, 2 * gb / (t * 1e-3));
+        }
+        if (!g) {
+            t = time_ms([&] { hipLaunchKernelGGL(k_read_flat, dim3((unsigned)(n / 1024)), dim3(256), 0, 0, src, n, sink); }, 10);
+            printf("grid %8u read flat    %7.1f GB/s\n", (unsigned)(n / 1024), gb / (t * 1e-3));
         }
         t = time_ms([&] { hipLaunchKernelGGL(k_write<false>, dim3(grid), dim3(256), 0, 0, dst, n); }, 10);
         printf("grid %8u write plain  %7.1f GB/s\n", grid, gb / (t * 1e-3));
