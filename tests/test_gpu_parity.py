@@ -575,6 +575,69 @@ def test_config3_full_size_bitwise_and_properties(dev):
                            torch.nan_to_num(y, nan=1e300)), tune
 
 
+@pytest.mark.parametrize('name, mode', [
+    ('config3', 'masked'), ('headline', 'fracb'), ('config4', 'fracb'),
+    ('config5', 'fracb'), ('config5', 'masked')])
+def test_full_size_sampled_rows_bitwise(dev, name, mode):
+    """
+    Every BASELINE configuration at its FULL size, as `Remapper` would run it
+    (auto-selected schedule): a few thousand destination rows -- the first,
+    the last and a random sample -- are recomputed by the CPU oracle from
+    their own CSR rows and must match bit for bit; and the plain
+    wave-per-row kernel must agree with the scheduled one on EVERY row.
+    """
+    from oracle import oracle
+    from pyremap_amd import engine, synthetic
+    m = synthetic.make_config(name, device=dev)
+    K = synthetic.CONFIGS[name]['K']
+    plan = engine.RemapPlan.from_triplets(m.row, m.col, m.S, m.frac_b,
+                                          m.n_a, m.n_b, device=dev)
+    choice = plan.auto_schedule(m.dst_dims)
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    x = torch.randn((m.n_a, K), generator=g, device=dev,
+                    dtype=torch.float64)
+    masked = mode == 'masked'
+    if masked:
+        x[torch.rand(m.n_a, generator=g, device=dev) < 0.2, :] = float('nan')
+        x[torch.rand(m.n_a, generator=g, device=dev) < 0.05, ::7] = \
+            float('nan')
+    emode = engine.MODE_MASKED if masked else engine.MODE_FRACB
+    y = engine.remap_tensor(plan, m.dst_dims, x, [0], emode, threshold=0.01)
+    y = y.reshape(m.n_b, K)
+    # -- sampled rows against the oracle ----------------------------------
+    edge = torch.arange(64, device=dev)
+    rows = torch.cat([edge, m.n_b - 1 - edge,
+                      torch.randint(0, m.n_b, (4000,), generator=g,
+                                    device=dev)]).unique()
+    starts = plan.rowptr[rows]
+    lens = plan.rowptr[rows + 1] - starts
+    total = int(lens.sum())
+    first = torch.cumsum(lens, 0) - lens
+    idx = torch.repeat_interleave(starts - first, lens) + \
+        torch.arange(total, device=dev)
+    ucols, inv = torch.unique(plan.col[idx].to(torch.int64),
+                              return_inverse=True)
+    indptr = np.zeros(len(rows) + 1, dtype=np.int64)
+    indptr[1:] = torch.cumsum(lens, 0).cpu().numpy()
+    sub = oracle.OracleCSR(indptr, inv.cpu().numpy().astype(np.int32),
+                           plan.val[idx].cpu().numpy(),
+                           (len(rows), len(ucols)))
+    ref, ref_mask = oracle.remap_flat(
+        sub, m.frac_b[rows].cpu().numpy(), x[ucols].cpu().numpy(), masked,
+        0.01, nthreads=8)
+    ref[ref_mask] = np.nan
+    assert_bitwise(y[rows].cpu().numpy(), ref,
+                   f'{name} {mode} {choice["family"]}')
+    assert bool(torch.isnan(y[rows]).any()) == bool(ref_mask.any())
+    del ref
+    # -- the unscheduled kernel agrees everywhere ---------------------------
+    y1 = engine.remap_tensor(plan, m.dst_dims, x, [0], emode, threshold=0.01,
+                             tune=[1]).reshape(m.n_b, K)
+    same = (y1 == y) | (torch.isnan(y1) & torch.isnan(y))
+    assert bool(same.all()), f'{name} {mode}: families disagree'
+
+
 def test_apply_is_graph_capturable(dev):
     """remap_apply_f64 allocates nothing and never synchronises: it can be
     captured in a HIP graph and replayed on new field contents."""
