@@ -124,7 +124,10 @@ class _Reader:
             nelems = self.nonneg()
             vals = self.values(nc_type, nelems)
             if nc_type == 2:
-                out[name] = vals.tobytes().decode('utf-8', 'replace')
+                # NUL terminators written by C programs are not part of the
+                # text (netCDF4-python drops them as well)
+                out[name] = vals.tobytes().decode(
+                    'utf-8', 'replace').replace('\x00', '')
             else:
                 vals = vals.astype(vals.dtype.newbyteorder('='))
                 out[name] = vals[0] if nelems == 1 else vals

@@ -27,6 +27,8 @@ import numpy as np
 
 from pyremap_amd.descriptor import (
     LatLonGridDescriptor,
+    MpasMeshDescriptor,
+    PointCollectionDescriptor,
     ProjectionGridDescriptor,
 )
 from pyremap_amd.io.mapfile import MappingFile
@@ -173,13 +175,78 @@ def _axes(descriptor):
         f'ProjectionGridDescriptor, not {type(descriptor).__name__}')
 
 
+def _points(descriptor):
+    """(lat, lon) in radians of a point-like destination, or None."""
+    if isinstance(descriptor, PointCollectionDescriptor):
+        scale = 1.0 if 'rad' in descriptor.units else np.pi / 180.0
+        return (np.asarray(descriptor.lat, dtype=np.float64) * scale,
+                np.asarray(descriptor.lon, dtype=np.float64) * scale)
+    if isinstance(descriptor, MpasMeshDescriptor) and descriptor.coords:
+        c = descriptor.coords
+        return (np.asarray(c[descriptor._lat_coord]['data'], np.float64),
+                np.asarray(c[descriptor._lon_coord]['data'], np.float64))
+    return None
+
+
+def _to_points(src_descriptor, dst_descriptor, method):
+    """Lat-lon grid -> scattered points (MPAS cell centres, point
+    collections): the same per-axis interpolation, one (y, x) pair per
+    destination point instead of a tensor product."""
+    if method == 'conserve':
+        raise ValueError(
+            'method conserve needs cells, not points, as the destination '
+            '(as in the reference, setup.py:50-55)')
+    sy, sx, sye, sxe, period, kind = _axes(src_descriptor)
+    if kind != 'sphere':
+        raise TypeError('point destinations need a lat-lon source grid')
+    plat, plon = _points(dst_descriptor)
+    axis = linear_1d if method == 'bilinear' else nearest_1d
+    n = len(plat)
+    jy, iy, wy = axis(sy, plat)
+    jx, ix, wx = axis(sx, plon, period)
+    # pair every y entry of a point with every x entry of the same point
+    oy = np.argsort(jy, kind='stable')
+    ox = np.argsort(jx, kind='stable')
+    jy, iy, wy = jy[oy], iy[oy], wy[oy]
+    jx, ix, wx = jx[ox], ix[ox], wx[ox]
+    cy = np.bincount(jy, minlength=n)
+    cx = np.bincount(jx, minlength=n)
+    sy0 = np.cumsum(cy) - cy
+    sx0 = np.cumsum(cx) - cx
+    per = cy * cx
+    point = np.repeat(np.arange(n), per)
+    k = np.arange(per.sum()) - np.repeat(np.cumsum(per) - per, per)
+    ky = sy0[point] + k // np.maximum(cx[point], 1)
+    kx = sx0[point] + k % np.maximum(cx[point], 1)
+    row = point
+    col = iy[ky] * len(sx) + ix[kx]
+    S = wy[ky] * wx[kx]
+    frac_b = np.ones(n)
+    if period is None:
+        inside = (plat >= min(sye[0], sye[-1])) & \
+            (plat <= max(sye[0], sye[-1])) & \
+            (plon >= min(sxe[0], sxe[-1])) & (plon <= max(sxe[0], sxe[-1]))
+        keep = inside[row]
+        row, col, S = row[keep], col[keep], S[keep]
+        frac_b = inside.astype(np.float64)
+    order = np.lexsort((col, row))
+    return MappingFile(
+        len(sy) * len(sx), n, np.array([len(sx), len(sy)], dtype=np.int32),
+        np.array([n], dtype=np.int32), (row[order] + 1).astype(np.int32),
+        (col[order] + 1).astype(np.int32), S[order], frac_b)
+
+
 def build_weights(src_descriptor, dst_descriptor, method='conserve'):
     """
     The mapping between two rectangular grids of the same kind (both lat-lon,
-    or both on the same map projection) as a :class:`MappingFile`.
+    or both on the same map projection), or from a lat-lon grid to scattered
+    points (an MPAS mesh's cell / edge / vertex positions, a point
+    collection), as a :class:`MappingFile`.
     """
     if method not in METHODS:
         raise ValueError(f'method {method!r}: expected one of {METHODS}')
+    if _points(dst_descriptor) is not None:
+        return _to_points(src_descriptor, dst_descriptor, method)
     sy, sx, sye, sxe, period, kind = _axes(src_descriptor)
     dy, dx, dye, dxe, _, dkind = _axes(dst_descriptor)
     if kind != dkind:

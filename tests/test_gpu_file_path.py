@@ -253,3 +253,130 @@ def test_build_map_analytic_then_remap(tmp_path):
     assert np.allclose(after, before, rtol=1e-12)
     with pytest.raises(NotImplementedError, match='analytic'):
         Remapper(src_descriptor=src, dst_descriptor=dst).build_map()
+
+
+def test_reference_fixture_latlon_file_to_latlon_array(tmp_path):
+    """
+    The reference's ``test_latlon_file_to_latlon_array``
+    (tests/test_interpolate.py:492-516) replayed on its own data files: the
+    1 deg SST file -> a 2 deg grid, through ``ncremap`` (file -> file) and
+    ``remap_numpy``, compared with the output the reference stored.  The
+    weights there came from ESMF (bilinear on great circles), here from
+    ``pyremap_amd.weights`` (bilinear in lat-lon), so SST agrees to
+    5e-3 K rather than the reference's rtol 1e-5; everything structural --
+    dims, coordinates, untouched variables, dtypes, attributes -- is exact.
+    """
+    from pyremap_amd import LatLonGridDescriptor, Remapper
+    from pyremap_amd.io.netcdf import open_dataset
+    here = os.path.join(os.path.dirname(__file__), 'golden', 'ref_fixtures')
+    in_filename = os.path.join(here, 'SST_annual_1870-1900.nc')
+    ref_filename = os.path.join(here, 'ref_latlon_file_to_latlon_array.nc')
+    src = LatLonGridDescriptor.read(in_filename, lat_var_name='lat',
+                                    lon_var_name='lon')
+    assert src.mesh_name == '1.0x1.0degree' and src.regional is False
+    assert src.units == 'degrees'
+    dst = LatLonGridDescriptor.create(np.linspace(-90.0, 90.0, 91),
+                                      np.linspace(-180.0, 180.0, 181),
+                                      units='degrees')
+    remapper = Remapper(ntasks=1, map_filename=str(tmp_path / 'map.nc'),
+                        method='bilinear', map_tool='analytic',
+                        use_tmp=False, src_descriptor=src,
+                        dst_descriptor=dst)
+    remapper.build_map()
+    assert os.path.exists(remapper.map_filename)
+    out_filename = str(tmp_path / 'out.nc')
+    remapper.ncremap(in_filename=in_filename, out_filename=out_filename,
+                     replace_mpas_fill=True)
+    ds_file = open_dataset(out_filename)
+    ds_mem = remapper.remap_numpy(open_dataset(in_filename), 0.01)
+    ds_ref = open_dataset(ref_filename)
+    for ds in (ds_file, ds_mem):
+        # assertDimsEqual of the reference's tests/__init__.py
+        for name in ds_ref.data_vars:
+            assert name in ds.variables, name
+            assert ds[name].dims == ds_ref[name].dims, name
+            assert ds[name].shape == ds_ref[name].shape, name
+        np.testing.assert_array_equal(ds['lat'].values, ds_ref['lat'].values)
+        np.testing.assert_array_equal(ds['lon'].values, ds_ref['lon'].values)
+        for name in ('date', 'datesec', 'date_frac'):
+            np.testing.assert_array_equal(ds[name].values,
+                                          ds_ref[name].values)
+            assert ds[name].dtype == ds_ref[name].dtype
+        sst, want = ds['SST'].values, ds_ref['SST'].values
+        assert sst.dtype == np.float64 == want.dtype    # f32 in, f64 out
+        assert np.array_equal(np.isnan(sst), np.isnan(want))
+        assert np.abs(sst - want).max() < 1e-2
+        assert np.abs(sst - want).mean() < 1e-3
+        assert ds['SST'].attrs['units'] == ds_ref['SST'].attrs['units']
+        assert ds.attrs['title'] == ds_ref.attrs['title']
+    # the two paths of this package agree with each other exactly
+    assert_bitwise(ds_file['SST'].values, ds_mem['SST'].values,
+                   'ncremap vs remap_numpy')
+
+
+@pytest.mark.parametrize('kind', ['mpas_cell', 'point_collection'])
+def test_reference_fixture_latlon_to_points(tmp_path, kind):
+    """
+    The reference's ``test_latlon_to_mpas_cell`` and
+    ``test_latlon_file_to_point_collection`` (tests/test_interpolate.py)
+    replayed: the 1 deg SST file -> the 7153 QU240 cell centres (taken from
+    the stored outputs, which carry them as coordinates), bilinear.  SST
+    agrees with what the reference stored (ESMF weights) to 5e-3 K; dims,
+    coordinates and pass-through variables exactly.
+    """
+    from pyremap_amd import (
+        LatLonGridDescriptor,
+        MpasCellMeshDescriptor,
+        PointCollectionDescriptor,
+        Remapper,
+    )
+    from pyremap_amd.io.netcdf import open_dataset
+    gold = os.path.join(os.path.dirname(__file__), 'golden')
+    in_filename = os.path.join(gold, 'ref_fixtures',
+                               'SST_annual_1870-1900.nc')
+    if kind == 'mpas_cell':
+        ds_ref = open_dataset(os.path.join(
+            gold, 'hdf5', 'nc4_ref_latlon_to_mpas_cell.nc'))
+        dst = MpasCellMeshDescriptor(mesh_name='oQU240',
+                                     lat=ds_ref['lat_cell'].values,
+                                     lon=ds_ref['lon_cell'].values)
+        dim, coords = 'nCells', ('lat_cell', 'lon_cell')
+    else:
+        ds_ref = open_dataset(os.path.join(
+            gold, 'ref_fixtures', 'ref_latlon_file_to_point_collection.nc'))
+        dst = PointCollectionDescriptor(ds_ref['lat'].values,
+                                        ds_ref['lon'].values,
+                                        collection_name='mpas_cells',
+                                        units='degrees',
+                                        out_dimension='n_points')
+        dim, coords = 'n_points', ('lat', 'lon')
+    src = LatLonGridDescriptor.read(in_filename)
+    remapper = Remapper(map_filename=str(tmp_path / f'map_{kind}.nc'),
+                        method='bilinear', map_tool='analytic',
+                        src_descriptor=src, dst_descriptor=dst)
+    remapper.build_map()
+    out = remapper.remap_numpy(open_dataset(in_filename), 0.01)
+    assert out['SST'].dims == ('time', dim) == ds_ref['SST'].dims
+    assert out['SST'].shape == ds_ref['SST'].shape == (1, 7153)
+    assert out['SST'].dtype == np.float64
+    for c in coords:
+        np.testing.assert_array_equal(out[c].values, ds_ref[c].values)
+        assert out[c].dims == (dim,)
+    want = np.asarray(ds_ref['SST'].values, dtype=np.float64)
+    got = out['SST'].values
+    assert not np.isnan(got).any()
+    assert np.abs(got - want).max() < 1e-2
+    assert np.abs(got - want).mean() < 1e-3
+    for name in ('date', 'datesec', 'date_frac'):
+        np.testing.assert_array_equal(out[name].values, ds_ref[name].values)
+    # file -> file gives the same numbers
+    out_filename = str(tmp_path / f'out_{kind}.nc')
+    remapper.ncremap(in_filename, out_filename)
+    assert_bitwise(open_dataset(out_filename)['SST'].values, got,
+                   'ncremap vs remap_numpy')
+    # a point collection cannot be the SOURCE of ncremap (ncremap.py:20-23)
+    if kind == 'point_collection':
+        back = Remapper(map_filename=remapper.map_filename,
+                        src_descriptor=dst, dst_descriptor=src)
+        with pytest.raises(TypeError, match='point collection'):
+            back.ncremap(in_filename, str(tmp_path / 'never.nc'))

@@ -182,3 +182,37 @@ def test_write_weights_round_trip(tmp_path):
     assert (back.n_a, back.n_b) == (m.n_a, m.n_b)
     # Fortran order in the file: [nlon, nlat]
     assert list(back.src_grid_dims) == [len(src.lon), len(src.lat)]
+
+
+def test_lat_lon_to_points():
+    from pyremap_amd import MpasCellMeshDescriptor, PointCollectionDescriptor
+    src = get_lat_lon_descriptor(5.0, 5.0)
+    rng = np.random.default_rng(4)
+    lat = np.degrees(np.arcsin(rng.uniform(-0.99, 0.99, 300)))
+    lon = rng.uniform(-180.0, 180.0, 300)
+    pts = PointCollectionDescriptor(lat, lon, 'pts', units='degrees')
+    cells = MpasCellMeshDescriptor(mesh_name='m', lat=np.radians(lat),
+                                   lon=np.radians(lon) % (2 * np.pi))
+    f = lambda la, lo: 1.0 + 0.05 * la + np.cos(np.radians(lo))
+    lat_s, lon_s = np.meshgrid(src.lat, src.lon, indexing='ij')
+    for dst in (pts, cells):
+        m = build_weights(src, dst, 'bilinear')
+        assert list(m.dst_grid_dims) == [300] and m.n_b == 300
+        A = _dense(m)
+        assert np.allclose(A.sum(axis=1), 1.0)
+        assert np.bincount(m.row - 1).max() <= 4
+        got = A @ f(lat_s, lon_s).reshape(-1)
+        inner = np.abs(lat) < 87.0
+        assert np.abs(got - f(lat, lon))[inner].max() < 2e-3
+        near = build_weights(src, dst, 'neareststod')
+        assert near.n_s == 300 and np.all(near.S == 1.0)
+        iy, ix = np.divmod(near.col - 1, len(src.lon))
+        assert np.abs(src.lat[iy] - lat).max() <= 2.5 + 1e-9
+        dlon = np.abs((src.lon[ix] - lon + 180.0) % 360.0 - 180.0)
+        assert dlon.max() <= 2.5 + 1e-9
+    # both descriptors describe the same points: same weights
+    a = build_weights(src, pts, 'bilinear')
+    b = build_weights(src, cells, 'bilinear')
+    assert np.array_equal(a.col, b.col) and np.allclose(a.S, b.S, atol=1e-12)
+    with pytest.raises(ValueError, match='conserve needs cells'):
+        build_weights(src, pts, 'conserve')
