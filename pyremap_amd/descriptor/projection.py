@@ -80,7 +80,9 @@ class PolarStereographic:
         lam = np.arctan2(xn, -yn)
         lon = self.lon_0 + sign * np.degrees(lam)
         lon = np.where(rho == 0.0, self.lon_0, lon)
+        # (-180, 180], the range pyproj reports
         lon = (lon + 180.0) % 360.0 - 180.0
+        lon = np.where(lon == -180.0, 180.0, lon)
         lat = sign * np.degrees(phi)
         return lon, lat
 

@@ -188,22 +188,40 @@ def _points(descriptor):
     return None
 
 
-def _to_points(src_descriptor, dst_descriptor, method):
-    """Lat-lon grid -> scattered points (MPAS cell centres, point
-    collections): the same per-axis interpolation, one (y, x) pair per
-    destination point instead of a tensor product."""
+def _forward(projection, lon_deg, lat_deg):
+    """(x, y) of points given in degrees, through this package's projection
+    class or a ``pyproj.Proj`` (which is callable that way)."""
+    if hasattr(projection, 'forward'):
+        return projection.forward(lon_deg, lat_deg)
+    return projection(lon_deg, lat_deg)
+
+
+def _to_points(src_descriptor, plat, plon, dst_dims, method):
+    """
+    Rectangular grid -> points given by latitude / longitude in radians (MPAS
+    cell centres, point collections, or the cell centres of a grid of another
+    kind): the per-axis interpolation of the tensor case, one (y, x) pair per
+    destination point.  Points outside the hull of the source cell centres
+    (bilinear; outside the source cells for neareststod) are not mapped.
+    """
     if method == 'conserve':
         raise ValueError(
-            'method conserve needs cells, not points, as the destination '
-            '(as in the reference, setup.py:50-55)')
+            'method conserve needs cells of the same kind of grid on both '
+            'sides; towards points or across grid kinds only bilinear and '
+            'neareststod have a closed form')
     sy, sx, sye, sxe, period, kind = _axes(src_descriptor)
-    if kind != 'sphere':
-        raise TypeError('point destinations need a lat-lon source grid')
-    plat, plon = _points(dst_descriptor)
+    if kind == 'sphere':
+        py, px = plat, plon
+    else:
+        if src_descriptor.projection is None:
+            raise ValueError('the source grid has no projection to locate '
+                             'the destination points with')
+        px, py = _forward(src_descriptor.projection, np.degrees(plon),
+                          np.degrees(plat))
     axis = linear_1d if method == 'bilinear' else nearest_1d
-    n = len(plat)
-    jy, iy, wy = axis(sy, plat)
-    jx, ix, wx = axis(sx, plon, period)
+    n = len(py)
+    jy, iy, wy = axis(sy, py)
+    jx, ix, wx = axis(sx, px, period)
     # pair every y entry of a point with every x entry of the same point
     oy = np.argsort(jy, kind='stable')
     ox = np.argsort(jx, kind='stable')
@@ -221,42 +239,73 @@ def _to_points(src_descriptor, dst_descriptor, method):
     row = point
     col = iy[ky] * len(sx) + ix[kx]
     S = wy[ky] * wx[kx]
-    frac_b = np.ones(n)
+    # what counts as "inside": between the outermost centres for bilinear
+    # (ESMF maps a point only if four source centres surround it), inside
+    # the outermost cells for nearest; a global lat-lon source has no
+    # longitude limits and its latitude rows reach the poles
+    if method == 'bilinear':
+        ylim, xlim = (sy[0], sy[-1]), (sx[0], sx[-1])
+    else:
+        ylim, xlim = (sye[0], sye[-1]), (sxe[0], sxe[-1])
+    inside = np.ones(n, dtype=bool)
     if period is None:
-        inside = (plat >= min(sye[0], sye[-1])) & \
-            (plat <= max(sye[0], sye[-1])) & \
-            (plon >= min(sxe[0], sxe[-1])) & (plon <= max(sxe[0], sxe[-1]))
-        keep = inside[row]
-        row, col, S = row[keep], col[keep], S[keep]
-        frac_b = inside.astype(np.float64)
+        inside &= (px >= min(xlim)) & (px <= max(xlim))
+    if period is None or kind == 'plane':
+        inside &= (py >= min(ylim)) & (py <= max(ylim))
+    keep = inside[row]
+    row, col, S = row[keep], col[keep], S[keep]
+    frac_b = inside.astype(np.float64)
     order = np.lexsort((col, row))
     return MappingFile(
         len(sy) * len(sx), n, np.array([len(sx), len(sy)], dtype=np.int32),
-        np.array([n], dtype=np.int32), (row[order] + 1).astype(np.int32),
-        (col[order] + 1).astype(np.int32), S[order], frac_b)
+        np.asarray(dst_dims, dtype=np.int32),
+        (row[order] + 1).astype(np.int32), (col[order] + 1).astype(np.int32),
+        S[order], frac_b)
+
+
+def _cell_centres(descriptor):
+    """(lat, lon) in radians of every cell centre of a rectangular grid, in
+    C order, and its Fortran-ordered dims."""
+    if isinstance(descriptor, LatLonGridDescriptor):
+        scale = 1.0 if 'rad' in descriptor.units else np.pi / 180.0
+        lat, lon = np.meshgrid(np.asarray(descriptor.lat) * scale,
+                               np.asarray(descriptor.lon) * scale,
+                               indexing='ij')
+    else:
+        xx, yy = np.meshgrid(descriptor.x, descriptor.y)
+        lat, lon = descriptor.project_to_lat_lon(xx, yy)
+        if lat is None:
+            raise ValueError('the destination grid has no usable projection')
+        lat, lon = np.radians(lat), np.radians(lon)
+    return lat.reshape(-1), lon.reshape(-1), \
+        [lat.shape[1], lat.shape[0]]
 
 
 def build_weights(src_descriptor, dst_descriptor, method='conserve'):
     """
-    The mapping between two rectangular grids of the same kind (both lat-lon,
-    or both on the same map projection), or from a lat-lon grid to scattered
-    points (an MPAS mesh's cell / edge / vertex positions, a point
-    collection), as a :class:`MappingFile`.
+    The mapping between two rectangular grids (lat-lon or on a map
+    projection; ``conserve`` only between grids of the same kind), or from
+    one to scattered points (an MPAS mesh's cell / edge / vertex positions,
+    a point collection), as a :class:`MappingFile`.
     """
     if method not in METHODS:
         raise ValueError(f'method {method!r}: expected one of {METHODS}')
-    if _points(dst_descriptor) is not None:
-        return _to_points(src_descriptor, dst_descriptor, method)
+    points = _points(dst_descriptor)
+    if points is not None:
+        return _to_points(src_descriptor, points[0], points[1],
+                          [len(points[0])], method)
     sy, sx, sye, sxe, period, kind = _axes(src_descriptor)
     dy, dx, dye, dxe, _, dkind = _axes(dst_descriptor)
-    if kind != dkind:
-        raise TypeError('source and destination must both be lat-lon grids '
-                        'or both be grids of one projection')
-    if kind == 'plane':
+    same_kind = kind == dkind
+    if same_kind and kind == 'plane':
         ps, pd = src_descriptor.projection, dst_descriptor.projection
-        if ps is not pd and getattr(ps, 'srs', ps) != getattr(pd, 'srs', pd):
-            raise ValueError('source and destination grids are on different '
-                             'projections')
+        same_kind = ps is pd or \
+            getattr(ps, 'srs', ps) == getattr(pd, 'srs', pd)
+    if not same_kind:
+        # across grid kinds (projection <-> lat-lon, two projections): the
+        # destination cell centres are points for the source grid
+        lat, lon, dims = _cell_centres(dst_descriptor)
+        return _to_points(src_descriptor, lat, lon, dims, method)
     ny_s, nx_s, ny_d, nx_d = len(sy), len(sx), len(dy), len(dx)
     if method == 'conserve':
         if kind == 'sphere':
@@ -275,11 +324,18 @@ def build_weights(src_descriptor, dst_descriptor, method='conserve'):
                               ny_d, nx_d)
         frac_b = np.ones(ny_d * nx_d)
         if period is None:
-            # destination points outside the source box are not mapped
-            inside_y = (dy >= min(sye[0], sye[-1])) & \
-                (dy <= max(sye[0], sye[-1]))
-            inside_x = (dx >= min(sxe[0], sxe[-1])) & \
-                (dx <= max(sxe[0], sxe[-1]))
+            # destination points outside the source box are not mapped:
+            # outside the hull of the centres for bilinear (ESMF's rule),
+            # outside the cells for nearest
+            ylim, xlim = ((sy[0], sy[-1]), (sx[0], sx[-1])) \
+                if method == 'bilinear' else \
+                ((sye[0], sye[-1]), (sxe[0], sxe[-1]))
+            inside_y = (dy >= min(ylim)) & (dy <= max(ylim))
+            if kind == 'sphere':
+                # latitude rows reach the poles: nothing is outside
+                inside_y = (dy >= min(sye[0], sye[-1])) & \
+                    (dy <= max(sye[0], sye[-1]))
+            inside_x = (dx >= min(xlim)) & (dx <= max(xlim))
             inside = (inside_y[:, None] & inside_x[None, :]).reshape(-1)
             keep = inside[row]
             row, col, S = row[keep], col[keep], S[keep]

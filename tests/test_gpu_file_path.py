@@ -380,3 +380,105 @@ def test_reference_fixture_latlon_to_points(tmp_path, kind):
                         src_descriptor=dst, dst_descriptor=src)
         with pytest.raises(TypeError, match='point collection'):
             back.ncremap(in_filename, str(tmp_path / 'never.nc'))
+
+
+def test_reference_fixture_stereographic_to_latlon():
+    """
+    The reference's ``test_stereographic_array_to_latlon_array``
+    (tests/test_interpolate.py:576-621) replayed: the latitude of a 100 km
+    Antarctic stereographic grid, as a ``(dim0, y, x, dim3)`` field, remapped
+    to a 2 deg lat-lon grid (a two-axis source in the middle of a 4-D array).
+    The stored reference output pins (i) this package's polar stereographic
+    projection against pyproj, (ii) which destination cells are mapped at all
+    -- the NaN pattern is IDENTICAL, 13 720 of 16 200 cells -- and (iii) the
+    values to 1e-3 degrees (ESMF bilinear vs bilinear in x-y).
+    """
+    from pyremap_amd import (
+        DataArray,
+        Dataset,
+        LatLonGridDescriptor,
+        ProjectionGridDescriptor,
+        Remapper,
+    )
+    from pyremap_amd.io.netcdf import open_dataset
+    from pyremap_amd.polar import get_antarctic_stereographic_projection
+    here = os.path.join(os.path.dirname(__file__), 'golden', 'ref_fixtures')
+    ds_ref = open_dataset(os.path.join(here, 'ref_stereographic_to_latlon.nc'))
+    x_max, y_max, res = 3000e3, 2500e3, 100e3
+    nx = 2 * int(x_max / res) + 1
+    ny = 2 * int(y_max / res) + 1
+    src = ProjectionGridDescriptor.create(
+        get_antarctic_stereographic_projection(),
+        np.linspace(-x_max, x_max, nx), np.linspace(-y_max, y_max, ny),
+        f'{int(res * 1e-3)}km_Antarctic_stereo')
+    dst = LatLonGridDescriptor.create(np.linspace(-90.0, 90.0, 91),
+                                      np.linspace(-180.0, 180.0, 181),
+                                      units='degrees')
+    lat2d = src.coords['lat']['data']
+    in_field = np.reshape(lat2d, (1, ny, nx, 1)).repeat(3, axis=0).repeat(
+        2, axis=3)
+    ds = Dataset()
+    ds['complicated'] = DataArray(in_field, dims=('dim0', 'y', 'x', 'dim3'))
+    remapper = Remapper(method='bilinear', map_tool='analytic',
+                        map_filename='<memory>', src_descriptor=src,
+                        dst_descriptor=dst)
+    from pyremap_amd.weights import build_weights
+    m = build_weights(src, dst, 'bilinear')
+    remapper = Remapper.from_triplets(m.row, m.col, m.S, m.frac_b, src, dst)
+    out = remapper.remap_numpy(ds, 0.01)
+    got = out['complicated'].values
+    want = ds_ref['complicated'].values
+    assert out['complicated'].dims == ds_ref['complicated'].dims == \
+        ('dim0', 'lat', 'lon', 'dim3')
+    assert got.shape == want.shape == (3, 90, 180, 2)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.isnan(want).sum() == 13720 * 6
+    ok = ~np.isnan(want)
+    assert np.abs(got - want)[ok].max() < 1e-3
+    np.testing.assert_array_equal(out['lat'].values, ds_ref['lat'].values)
+    np.testing.assert_array_equal(out['lon'].values, ds_ref['lon'].values)
+    # all dim0 slices and both dim3 slices are the same remap
+    assert_bitwise(got[0], got[2], 'dim0 slices')
+    assert_bitwise(got[..., 0], got[..., 1], 'dim3 slices')
+
+
+def test_reference_fixture_latlon_to_stereographic(tmp_path):
+    """
+    The reference's ``test_latlon_to_stereographic``
+    (tests/test_interpolate.py:547-574) replayed: the SST file -> the
+    stereographic grid.  The stored output also carries pyproj's latitudes
+    and longitudes of that grid: ours agree to 1e-11 degrees.
+    """
+    from pyremap_amd import LatLonGridDescriptor, Remapper
+    from pyremap_amd import get_polar_descriptor
+    from pyremap_amd.io.netcdf import open_dataset
+    here = os.path.join(os.path.dirname(__file__), 'golden', 'ref_fixtures')
+    in_filename = os.path.join(here, 'SST_annual_1870-1900.nc')
+    ds_ref = open_dataset(os.path.join(here, 'ref_latlon_to_stereographic.nc'))
+    src = LatLonGridDescriptor.read(in_filename)
+    dst = get_polar_descriptor(6000.0, 5000.0, 100.0, 100.0)
+    assert np.abs(dst.coords['lat']['data'] -
+                  ds_ref['lat'].values).max() < 1e-11
+    assert np.abs(dst.coords['lon']['data'] -
+                  ds_ref['lon'].values).max() < 1e-11
+    remapper = Remapper(map_filename=str(tmp_path / 'map.nc'),
+                        method='bilinear', map_tool='analytic',
+                        src_descriptor=src, dst_descriptor=dst)
+    remapper.build_map()
+    out_filename = str(tmp_path / 'out.nc')
+    remapper.ncremap(in_filename, out_filename)
+    ds_file = open_dataset(out_filename)
+    ds_mem = remapper.remap_numpy(open_dataset(in_filename), 0.01)
+    want = np.asarray(ds_ref['SST'].values, dtype=np.float64)
+    for ds in (ds_file, ds_mem):
+        assert ds['SST'].dims == ('time', 'y', 'x') == ds_ref['SST'].dims
+        got = ds['SST'].values
+        assert got.shape == want.shape == (1, 51, 61)
+        assert not np.isnan(got).any()
+        assert np.abs(got - want).max() < 5e-3
+        for name in ('date', 'datesec', 'date_frac'):
+            np.testing.assert_array_equal(ds[name].values,
+                                          ds_ref[name].values)
+        np.testing.assert_array_equal(ds['x'].values, dst.x)
+    assert_bitwise(ds_file['SST'].values, ds_mem['SST'].values,
+                   'ncremap vs remap_numpy')

@@ -164,7 +164,7 @@ def test_nearest_and_projection_grids():
             assert np.allclose(got, (1.0 + 2e-5 * xd - 1e-5 * yd).reshape(-1))
         if method == 'neareststod':
             assert np.bincount(m.row - 1, minlength=m.n_b).max() == 1
-    with pytest.raises(TypeError, match='both be lat-lon'):
+    with pytest.raises(ValueError, match='conserve needs cells'):
         build_weights(src, get_lat_lon_descriptor(10.0, 10.0))
     with pytest.raises(ValueError, match='expected one of'):
         build_weights(src, dst, 'patch')
@@ -216,3 +216,37 @@ def test_lat_lon_to_points():
     assert np.array_equal(a.col, b.col) and np.allclose(a.S, b.S, atol=1e-12)
     with pytest.raises(ValueError, match='conserve needs cells'):
         build_weights(src, pts, 'conserve')
+
+
+def test_projection_grid_to_lat_lon_and_back():
+    """Across grid kinds the destination cell centres are located in the
+    source grid through the projection (the reference's
+    test_stereographic_array_to_latlon_array / test_latlon_to_stereographic
+    pairs): latitude, a smooth field of position, survives the trip."""
+    stereo = get_polar_descriptor(6000.0, 5000.0, 100.0, 100.0)
+    latlon = get_lat_lon_descriptor(2.0, 2.0)
+    m = build_weights(stereo, latlon, 'bilinear')
+    assert list(m.src_grid_dims) == [61, 51]
+    assert list(m.dst_grid_dims) == [len(latlon.lon), len(latlon.lat)]
+    A = _dense(m)
+    mapped = m.frac_b > 0
+    assert np.allclose(A.sum(axis=1)[mapped], 1.0)
+    assert np.all(A.sum(axis=1)[~mapped] == 0.0)
+    lat_src = stereo.coords['lat']['data'].reshape(-1)
+    lat_dst = np.repeat(latlon.lat, len(latlon.lon))
+    got = A @ lat_src
+    assert 0.10 < mapped.mean() < 0.20          # the Antarctic cap only
+    assert lat_dst[mapped].max() < -55.0
+    assert np.abs(got - lat_dst)[mapped].max() < 0.12
+    # and back: lat-lon -> stereographic (global source: every point mapped)
+    back = build_weights(latlon, stereo, 'bilinear')
+    assert np.all(back.frac_b == 1.0)
+    B = _dense(back)
+    lat_ll = np.repeat(latlon.lat, len(latlon.lon))
+    # linear in latitude: exact, except poleward of the last row of centres
+    # (the pole itself sits in this grid), which takes that row's value
+    err = np.abs(B @ lat_ll - lat_src)
+    assert err[lat_src >= -89.0].max() < 1e-9
+    assert err.max() <= 1.0
+    with pytest.raises(ValueError, match='conserve needs cells'):
+        build_weights(stereo, latlon, 'conserve')
