@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define REMAP_ABI_VERSION 8
+#define REMAP_ABI_VERSION 9
 
 enum {
     REMAP_OK = 0,
@@ -69,8 +69,8 @@ enum {
      * multiply and add in CSR order, which is bit-identical to scipy's
      * csr_matvecs; FMA is within 1 ulp per term of it, not identical. */
     REMAP_FLAG_FMA = 1u << 0,
-    /* plain (cached) stores for Y instead of non-temporal ones */
-    REMAP_FLAG_CACHED_STORE = 1u << 1,
+    /* bit 1 is unused (it once asked for write-back instead of non-temporal
+     * stores of Y; non-temporal measured faster on every configuration) */
     /* `tune` is a preference, not a demand: if the requested kernel family
      * cannot serve this call (K <= 32, odd strides, a partial row range, a
      * missing schedule ...) choose automatically instead of failing */

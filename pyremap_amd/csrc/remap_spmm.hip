@@ -115,24 +115,23 @@ __device__ __forceinline__ double elem(const V &v, int e)
     }
 }
 
+// Y is written once and never read back: non-temporal stores (+3..5 % on
+// configs 3 and H against write-back ones, A/B in one run).  There is
+// deliberately no run-time switch to plain stores here: with `if (cached)
+// plain else nontemporal` on the same address LLVM merges the two stores and
+// silently drops the non-temporal hint -- the first builds of this file held
+// 414 plain stores and not a single `nt`.
 template <int VEC>
-__device__ __forceinline__ void store_y(double *p, const double (&y)[VEC],
-                                        bool cached)
+__device__ __forceinline__ void store_y(double *p, const double (&y)[VEC])
 {
     if constexpr (VEC == 1) {
-        if (cached)
-            *p = y[0];
-        else
-            __builtin_nontemporal_store(y[0], p);
+        __builtin_nontemporal_store(y[0], p);
     } else {
         typedef double d2 __attribute__((ext_vector_type(2)));
         d2 v;
         v[0] = y[0];
         v[1] = y[1];
-        if (cached)
-            *reinterpret_cast<d2 *>(p) = v;
-        else
-            __builtin_nontemporal_store(v, reinterpret_cast<d2 *>(p));
+        __builtin_nontemporal_store(v, reinterpret_cast<d2 *>(p));
     }
 }
 
@@ -194,7 +193,7 @@ template <int VEC, int TILES, int MODE>
 __device__ __forceinline__ void finish_row(
     const KParams &p, int64_t i, double fb, const bool (&act)[TILES],
     const int64_t (&yoff)[TILES], const double (&acc)[TILES][VEC],
-    const double (&den)[TILES][VEC], bool cached)
+    const double (&den)[TILES][VEC])
 {
 #pragma unroll
     for (int t = 0; t < TILES; ++t) {
@@ -221,7 +220,7 @@ __device__ __forceinline__ void finish_row(
         const int64_t o = i * p.ldy + yoff[t];
         if ((p.debug & 1) && y[0] != 1.2345e300)
             continue;
-        store_y<VEC>(p.Y + o, y, cached);
+        store_y<VEC>(p.Y + o, y);
 #ifndef REMAP_STAMPS
         if (p.mask_out) {
 #pragma unroll
@@ -295,7 +294,6 @@ __global__ __launch_bounds__(kBlock) void spmm_rowwave(const KParams p,
     tile_offsets<VEC, TILES>(p, chunk, lane, xoff, yoff, act);
 
     const XT *__restrict__ X = static_cast<const XT *>(p.X);
-    const bool cached = (flags & REMAP_FLAG_CACHED_STORE) != 0;
     const int64_t block_row0 =
         p.row_begin + rb * (int64_t)(kWavesPerBlock * p.rows_per_wave);
 
@@ -335,7 +333,7 @@ __global__ __launch_bounds__(kBlock) void spmm_rowwave(const KParams p,
         double fb = 0.0;
         if constexpr (MODE == REMAP_MODE_FRACB)
             fb = p.frac_b[i];
-        finish_row<VEC, TILES, MODE>(p, i, fb, act, yoff, acc, den, cached);
+        finish_row<VEC, TILES, MODE>(p, i, fb, act, yoff, acc, den);
     }
 }
 
@@ -514,7 +512,6 @@ __global__ __launch_bounds__(kPatchBlock) void spmm_patch(
     __syncthreads();
 
     // 3. compute the patch's rows from LDS
-    const bool cached = (flags & REMAP_FLAG_CACHED_STORE) != 0;
     const char *mine = lds + lane * (VEC * 8);
     // the next row's header (id, entry range, frac_b) is read while this
     // row is being computed: short rows (4 entries of a bilinear map) are a
@@ -567,7 +564,7 @@ __global__ __launch_bounds__(kPatchBlock) void spmm_patch(
                 }
             }
         }
-        finish_row<VEC, 1, MODE>(p, i, fb_row, act, yoff, acc, den, cached);
+        finish_row<VEC, 1, MODE>(p, i, fb_row, act, yoff, acc, den);
     }
 }
 
@@ -691,7 +688,6 @@ __global__ __launch_bounds__(kBlock) void spmm_rowscalar(
 #pragma unroll
     for (int t = 0; t < TILES; ++t)
         xo[t] = static_cast<uint32_t>(xoff[t] * sizeof(XT));
-    const bool cached = (flags & REMAP_FLAG_CACHED_STORE) != 0;
     const int64_t block_row0 =
         p.row_begin + rb * (int64_t)(kWavesPerBlock * p.rows_per_wave);
     REMAP_STAMP_INIT();
@@ -767,7 +763,7 @@ __global__ __launch_bounds__(kBlock) void spmm_rowscalar(
         double fb = 0.0;
         if constexpr (MODE == REMAP_MODE_FRACB)
             fb = frac_b[i];
-        finish_row<VEC, TILES, MODE>(p, i, fb, act, yoff, acc, den, cached);
+        finish_row<VEC, TILES, MODE>(p, i, fb, act, yoff, acc, den);
         REMAP_STAMP(4);  // accumulated, divided, stores issued
     }
     REMAP_STAMP_FLUSH();
@@ -815,7 +811,6 @@ __global__ __launch_bounds__(kBlock) void spmm_rowgroup(
 #pragma unroll
     for (int t = 0; t < TILES; ++t)
         xo[t] = static_cast<uint32_t>(xoff[t] * sizeof(XT));
-    const bool cached = (flags & REMAP_FLAG_CACHED_STORE) != 0;
     const int64_t n_groups_here =
         (p.row_end - p.row_begin + kGroup - 1) / kGroup;
     const int64_t block_g0 = rb * (int64_t)(kWavesPerBlock * p.rows_per_wave);
@@ -913,7 +908,7 @@ __global__ __launch_bounds__(kBlock) void spmm_rowgroup(
                 if constexpr (MODE == REMAP_MODE_FRACB)
                     fb = readlane_f64(my_fb, m);
                 finish_row<VEC, TILES, MODE>(p, i, fb, act, yoff, acc[m],
-                                             den[m], cached);
+                                             den[m]);
             }
         }
     }
@@ -963,10 +958,8 @@ __global__ __launch_bounds__(kBlock) void spmm_rowlane(const KParams p,
         y = ok ? acc / den : __builtin_nan("");
     }
     const int64_t o = i * p.ldy + (int64_t)b * p.bsy + k;
-    if (flags & REMAP_FLAG_CACHED_STORE)
-        p.Y[o] = y;
-    else
-        __builtin_nontemporal_store(y, p.Y + o);
+    (void)flags;
+    __builtin_nontemporal_store(y, p.Y + o);
     if (p.mask_out)
         p.mask_out[o] = ok ? 0 : 1;
 }

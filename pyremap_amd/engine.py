@@ -27,13 +27,12 @@ MODE_FRACB = 1
 MODE_MASKED = 2
 
 FLAG_FMA = 1
-FLAG_CACHED_STORE = 2
 FLAG_TUNE_HINT = 4
 
 DTYPE_F64 = 0
 DTYPE_F32 = 1
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 #: readable pad entries kept behind col/val (remap_csr.csr_pad)
 CSR_PAD = 8
