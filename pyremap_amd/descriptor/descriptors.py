@@ -62,6 +62,16 @@ class MeshDescriptor:
             'SCRIP files feed ESMF/MOAB weight generation, which is outside '
             'the scope of pyremap_amd (it applies existing weights)')
 
+    def write_netcdf(self, ds, filename):
+        """``mesh_descriptor.py:93-112``: write ``ds`` in this descriptor's
+        ``format`` (NetCDF-4 is not writable here: the widest classic format
+        is used instead)."""
+        from pyremap_amd.utility import write_netcdf
+        fmt = self.format if self.format.startswith('NETCDF3') else \
+            'NETCDF3_64BIT_DATA'
+        write_netcdf(ds, filename, format=fmt, engine=self.engine,
+                     logger=self.logger)
+
     def mesh_name_from_attr(self, ds):
         """``mesh_descriptor.py:114-128``."""
         if self.mesh_name is None:

@@ -363,3 +363,48 @@ def test_row_shard_bounds_balance():
         work = [int(rowptr[b[i + 1]] - rowptr[b[i]]) + 2 * (b[i + 1] - b[i])
                 for i in range(world)]
         assert max(work) <= 1.05 * sum(work) / world + 20
+
+
+def test_utility_write_netcdf_fill_value_rules(tmp_path):
+    """``pyremap.utility.write_netcdf`` (utility.py:8-72): a _FillValue only
+    where a numeric variable really holds NaNs; custom fill values by type."""
+    import numpy as np
+
+    import pyremap_amd
+    from pyremap_amd import utility
+    from pyremap_amd.io import netcdf3
+    ds = pyremap_amd.Dataset()
+    a = np.arange(12.0).reshape(3, 4)
+    b = a.copy()
+    b[1, 2] = np.nan
+    ds['clean'] = pyremap_amd.DataArray(a, dims=('y', 'x'))
+    ds['holes'] = pyremap_amd.DataArray(b, dims=('y', 'x'))
+    ds['holes32'] = pyremap_amd.DataArray(b.astype(np.float32),
+                                          dims=('y', 'x'))
+    ds['count'] = pyremap_amd.DataArray(np.arange(3, dtype=np.int32),
+                                        dims=('y',))
+    path = str(tmp_path / 'out.nc')
+    utility.write_netcdf(ds, path, format='NETCDF3_64BIT_DATA')
+    nc = netcdf3.read(path)
+    assert '_FillValue' not in nc.variables['clean'].attrs
+    assert '_FillValue' not in nc.variables['count'].attrs
+    assert nc.variables['holes'].attrs['_FillValue'] == \
+        9.969209968386869e+36
+    assert nc.variables['holes'].data[1, 2] == 9.969209968386869e+36
+    assert nc.variables['holes32'].data.dtype.kind == 'f'
+    back = pyremap_amd.io.netcdf.open_dataset(path)
+    assert np.isnan(back['holes'].values[1, 2])
+    np.testing.assert_array_equal(back['clean'].values, a)
+    utility.write_netcdf(ds, path, format='NETCDF3_64BIT',
+                         fillvalues={'f8': -1e30, 'f4': -1e30})
+    nc = netcdf3.read(path)
+    assert nc.variables['holes'].attrs['_FillValue'] == -1e30
+    import pytest
+    with pytest.raises(NotImplementedError, match='classic formats'):
+        utility.write_netcdf(ds, path, format='NETCDF4')
+    # the descriptor method of the same name
+    d = pyremap_amd.get_lat_lon_descriptor(30.0, 30.0)
+    d.format = 'NETCDF3_64BIT'
+    d.write_netcdf(ds, str(tmp_path / 'desc.nc'))
+    assert netcdf3.read(str(tmp_path / 'desc.nc')).variables['clean'] \
+        .data.shape == (3, 4)
