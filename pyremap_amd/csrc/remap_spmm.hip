@@ -1141,7 +1141,14 @@ int launch_rowgroup(const remap_apply_args *a, const KParams &p, int tiles,
     typename GroupFn<XT>::type fn =
         tiles == 1 ? pick_rowgroup_mode<XT, 1>(a->mode, fma)
                    : pick_rowgroup_mode<XT, 2>(a->mode, fma);
-    hipLaunchKernelGGL(fn, dim3(static_cast<uint32_t>(grid)), dim3(kBlock), 0,
+    // tune[7]: KiB of (unused) dynamic LDS per block -- an occupancy throttle
+    const uint32_t lds_bytes = a->tune[7] > 0 ? a->tune[7] * 1024u : 0u;
+    if (lds_bytes > 64 * 1024)
+        REMAP_HIP_CHECK(hipFuncSetAttribute(
+            reinterpret_cast<const void *>(fn),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL(fn, dim3(static_cast<uint32_t>(grid)), dim3(kBlock),
+                       lds_bytes,
                        stream, p, a->flags, a->group_ptr, a->group_col,
                        a->group_w, a->group_mask, a->row_order, a->frac_b,
                        static_cast<const XT *>(a->X));
