@@ -1161,9 +1161,24 @@ bool aligned(const void *p, size_t a)
     return (reinterpret_cast<uintptr_t>(p) % a) == 0;
 }
 
-}  // namespace
+// ---------------------------------------------------------------------------
+// dispatch: validate -> describe the call -> pick a family -> shape the grid
+// ---------------------------------------------------------------------------
 
-int apply(const remap_apply_args *a, hipStream_t stream)
+// What the launch helpers need to know about one call.
+struct Call {
+    int64_t K;            // flat columns = n_batch * k_inner
+    int64_t n_rows;       // row_end - row_begin
+    bool fma;
+    bool f32;
+    bool can_vec2;        // two elements per lane: even strides, aligned bases
+    bool small_offsets;   // byte offsets inside a row fit 32 bits
+    bool patch_ok;        // a usable patch plan is attached
+    bool group_ok;        // a usable row-group schedule is attached
+};
+
+// Argument checks.  Returns REMAP_OK with c.K == 0 for an empty output.
+int check_args(const remap_apply_args *a, Call &c)
 {
     if (!a)
         return fail(REMAP_ERR_ARG, "remap_apply_f64: args is NULL");
@@ -1178,10 +1193,12 @@ int apply(const remap_apply_args *a, hipStream_t stream)
                     (long long)A.n_rows);
     if (a->n_batch < 0 || a->k_inner < 0)
         return fail(REMAP_ERR_ARG, "remap_apply_f64: negative batch size");
-    const int64_t K64 = a->n_batch * a->k_inner;
-    const int64_t n_rows = a->row_end - a->row_begin;
-    if (n_rows == 0 || K64 == 0)
+    c.K = a->n_batch * a->k_inner;
+    c.n_rows = a->row_end - a->row_begin;
+    if (c.n_rows == 0 || c.K == 0) {
+        c.K = 0;
         return REMAP_OK;  // empty output: nothing to launch
+    }
     if (!A.rowptr || !a->Y || (!a->X && A.n_cols > 0))
         return fail(REMAP_ERR_ARG, "remap_apply_f64: NULL device pointer");
     if (A.nnz > 0 && (!A.col || !A.val))
@@ -1195,19 +1212,35 @@ int apply(const remap_apply_args *a, hipStream_t stream)
     if (a->mode == REMAP_MODE_FRACB && !a->frac_b)
         return fail(REMAP_ERR_ARG,
                     "remap_apply_f64: REMAP_MODE_FRACB needs frac_b");
-    if (K64 >= (int64_t(1) << 31))
+    if (c.K >= (int64_t(1) << 31))
         return fail(REMAP_ERR_UNSUPPORTED,
                     "remap_apply_f64: K = %lld fields per call exceeds 2^31",
-                    (long long)K64);
+                    (long long)c.K);
+    c.fma = (a->flags & REMAP_FLAG_FMA) != 0;
+    c.f32 = a->x_dtype == REMAP_DTYPE_F32;
+    const size_t xelem = c.f32 ? 4 : 8;
+    c.can_vec2 =
+        (a->k_inner % 2 == 0) && (a->x_row_stride % 2 == 0) &&
+        (a->x_batch_stride % 2 == 0) && (a->y_row_stride % 2 == 0) &&
+        (a->y_batch_stride % 2 == 0) && aligned(a->X, 2 * xelem) &&
+        aligned(a->Y, 16);
+    // per-lane byte offset of the last flat column, from a row base
+    c.small_offsets =
+        ((a->n_batch - 1) * a->x_batch_stride + a->k_inner) *
+            (int64_t)xelem < (int64_t(1) << 31);
+    c.patch_ok = patch_usable(a, c.K, c.f32, c.can_vec2);
+    c.group_ok = a->group_ptr && a->group_col && a->group_w &&
+                 a->group_mask &&
+                 a->n_groups == (c.n_rows + kGroup - 1) / kGroup;
+    return REMAP_OK;
+}
 
-    const bool fma = (a->flags & REMAP_FLAG_FMA) != 0;
-    const bool f32 = a->x_dtype == REMAP_DTYPE_F32;
-    const size_t xelem = f32 ? 4 : 8;
-
+KParams base_params(const remap_apply_args *a, const Call &c)
+{
     KParams p;
-    p.rowptr = A.rowptr;
-    p.col = A.col;
-    p.val = A.val;
+    p.rowptr = a->A.rowptr;
+    p.col = a->A.col;
+    p.val = a->A.val;
     p.X = a->X;
     p.Y = a->Y;
     p.frac_b = a->frac_b;
@@ -1222,211 +1255,129 @@ int apply(const remap_apply_args *a, hipStream_t stream)
     p.ldy = a->y_row_stride;
     p.bsy = a->y_batch_stride;
     p.thr = a->threshold;
-    p.K = static_cast<uint32_t>(K64);
+    p.K = static_cast<uint32_t>(c.K);
     p.k_inner = static_cast<uint32_t>(a->k_inner);
+    p.n_rowblocks = p.n_blocks = p.blocks_per_xcd = 0;
+    p.rows_per_wave = 0;
+    p.xcd_map = 0;
+    return p;
+}
 
-    const bool can_vec2_all =
-        (a->k_inner % 2 == 0) && (p.ldx % 2 == 0) && (p.bsx % 2 == 0) &&
-        (p.ldy % 2 == 0) && (p.bsy % 2 == 0) &&
-        aligned(a->X, 2 * xelem) && aligned(a->Y, 16);
-    const bool patch_ok = patch_usable(a, K64, f32, can_vec2_all);
-    // per-lane element offset of the last flat column, from a row base
-    const bool small_offsets =
-        ((a->n_batch - 1) * p.bsx + a->k_inner) * (int64_t)xelem <
-        (int64_t(1) << 31);
-    // REMAP_FLAG_TUNE_HINT: a preferred family that cannot serve this call is
-    // dropped in favour of the automatic choice instead of failing
-    remap_apply_args relaxed;
-    if ((a->flags & REMAP_FLAG_TUNE_HINT) && a->tune[0] != 0) {
-        bool usable = K64 > 32;
-        if (a->tune[0] == 10)
-            usable = usable && a->group_ptr && a->group_col && a->group_w &&
-                     a->group_mask &&
-                     a->n_groups == (n_rows + kGroup - 1) / kGroup &&
-                     can_vec2_all && small_offsets;
-        else if (a->tune[0] == 5)
-            usable = usable && patch_ok;
-        else if (a->tune[0] == 6)
-            usable = usable && A.csr_pad >= 8 && small_offsets &&
-                     (a->tune[1] != 2 || can_vec2_all);
-        if (!usable) {
-            relaxed = *a;
-            for (int t = 0; t < 8; ++t)
-                relaxed.tune[t] = 0;
-            a = &relaxed;
-        }
+// REMAP_FLAG_TUNE_HINT: can the preferred family serve this call?
+bool hint_usable(const remap_apply_args *a, const Call &c)
+{
+    if (c.K <= 32)
+        return false;  // the lane-per-(row, k) kernel owns small K
+    switch (a->tune[0]) {
+    case 10:
+        return c.group_ok && c.can_vec2 && c.small_offsets;
+    case 5:
+        return c.patch_ok;
+    case 6:
+        return a->A.csr_pad >= 8 && c.small_offsets &&
+               (a->tune[1] != 2 || c.can_vec2);
+    default:
+        return true;
     }
-    int family = a->tune[0];
-    if (family == 0) {
-        // measured on config 3: scalar-cache metadata
-        // beats the plain wave-per-row kernel by ~10 %.  The LDS patch family
-        // wins when source rows are heavily shared (2.2x on config 4) and
-        // ties otherwise: the host attaches a patch plan only in the first
-        // case (RemapPlan.auto_schedule), so its presence decides.
-        family = (K64 <= 32) ? 2
-                 : (patch_ok && K64 >= 64) ? 5
-                 : (A.csr_pad >= 8 ? 6 : 1);
-    }
-    if (family == 10) {
-        const bool group_ok =
-            a->group_ptr && a->group_col && a->group_w && a->group_mask &&
-            a->n_groups == (n_rows + kGroup - 1) / kGroup;
-        if (!group_ok || !can_vec2_all || !small_offsets)
-            return fail(REMAP_ERR_ARG,
-                        "remap_apply_f64: the rowgroup kernel needs the "
-                        "row-group schedule for [row_begin, row_end), even "
-                        "strides and 32-bit offsets");
-        // f32 rows are half as long: two K tiles per wave keep the bytes per
-        // wave and row at 1 KiB (measured +7 % on config 3 with f32 fields)
-        int tiles = a->tune[2] == 0 ? (f32 ? 2 : 1) : a->tune[2];
-        if (tiles != 2 || K64 <= 128)
-            tiles = 1;
-        int gpw = a->tune[3] > 0 ? a->tune[3] : 2;   // groups per wave
-        const int64_t chunk_cols = (int64_t)kWave * 2 * tiles;
-        const int64_t n_chunks = (K64 + chunk_cols - 1) / chunk_cols;
-        const int64_t groups_per_block = (int64_t)kWavesPerBlock * gpw;
-        p.n_rowblocks = (a->n_groups + groups_per_block - 1) /
-                        groups_per_block;
-        p.n_blocks = p.n_rowblocks * n_chunks;
-        p.rows_per_wave = gpw;
-        p.xcd_map = (a->tune[4] == 1) ? 0 : 1;
-        p.blocks_per_xcd = (p.n_blocks + kXcds - 1) / kXcds;
-        const int64_t ggrid = p.xcd_map ? p.blocks_per_xcd * kXcds
-                                        : p.n_blocks;
-        if (ggrid <= 0 || ggrid > 0x7fffffffLL)
-            return fail(REMAP_ERR_UNSUPPORTED,
-                        "remap_apply_f64: grid of %lld blocks",
-                        (long long)ggrid);
-        return f32 ? launch_rowgroup<float>(a, p, tiles, fma, ggrid, stream)
-                   : launch_rowgroup<double>(a, p, tiles, fma, ggrid, stream);
-    }
-    if (family == 5) {
-        if (!patch_ok)
-            return fail(REMAP_ERR_ARG,
-                        "remap_apply_f64: the patch kernel needs a patch "
-                        "plan covering [row_begin, row_end), float64 X and "
-                        "even strides");
-        const int64_t wc = a->patch_row_bytes / 8;
-        const int64_t n_chunks = (K64 + wc - 1) / wc;
-        p.n_rowblocks = a->n_patches;
-        p.n_blocks = a->n_patches * n_chunks;
-        p.rows_per_wave = 0;
-        int map = a->tune[4];
-        p.xcd_map = (map == 0 || map == 2) ? 1 : 0;
-        p.blocks_per_xcd = (p.n_blocks + kXcds - 1) / kXcds;
-        const int64_t pgrid = p.xcd_map ? p.blocks_per_xcd * kXcds
-                                        : p.n_blocks;
-        if (pgrid <= 0 || pgrid > 0x7fffffffLL)
-            return fail(REMAP_ERR_UNSUPPORTED,
-                        "remap_apply_f64: grid of %lld blocks",
-                        (long long)pgrid);
-        uint32_t lds_bytes = patch_lds_bytes(a->patch_umax, a->patch_emax,
-                                             a->patch_rows,
-                                             a->patch_row_bytes);
-        if (a->tune[7] > 0 && (uint32_t)a->tune[7] * 1024u > lds_bytes)
-            lds_bytes = a->tune[7] * 1024u;  // occupancy experiments
-        if (lds_bytes < 1024)
-            lds_bytes = 1024;
-        patch_fn pf = pick_patch(a->mode, fma, a->patch_row_bytes);
-        if (lds_bytes > 64 * 1024)
-            REMAP_HIP_CHECK(hipFuncSetAttribute(
-                reinterpret_cast<const void *>(pf),
-                hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-        hipLaunchKernelGGL(pf, dim3(static_cast<uint32_t>(pgrid)),
-                           dim3(kPatchBlock), lds_bytes, stream, p, a->flags,
-                           a->patch_rowptr, a->patch_val, a->patch_lidx,
-                           a->patch_ptr, a->patch_ucol, a->row_order,
-                           a->frac_b, a->patch_rows, a->patch_umax,
-                           a->patch_emax, a->n_patches);
-        REMAP_HIP_CHECK(hipGetLastError());
-        return REMAP_OK;
-    }
+}
 
-    kernel_fn fn = nullptr;
-    int64_t grid = 0;
-    if (family == 2) {
-        fn = f32 ? pick_rowlane<float>(a->mode, fma)
-                 : pick_rowlane<double>(a->mode, fma);
-        const int64_t threads = n_rows * K64;
-        grid = (threads + kBlock - 1) / kBlock;
-        p.n_rowblocks = p.n_blocks = p.blocks_per_xcd = 0;
-        p.rows_per_wave = 0;
-        p.xcd_map = 0;
-    } else if (family == 1 || family == 6) {
-        // two elements per lane need even strides and aligned bases
-        const bool can_vec2 =
-            (a->k_inner % 2 == 0) && (p.ldx % 2 == 0) && (p.bsx % 2 == 0) &&
-            (p.ldy % 2 == 0) && (p.bsy % 2 == 0) &&
-            aligned(a->X, 2 * xelem) && aligned(a->Y, 16);
-        int vec = a->tune[1];
-        if (vec == 0)
-            vec = (can_vec2 && K64 > 64) ? 2 : 1;
-        if (vec == 2 && !can_vec2)
-            return fail(REMAP_ERR_ARG,
-                        "remap_apply_f64: 2 elements per lane need even "
-                        "strides and 16-byte aligned X/Y");
-        if (vec != 1 && vec != 2)
-            return fail(REMAP_ERR_ARG, "remap_apply_f64: tune[1] = %d", vec);
-        int tiles = a->tune[2];
-        if (tiles == 0)
-            tiles = ((family == 1 || f32) && K64 >= 256) ? 2 : 1;  // measured
-        if (vec == 1)
-            tiles = 1;
-        if (tiles != 1 && tiles != 2 && tiles != 4)
-            return fail(REMAP_ERR_ARG, "remap_apply_f64: tune[2] = %d",
-                        tiles);
-        if (family == 6 && tiles == 4)
-            tiles = 2;
-        if (family == 6 && A.csr_pad < 8)
-            return fail(REMAP_ERR_ARG,
-                        "remap_apply_f64: the rowscalar kernels need "
-                        "csr_pad >= 8 readable entries behind col/val");
-        if (family == 6 && !small_offsets) {
-            if (a->tune[0] == 6)
-                return fail(REMAP_ERR_UNSUPPORTED,
-                            "remap_apply_f64: batch stride beyond the "
-                            "32-bit offsets of the rowscalar kernels");
-            family = 1;
-        }
-        int rpw = a->tune[3];
-        if (rpw == 0)
-            rpw = 4;
-        if (rpw < 1 || rpw > 1024)
-            return fail(REMAP_ERR_ARG, "remap_apply_f64: tune[3] = %d", rpw);
-        int map = a->tune[4];
-        if (map == 0)
-            map = 2;
-        const int64_t chunk_cols = (int64_t)kWave * vec * tiles;
-        const int64_t n_chunks = (K64 + chunk_cols - 1) / chunk_cols;
-        const int64_t rows_per_block = (int64_t)kWavesPerBlock * rpw;
-        p.n_rowblocks = (n_rows + rows_per_block - 1) / rows_per_block;
-        p.n_blocks = p.n_rowblocks * n_chunks;
-        p.rows_per_wave = rpw;
-        p.xcd_map = (map == 2) ? 1 : 0;
-        p.blocks_per_xcd = (p.n_blocks + kXcds - 1) / kXcds;
-        grid = p.xcd_map ? p.blocks_per_xcd * kXcds : p.n_blocks;
-        if (family == 6) {
-            if (grid <= 0 || grid > 0x7fffffffLL)
-                return fail(REMAP_ERR_UNSUPPORTED,
-                            "remap_apply_f64: grid of %lld blocks",
-                            (long long)grid);
-            return f32 ? launch_rowscalar<float>(a, p, vec, tiles, fma, grid,
-                                                 stream)
-                       : launch_rowscalar<double>(a, p, vec, tiles, fma, grid,
-                                                  stream);
-        }
-        fn = f32 ? pick_rowwave_shape<float>(vec, tiles, a->mode, fma)
-                 : pick_rowwave_shape<double>(vec, tiles, a->mode, fma);
-    } else {
-        return fail(REMAP_ERR_ARG, "remap_apply_f64: tune[0] = %d", family);
-    }
+// Measured on config 3: scalar-cache metadata beats the
+// plain wave-per-row kernel by ~10 %.  The LDS patch family wins when source
+// rows are heavily shared (config 4) and ties otherwise: the host attaches a
+// patch plan only in the first case (RemapPlan.auto_schedule), so its
+// presence decides.
+int automatic_family(const remap_apply_args *a, const Call &c)
+{
+    if (c.K <= 32)
+        return 2;
+    if (c.patch_ok && c.K >= 64)
+        return 5;
+    return a->A.csr_pad >= 8 ? 6 : 1;
+}
+
+// (row blocks x K chunks) work list -> grid size, XCD-aware or not.
+int shape_grid(KParams &p, int64_t n_rowblocks, int64_t n_chunks, bool xcd,
+               int64_t &grid)
+{
+    p.n_rowblocks = n_rowblocks;
+    p.n_blocks = n_rowblocks * n_chunks;
+    p.xcd_map = xcd ? 1 : 0;
+    p.blocks_per_xcd = (p.n_blocks + kXcds - 1) / kXcds;
+    grid = xcd ? p.blocks_per_xcd * kXcds : p.n_blocks;
     if (grid <= 0 || grid > 0x7fffffffLL)
         return fail(REMAP_ERR_UNSUPPORTED,
                     "remap_apply_f64: grid of %lld blocks; split the rows",
                     (long long)grid);
+    return REMAP_OK;
+}
 
-    // tune[7]: KiB of (unused) dynamic LDS per block -- an occupancy throttle
-    // for experiments: 160 KiB per CU / this = resident blocks per CU
+int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+int run_rowgroup(const remap_apply_args *a, const Call &c, KParams p,
+                 hipStream_t stream)
+{
+    if (!c.group_ok || !c.can_vec2 || !c.small_offsets)
+        return fail(REMAP_ERR_ARG,
+                    "remap_apply_f64: the rowgroup kernel needs the "
+                    "row-group schedule for [row_begin, row_end), even "
+                    "strides and 32-bit offsets");
+    // f32 rows are half as long: two K tiles per wave keep the bytes per
+    // wave and row at 1 KiB (measured +7 % on config 3 with f32 fields)
+    int tiles = a->tune[2] == 0 ? (c.f32 ? 2 : 1) : a->tune[2];
+    if (tiles != 2 || c.K <= 128)
+        tiles = 1;
+    const int gpw = a->tune[3] > 0 ? a->tune[3] : 2;   // groups per wave
+    p.rows_per_wave = gpw;
+    int64_t grid;
+    const int rc = shape_grid(
+        p, ceil_div(a->n_groups, (int64_t)kWavesPerBlock * gpw),
+        ceil_div(c.K, (int64_t)kWave * 2 * tiles), a->tune[4] != 1, grid);
+    if (rc != REMAP_OK)
+        return rc;
+    return c.f32 ? launch_rowgroup<float>(a, p, tiles, c.fma, grid, stream)
+                 : launch_rowgroup<double>(a, p, tiles, c.fma, grid, stream);
+}
+
+int run_patch(const remap_apply_args *a, const Call &c, KParams p,
+              hipStream_t stream)
+{
+    if (!c.patch_ok)
+        return fail(REMAP_ERR_ARG,
+                    "remap_apply_f64: the patch kernel needs a patch plan "
+                    "covering [row_begin, row_end), float64 X and even "
+                    "strides");
+    int64_t grid;
+    const int rc = shape_grid(p, a->n_patches,
+                              ceil_div(c.K, a->patch_row_bytes / 8),
+                              a->tune[4] == 0 || a->tune[4] == 2, grid);
+    if (rc != REMAP_OK)
+        return rc;
+    uint32_t lds_bytes = patch_lds_bytes(a->patch_umax, a->patch_emax,
+                                         a->patch_rows, a->patch_row_bytes);
+    if (a->tune[7] > 0 && (uint32_t)a->tune[7] * 1024u > lds_bytes)
+        lds_bytes = a->tune[7] * 1024u;  // occupancy experiments
+    if (lds_bytes < 1024)
+        lds_bytes = 1024;
+    patch_fn pf = pick_patch(a->mode, c.fma, a->patch_row_bytes);
+    if (lds_bytes > 64 * 1024)
+        REMAP_HIP_CHECK(hipFuncSetAttribute(
+            reinterpret_cast<const void *>(pf),
+            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    hipLaunchKernelGGL(pf, dim3(static_cast<uint32_t>(grid)),
+                       dim3(kPatchBlock), lds_bytes, stream, p, a->flags,
+                       a->patch_rowptr, a->patch_val, a->patch_lidx,
+                       a->patch_ptr, a->patch_ucol, a->row_order, a->frac_b,
+                       a->patch_rows, a->patch_umax, a->patch_emax,
+                       a->n_patches);
+    REMAP_HIP_CHECK(hipGetLastError());
+    return REMAP_OK;
+}
+
+// tune[7]: KiB of (unused) dynamic LDS per block -- an occupancy throttle for
+// experiments: 160 KiB per CU / this = resident blocks per CU
+int launch_plain(kernel_fn fn, const remap_apply_args *a, const KParams &p,
+                 int64_t grid, hipStream_t stream)
+{
     const uint32_t lds_bytes = a->tune[7] > 0 ? a->tune[7] * 1024u : 0u;
     if (lds_bytes > 64 * 1024)
         REMAP_HIP_CHECK(hipFuncSetAttribute(
@@ -1436,6 +1387,109 @@ int apply(const remap_apply_args *a, hipStream_t stream)
                        lds_bytes, stream, p, a->flags);
     REMAP_HIP_CHECK(hipGetLastError());
     return REMAP_OK;
+}
+
+int run_rowlane(const remap_apply_args *a, const Call &c, const KParams &p,
+                hipStream_t stream)
+{
+    const int64_t grid = ceil_div(c.n_rows * c.K, kBlock);
+    if (grid <= 0 || grid > 0x7fffffffLL)
+        return fail(REMAP_ERR_UNSUPPORTED,
+                    "remap_apply_f64: grid of %lld blocks; split the rows",
+                    (long long)grid);
+    return launch_plain(c.f32 ? pick_rowlane<float>(a->mode, c.fma)
+                              : pick_rowlane<double>(a->mode, c.fma),
+                        a, p, grid, stream);
+}
+
+// families 1 (vector-memory metadata) and 6 (scalar-cache metadata)
+int run_rowwave(const remap_apply_args *a, const Call &c, KParams p,
+                int family, hipStream_t stream)
+{
+    int vec = a->tune[1];
+    if (vec == 0)
+        vec = (c.can_vec2 && c.K > 64) ? 2 : 1;
+    if (vec == 2 && !c.can_vec2)
+        return fail(REMAP_ERR_ARG,
+                    "remap_apply_f64: 2 elements per lane need even "
+                    "strides and 16-byte aligned X/Y");
+    if (vec != 1 && vec != 2)
+        return fail(REMAP_ERR_ARG, "remap_apply_f64: tune[1] = %d", vec);
+    int tiles = a->tune[2];
+    if (tiles == 0)
+        tiles = ((family == 1 || c.f32) && c.K >= 256) ? 2 : 1;  // measured
+    if (vec == 1)
+        tiles = 1;
+    if (tiles != 1 && tiles != 2 && tiles != 4)
+        return fail(REMAP_ERR_ARG, "remap_apply_f64: tune[2] = %d", tiles);
+    if (family == 6 && tiles == 4)
+        tiles = 2;
+    if (family == 6 && a->A.csr_pad < 8)
+        return fail(REMAP_ERR_ARG,
+                    "remap_apply_f64: the rowscalar kernels need "
+                    "csr_pad >= 8 readable entries behind col/val");
+    if (family == 6 && !c.small_offsets) {
+        if (a->tune[0] == 6)
+            return fail(REMAP_ERR_UNSUPPORTED,
+                        "remap_apply_f64: batch stride beyond the "
+                        "32-bit offsets of the rowscalar kernels");
+        family = 1;
+    }
+    const int rpw = a->tune[3] == 0 ? 4 : a->tune[3];
+    if (rpw < 1 || rpw > 1024)
+        return fail(REMAP_ERR_ARG, "remap_apply_f64: tune[3] = %d", rpw);
+    p.rows_per_wave = rpw;
+    int64_t grid;
+    const int rc = shape_grid(
+        p, ceil_div(c.n_rows, (int64_t)kWavesPerBlock * rpw),
+        ceil_div(c.K, (int64_t)kWave * vec * tiles),
+        a->tune[4] == 0 || a->tune[4] == 2, grid);
+    if (rc != REMAP_OK)
+        return rc;
+    if (family == 6)
+        return c.f32 ? launch_rowscalar<float>(a, p, vec, tiles, c.fma, grid,
+                                               stream)
+                     : launch_rowscalar<double>(a, p, vec, tiles, c.fma,
+                                                grid, stream);
+    return launch_plain(
+        c.f32 ? pick_rowwave_shape<float>(vec, tiles, a->mode, c.fma)
+              : pick_rowwave_shape<double>(vec, tiles, a->mode, c.fma),
+        a, p, grid, stream);
+}
+
+}  // namespace
+
+int apply(const remap_apply_args *a, hipStream_t stream)
+{
+    Call c;
+    const int rc = check_args(a, c);
+    if (rc != REMAP_OK || c.K == 0)
+        return rc;
+    // a preferred family that cannot serve this call gives way to the
+    // automatic choice instead of failing
+    remap_apply_args relaxed;
+    if ((a->flags & REMAP_FLAG_TUNE_HINT) && a->tune[0] != 0 &&
+        !hint_usable(a, c)) {
+        relaxed = *a;
+        for (int t = 0; t < 8; ++t)
+            relaxed.tune[t] = 0;
+        a = &relaxed;
+    }
+    const int family = a->tune[0] != 0 ? a->tune[0] : automatic_family(a, c);
+    const KParams p = base_params(a, c);
+    switch (family) {
+    case 10:
+        return run_rowgroup(a, c, p, stream);
+    case 5:
+        return run_patch(a, c, p, stream);
+    case 2:
+        return run_rowlane(a, c, p, stream);
+    case 1:
+    case 6:
+        return run_rowwave(a, c, p, family, stream);
+    default:
+        return fail(REMAP_ERR_ARG, "remap_apply_f64: tune[0] = %d", family);
+    }
 }
 
 // ---------------------------------------------------------------------------
