@@ -34,8 +34,9 @@ def is_stale():
     if not os.path.exists(LIB_PATH):
         return True
     built = os.path.getmtime(LIB_PATH)
-    deps = sources() + [os.path.join(CSRC, 'remap_common.h'),
-                        os.path.join(INCLUDE, 'remap_hip.h')]
+    deps = sources() + [os.path.join(INCLUDE, 'remap_hip.h')] + \
+        [os.path.join(CSRC, f) for f in os.listdir(CSRC)
+         if f.endswith('.h')]
     return any(os.path.getmtime(d) > built for d in deps)
 
 

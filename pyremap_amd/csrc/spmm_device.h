@@ -1,0 +1,233 @@
+// spmm_device.h -- KParams, loads/stores, the fused epilogue, the block map.
+// Part of remap_spmm.hip: included there inside namespace remap::(anonymous),
+// in the order given there; not a stand-alone header.
+struct KParams {
+    const int64_t *__restrict__ rowptr;
+    const int32_t *__restrict__ col;
+    const double *__restrict__ val;
+    const void *__restrict__ X;
+    double *__restrict__ Y;
+    const double *__restrict__ frac_b;
+    uint8_t *__restrict__ mask_out;
+    const int32_t *__restrict__ row_order;
+    int64_t row_begin;
+    int64_t row_end;
+    int64_t ldx, bsx, ldy, bsy;
+    int64_t n_rowblocks;   // row blocks per chunk
+    int64_t n_blocks;      // n_rowblocks * n_chunks
+    int64_t blocks_per_xcd;
+    double thr;
+    uint32_t K;
+    uint32_t k_inner;
+    int32_t rows_per_wave;
+    int32_t xcd_map;
+    uint32_t x_range;      // bytes addressable from a source row base
+    uint32_t y_range;      // bytes addressable from a destination row base
+    int32_t debug;         // diagnostics only (tune[6]): 1 = no Y stores,
+                           // 2 = gather from the first 1024 source rows
+};
+
+template <bool FMA>
+__device__ __forceinline__ double mul_add(double a, double x, double acc)
+{
+    if constexpr (FMA) {
+        return __builtin_fma(a, x, acc);
+    } else {
+        // separate multiply and add (the file is built with
+        // -ffp-contract=off): scipy's `y[k] += a * x[k]`
+        const double prod = a * x;
+        return acc + prod;
+    }
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int src_lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
+}
+
+template <typename XT, int VEC>
+struct XVec;
+template <>
+struct XVec<double, 1> { typedef double type; };
+template <>
+struct XVec<double, 2> { typedef double type __attribute__((ext_vector_type(2))); };
+template <>
+struct XVec<float, 1> { typedef float type; };
+template <>
+struct XVec<float, 2> { typedef float type __attribute__((ext_vector_type(2))); };
+
+template <typename XT, int VEC>
+__device__ __forceinline__ typename XVec<XT, VEC>::type load_x(const XT *p)
+{
+    return *reinterpret_cast<const typename XVec<XT, VEC>::type *>(p);
+}
+
+template <typename V, int VEC>
+__device__ __forceinline__ double elem(const V &v, int e)
+{
+    if constexpr (VEC == 1) {
+        return static_cast<double>(v);
+    } else {
+        return static_cast<double>(v[e]);
+    }
+}
+
+// Y is written once and never read back: non-temporal stores (+3..5 % on
+// configs 3 and H against write-back ones, A/B in one run).  There is
+// deliberately no run-time switch to plain stores here: with `if (cached)
+// plain else nontemporal` on the same address LLVM merges the two stores and
+// silently drops the non-temporal hint -- the first builds of this file held
+// 414 plain stores and not a single `nt`.
+template <int VEC>
+__device__ __forceinline__ void store_y(double *p, const double (&y)[VEC])
+{
+    if constexpr (VEC == 1) {
+        __builtin_nontemporal_store(y[0], p);
+    } else {
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        d2 v;
+        v[0] = y[0];
+        v[1] = y[1];
+        __builtin_nontemporal_store(v, reinterpret_cast<d2 *>(p));
+    }
+}
+
+// ---------------------------------------------------------------------------
+// pieces shared by the wave-per-row kernels
+// ---------------------------------------------------------------------------
+
+// Entries [0, n) of one row chunk are held one per lane in (my_col, my_val).
+// Groups of UNROLL entries: every X load of a group is issued before the
+// first use, then the group is accumulated strictly in CSR order.
+template <typename XT, int VEC, int TILES, int MODE, bool FMA, int UNROLL>
+__device__ __forceinline__ void accumulate_entries(
+    const XT *__restrict__ X, int64_t ldx, const int64_t (&xoff)[TILES],
+    int32_t my_col, double my_val, int n, double (&acc)[TILES][VEC],
+    double (&den)[TILES][VEC], int debug = 0)
+{
+    typedef typename XVec<XT, VEC>::type xvec_t;
+    for (int u0 = 0; u0 < n; u0 += UNROLL) {
+        xvec_t xv[UNROLL][TILES];
+#pragma unroll
+        for (int uu = 0; uu < UNROLL; ++uu) {
+            if (u0 + uu < n) {
+                int32_t c = __builtin_amdgcn_readlane(my_col, u0 + uu);
+                if (debug & 2)
+                    c &= 1023;
+                const XT *xr = X + static_cast<int64_t>(c) * ldx;
+#pragma unroll
+                for (int t = 0; t < TILES; ++t)
+                    xv[uu][t] = load_x<XT, VEC>(xr + xoff[t]);
+            }
+        }
+        asm volatile("" ::: "memory");  // loads stay ahead of their uses
+#pragma unroll
+        for (int uu = 0; uu < UNROLL; ++uu) {
+            if (u0 + uu < n) {
+                const double a = readlane_f64(my_val, u0 + uu);
+#pragma unroll
+                for (int t = 0; t < TILES; ++t)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        const double x = elem<xvec_t, VEC>(xv[uu][t], v);
+                        if constexpr (MODE == REMAP_MODE_MASKED) {
+                            const bool valid = (x == x);
+                            const double xz = valid ? x : 0.0;
+                            const double mz = valid ? 1.0 : 0.0;
+                            acc[t][v] = mul_add<FMA>(a, xz, acc[t][v]);
+                            den[t][v] = mul_add<FMA>(a, mz, den[t][v]);
+                        } else {
+                            acc[t][v] = mul_add<FMA>(a, x, acc[t][v]);
+                        }
+                    }
+            }
+        }
+    }
+}
+
+// Fused epilogue of one row: normalise, mask, store (remap_numpy.py:266-278).
+template <int VEC, int TILES, int MODE>
+__device__ __forceinline__ void finish_row(
+    const KParams &p, int64_t i, double fb, const bool (&act)[TILES],
+    const int64_t (&yoff)[TILES], const double (&acc)[TILES][VEC],
+    const double (&den)[TILES][VEC])
+{
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+        if (!act[t])
+            continue;
+        double y[VEC];
+        bool ok[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            if constexpr (MODE == REMAP_MODE_RAW) {
+                ok[v] = true;
+                y[v] = acc[t][v];
+            } else if constexpr (MODE == REMAP_MODE_FRACB) {
+                // x / 1.0 == x exactly: bilinear maps (frac_b == 1) skip
+                // the 11-instruction f64 division; fb is wave-uniform
+                ok[v] = fb > 0.0;
+                y[v] = !ok[v] ? __builtin_nan("")
+                       : (fb == 1.0) ? acc[t][v] : acc[t][v] / fb;
+            } else {
+                ok[v] = den[t][v] > p.thr;
+                y[v] = ok[v] ? acc[t][v] / den[t][v] : __builtin_nan("");
+            }
+        }
+        const int64_t o = i * p.ldy + yoff[t];
+        if ((p.debug & 1) && y[0] != 1.2345e300)
+            continue;
+        store_y<VEC>(p.Y + o, y);
+#ifndef REMAP_STAMPS
+        if (p.mask_out) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v)
+                p.mask_out[o + v] = ok[v] ? 0 : 1;
+        }
+#endif
+    }
+}
+
+// Per-lane element offsets of a wave's K tiles (flat column -> batch, k).
+template <int VEC, int TILES>
+__device__ __forceinline__ void tile_offsets(
+    const KParams &p, int64_t chunk, int lane, int64_t (&xoff)[TILES],
+    int64_t (&yoff)[TILES], bool (&act)[TILES])
+{
+    constexpr int CH = kWave * VEC;
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+        const uint32_t kf = (static_cast<uint32_t>(chunk) * TILES + t) * CH +
+                            lane * VEC;
+        act[t] = kf < p.K;
+        const uint32_t b = act[t] ? kf / p.k_inner : 0u;
+        const uint32_t k = act[t] ? kf - b * p.k_inner : 0u;
+        // idle lanes (K tail) read offset 0 of the row: harmless, never used
+        xoff[t] = static_cast<int64_t>(b) * p.bsx + k;
+        yoff[t] = static_cast<int64_t>(b) * p.bsy + k;
+    }
+}
+
+// physical block -> logical block.  Blocks are dealt round-robin over the 8
+// XCDs, so bid % 8 labels the XCD; give each label a contiguous range.
+__device__ __forceinline__ int64_t logical_block(const KParams &p)
+{
+    int64_t L = blockIdx.x;
+    if (p.xcd_map) {
+        const int64_t xcd = L & (kXcds - 1);
+        const int64_t slot = L >> 3;
+        L = xcd * p.blocks_per_xcd + slot;
+    }
+    return L;
+}
+
+__device__ __forceinline__ int64_t readlane_i64(int64_t v, int src_lane)
+{
+    const int lo = __builtin_amdgcn_readlane(static_cast<int>(v), src_lane);
+    const int hi =
+        __builtin_amdgcn_readlane(static_cast<int>(v >> 32), src_lane);
+    return (static_cast<int64_t>(hi) << 32) |
+           static_cast<int64_t>(static_cast<uint32_t>(lo));
+}

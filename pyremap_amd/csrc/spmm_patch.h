@@ -1,0 +1,233 @@
+// spmm_patch.h -- family 5: LDS-staged gather of destination patches.
+// Part of remap_spmm.hip: included there inside namespace remap::(anonymous),
+// in the order given there; not a stand-alone header.
+// ---------------------------------------------------------------------------
+// patch: LDS-staged gather.  One workgroup owns one PATCH of destination rows
+// (a 2-D tile of the destination grid when a row order is installed) x one
+// 128-column K-chunk:
+//
+//   1. gather   every DISTINCT source row the patch references is fetched
+//               ONCE, straight into LDS, by LDS-DMA (`global_load_lds_dwordx4`:
+//               1 KiB = one row chunk per wave instruction, per-lane source
+//               address, no VGPRs, all of a wave's fetches in flight at once);
+//   2. barrier  (drains the DMA);
+//   3. compute  each wave walks its rows of the patch: (local index, S) pairs
+//               come through the SCALAR cache (s_load, 8 entries at a time,
+//               no vector-memory instructions), source data from LDS with
+//               `ds_read_b128` (lanes across K, sequential sum per lane: the
+//               same order and the same bits as the other families), fused
+//               epilogue, 16-byte non-temporal stores.
+//
+// Why: on conservative maps every source row is referenced by nnz/n_a = 3-5
+// neighbouring destination rows.  In the register-gather kernels each of
+// those references is a separate trip through the CU's vector-memory
+// pipeline (texture addresser + L1 miss queue), which is the saturated
+// resource; here only distinct rows take that trip and
+// the re-touches are LDS reads.  Several workgroups per CU overlap one
+// another's gather and compute phases.
+//
+// Metadata pointers are separate __restrict__ kernel arguments (not members
+// of KParams) so hipcc can prove them read-only and use scalar loads.
+// ---------------------------------------------------------------------------
+constexpr int kPatchBlock = 1024;  // 16 waves
+constexpr int kPatchWaves = kPatchBlock / kWave;
+
+// LDS image of one workgroup (row_bytes = 1024 or 512 per staged row chunk):
+//   [0, (umax + 1) * row_bytes)  the distinct source-row chunks
+//   then                   val  f64[emax]   the patch's weights, slot order
+//                          fb   f64[rows]   frac_b of the patch's rows
+//                          lidx i32[emax]   their local row indices
+//                          rptr i32[rows+1] entry offsets of the patch's rows
+//                          rid  i32[rows]   the rows' ids
+__host__ __device__ inline uint32_t patch_lds_bytes(int umax, int emax,
+                                                    int rows, int row_bytes)
+{
+    return (static_cast<uint32_t>(umax) + 1u) * row_bytes +
+           static_cast<uint32_t>(emax) * 12u +
+           static_cast<uint32_t>(rows) * 16u + 32u;
+}
+
+// WC = columns per K-chunk: 128 (two doubles per lane, 1 KiB per staged row)
+// or 64 (one double per lane, 512 B per staged row: half the LDS per row, so
+// twice the patch area fits -- for mappings whose rows reference many
+// source rows, e.g. 2nd-order conservative stencils)
+template <int MODE, bool FMA, int WC>
+__global__ __launch_bounds__(kPatchBlock) void spmm_patch(
+    const KParams p, const uint32_t flags,
+    const int32_t *__restrict__ prow, const double *__restrict__ pval,
+    const int32_t *__restrict__ plidx, const int32_t *__restrict__ pptr,
+    const int32_t *__restrict__ ucol, const int32_t *__restrict__ row_order,
+    const double *__restrict__ frac_b, const int32_t patch_rows,
+    const int32_t umax, const int32_t emax, const int64_t n_patches)
+{
+    constexpr int VEC = WC / kWave;           // doubles per lane
+    constexpr int kRowBytes = WC * 8;         // staged bytes per source row
+    constexpr int kRowsPerDma = 1024 / kRowBytes;  // rows per DMA instruction
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    typedef typename XVec<double, VEC>::type xvec_t;
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t L = logical_block(p);
+    if (L >= p.n_blocks)
+        return;
+    const int64_t chunk = L / n_patches;  // chunk-major work list
+    const int64_t patch = L - chunk * n_patches;
+
+    // compute-phase columns of this lane
+    int64_t xoff[1], yoff[1];
+    bool act[1];
+    tile_offsets<VEC, 1>(p, chunk, lane, xoff, yoff, act);
+    // gather-phase columns: every lane moves 16 B (2 doubles); with 512-byte
+    // rows one instruction carries two source rows (lanes 0-31 / 32-63)
+    int64_t goff;
+    {
+        constexpr int kLanesPerRow = kWave / kRowsPerDma;
+        const uint32_t kf = static_cast<uint32_t>(chunk) * WC +
+                            (lane % kLanesPerRow) * 2;
+        const bool in = kf < p.K;
+        const uint32_t bb = in ? kf / p.k_inner : 0u;
+        const uint32_t kk = in ? kf - bb * p.k_inner : 0u;
+        goff = static_cast<int64_t>(bb) * p.bsx + kk;
+    }
+    const int sub = lane / (kWave / kRowsPerDma);  // which row of the pair
+
+    double *lds_val =
+        reinterpret_cast<double *>(lds + (umax + 1) * kRowBytes);
+    double *lds_fb = lds_val + emax;
+    int32_t *lds_lidx = reinterpret_cast<int32_t *>(lds_fb + patch_rows);
+    int32_t *lds_rptr = lds_lidx + emax;
+    int32_t *lds_rid = lds_rptr + patch_rows + 1;
+
+    // 1. gather: distinct source rows by LDS-DMA, the patch's entries by
+    //    plain loads (they are contiguous: patch-major CSR).  The phase is a
+    //    chain of dependent memory trips with every wave of the workgroup
+    //    waiting at the barrier behind it, so loads are issued level by
+    //    level: everything addressed by the patch id alone first, then what
+    //    those values address, LDS writes last (3 trips instead of 5).
+    const int u0 = pptr[patch];
+    const int U = pptr[patch + 1] - u0;
+    const int64_t slot0 = p.row_begin + patch * patch_rows;
+    const int64_t local0 = patch * patch_rows;  // index into prow
+    int nrows = patch_rows;
+    if (slot0 + nrows > p.row_end)
+        nrows = static_cast<int>(p.row_end - slot0);
+    const int e0 = prow[local0];
+    const int n_e = prow[local0 + nrows] - e0;
+    // branch-free (clamped) loads: a load inside a divergent branch makes
+    // hipcc wait for it on the spot
+    const int tc = tid < nrows ? tid : nrows - 1;
+    const int32_t *ro = row_order ? row_order + slot0 : prow + local0;
+    const int32_t rid_ld = ro[tc];
+    const int32_t my_rid =
+        row_order ? rid_ld : static_cast<int32_t>(slot0 + tc);
+    const int32_t my_rp = prow[local0 + (tid <= nrows ? tid : nrows)];
+    constexpr int kPre = 2;  // entry batches held in registers meanwhile
+    double ev[kPre];
+    int32_t el[kPre];
+#pragma unroll
+    for (int k = 0; k < kPre; ++k) {
+        const int t = tid + k * kPatchBlock;
+        ev[k] = 0.0;
+        el[k] = 0;
+        if (t < n_e) {
+            ev[k] = pval[e0 + t];
+            el[k] = plidx[e0 + t];
+        }
+    }
+    // before the DMA loop: behind it the wait for my_rid would be vmcnt(0)
+    double my_fb = 0.0;
+    if constexpr (MODE == REMAP_MODE_FRACB)
+        my_fb = frac_b[my_rid];
+    const double *__restrict__ X = static_cast<const double *>(p.X);
+    for (int j = wave * kRowsPerDma; j < U; j += kPatchWaves * kRowsPerDma) {
+        // the second row of a pair may not exist: fetch the first again
+        // (lands in the spare slot behind the list)
+        const int jj = (j + sub < U) ? j + sub : j;
+        int32_t c = ucol[u0 + jj];
+        if (p.debug & 2)
+            c &= 1023;
+        const double *g = X + static_cast<int64_t>(c) * p.ldx + goff;
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void *)g,
+            (__attribute__((address_space(3))) void *)(lds + j * kRowBytes),
+            16, 0, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < kPre; ++k) {
+        const int t = tid + k * kPatchBlock;
+        if (t < n_e) {
+            lds_val[t] = ev[k];
+            lds_lidx[t] = el[k];
+        }
+    }
+    for (int t = tid + kPre * kPatchBlock; t < n_e; t += kPatchBlock) {
+        lds_val[t] = pval[e0 + t];
+        lds_lidx[t] = plidx[e0 + t];
+    }
+    if (tid <= nrows)
+        lds_rptr[tid] = my_rp - e0;
+    if (tid < nrows) {
+        lds_rid[tid] = my_rid;
+        if constexpr (MODE == REMAP_MODE_FRACB)
+            lds_fb[tid] = my_fb;
+    }
+    // 2. everything landed, visible to every wave
+    __syncthreads();
+
+    // 3. compute the patch's rows from LDS
+    const char *mine = lds + lane * (VEC * 8);
+    // the next row's header (id, entry range, frac_b) is read while this
+    // row is being computed: short rows (4 entries of a bilinear map) are a
+    // chain of LDS round trips otherwise
+    int32_t nx_rid = 0, nx_s = 0, nx_e = 0;
+    double nx_fb = 0.0;
+    if (wave < nrows) {
+        nx_rid = lds_rid[wave];
+        nx_s = lds_rptr[wave];
+        nx_e = lds_rptr[wave + 1];
+        if constexpr (MODE == REMAP_MODE_FRACB)
+            nx_fb = lds_fb[wave];
+    }
+    for (int r = wave; r < nrows; r += kPatchWaves) {
+        const int64_t i = __builtin_amdgcn_readfirstlane(nx_rid);
+        const int s = __builtin_amdgcn_readfirstlane(nx_s);
+        const int e = __builtin_amdgcn_readfirstlane(nx_e);
+        const double fb_row = nx_fb;
+        if (r + kPatchWaves < nrows) {
+            nx_rid = lds_rid[r + kPatchWaves];
+            nx_s = lds_rptr[r + kPatchWaves];
+            nx_e = lds_rptr[r + kPatchWaves + 1];
+            if constexpr (MODE == REMAP_MODE_FRACB)
+                nx_fb = lds_fb[r + kPatchWaves];
+        }
+        double acc[1][VEC];
+        double den[1][VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            acc[0][v] = 0.0;
+            den[0][v] = 0.0;
+        }
+#pragma unroll 4
+        for (int jj = s; jj < e; ++jj) {
+            // (index, weight) by LDS broadcast (same address in every lane);
+            // measured faster than one coalesced read + v_readlane
+            const int32_t li = lds_lidx[jj];
+            const double a = lds_val[jj];
+            const xvec_t xq = *reinterpret_cast<const xvec_t *>(
+                mine + li * kRowBytes);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const double x = elem<xvec_t, VEC>(xq, v);
+                if constexpr (MODE == REMAP_MODE_MASKED) {
+                    const bool valid = (x == x);
+                    acc[0][v] = mul_add<FMA>(a, valid ? x : 0.0, acc[0][v]);
+                    den[0][v] = mul_add<FMA>(a, valid ? 1.0 : 0.0, den[0][v]);
+                } else {
+                    acc[0][v] = mul_add<FMA>(a, x, acc[0][v]);
+                }
+            }
+        }
+        finish_row<VEC, 1, MODE>(p, i, fb_row, act, yoff, acc, den);
+    }
+}
