@@ -482,3 +482,61 @@ def test_reference_fixture_latlon_to_stereographic(tmp_path):
         np.testing.assert_array_equal(ds['x'].values, dst.x)
     assert_bitwise(ds_file['SST'].values, ds_mem['SST'].values,
                    'ncremap vs remap_numpy')
+
+
+def test_examples_run(tmp_path, monkeypatch):
+    """examples/: the stereographic -> stereographic script of the reference's
+    examples directory (analytic weights) and the apply-a-mapping-file
+    script, end to end on generated files."""
+    import importlib.util
+    from pyremap_amd import DataArray, Dataset, synthetic
+    from pyremap_amd.io.netcdf import open_dataset, write_netcdf
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def load(name):
+        spec = importlib.util.spec_from_file_location(
+            name, os.path.join(root, 'examples', f'{name}.py'))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+
+    monkeypatch.chdir(tmp_path)
+    # -- stereographic 50 km -> 20 km ---------------------------------------
+    x = np.linspace(-1.0e6, 1.0e6, 41)
+    y = np.linspace(-5.0e5, 5.0e5, 21)
+    xx, yy = np.meshgrid(x, y)
+    ds = Dataset()
+    ds['x'] = DataArray(x, dims=('x',))
+    ds['y'] = DataArray(y, dims=('y',))
+    thick = 1000.0 + 1e-3 * xx - 2e-3 * yy
+    ds['thickness'] = DataArray(np.stack([thick, 2 * thick]),
+                                dims=('time', 'y', 'x'))
+    write_netcdf(ds, 'stereo_in.nc')
+    r = load('remap_stereographic').main(
+        ['-i', 'stereo_in.nc', '-o', 'stereo_out.nc', '-r', '20'])
+    assert os.path.exists(r.map_filename)
+    out = open_dataset('stereo_out.nc')
+    assert out['thickness'].shape == (2, 51, 101)
+    xo, yo = np.meshgrid(out['x'].values, out['y'].values)
+    want = 1000.0 + 1e-3 * xo - 2e-3 * yo            # linear: exact
+    assert np.abs(out['thickness'].values[0] - want).max() < 1e-9
+    assert np.abs(out['thickness'].values[1] - 2 * want).max() < 1e-9
+    # -- apply a mapping file to an "MPAS" file -----------------------------
+    m = synthetic.conservative_map(800, (18, 36), 1, 5, seed=5)
+    m.save('map_toy_to_10x10degree_aave.nc')
+    ds2 = Dataset()
+    field = np.random.default_rng(0).standard_normal((3, 800, 4))
+    field[:, :50, 2:] = -9.99999979021476795361e+33       # MPAS fill value
+    ds2['temperature'] = DataArray(field, dims=('Time', 'nCells',
+                                                'nVertLevels'))
+    ds2['other'] = DataArray(field[..., 0], dims=('Time', 'nCells'))
+    write_netcdf(ds2, 'mpas_in.nc')
+    load('remap_with_mapping_file').main(
+        ['-m', 'map_toy_to_10x10degree_aave.nc', '-i', 'mpas_in.nc', '-o',
+         'mpas_out.nc', '--dlon', '10', '--dlat', '10', '-v', 'temperature',
+         '--renormalize', '0.01'])
+    out2 = open_dataset('mpas_out.nc')
+    assert out2['temperature'].dims == ('Time', 'lat', 'lon', 'nVertLevels')
+    assert out2['temperature'].shape == (3, 18, 36, 4)
+    assert 'other' not in out2.variables
+    assert np.nanmax(np.abs(out2['temperature'].values)) < 10.0   # no fills
