@@ -785,3 +785,97 @@ def test_rowgroup_kernel_bitwise(dev, grid, K):
                                  tune=tune)
             assert np.array_equal(mask.cpu().numpy().astype(bool), ref_mask)
             assert_bitwise(y.cpu().numpy(), ref, f'{grid} K={K} {tune}')
+
+
+# ---------------------------------------------------------------------------
+# randomised end-to-end cases: whatever the plan, the layout and the mode
+# ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize('seed', range(12))
+def test_random_cases_bitwise(dev, seed):
+    """
+    Twelve seeds x ten random cases: random mapping (bilinear-like,
+    conservative-like or structureless), random destination grid shape,
+    schedule chosen by ``auto_schedule`` (or none), random field layout (the
+    source axis anywhere in a 1- to 4-D array), f32 or f64, the three modes,
+    whole plan or a row shard -- always bit-identical to the oracle's
+    restatement of ``_remap_numpy_array``.
+    """
+    from oracle import oracle
+    from pyremap_amd import engine, synthetic
+    rng = np.random.default_rng(1000 + seed)
+    for case in range(10):
+        my, mx = int(rng.integers(3, 40)), int(rng.integers(4, 60))
+        kind = rng.choice(['bilinear', 'conservative', 'rich', 'random'])
+        if kind == 'bilinear':
+            sy, sx = int(rng.integers(2, 12)), int(rng.integers(2, 14))
+            m = synthetic.bilinear_map((sy, sx), (my, mx),
+                                       seed=int(rng.integers(1 << 30)),
+                                       device=dev)
+        elif kind == 'random':
+            m = _random_map(int(rng.integers(5, 3000)), (my, mx),
+                            int(rng.integers(1, 6)),
+                            int(rng.integers(1 << 30)), dev)
+        else:
+            lo, hi = (1, 6) if kind == 'conservative' else (10, 22)
+            m = synthetic.conservative_map(
+                int(rng.integers(50, 4000)), (my, mx), lo, hi,
+                seed=int(rng.integers(1 << 30)), device=dev,
+                signed=bool(rng.integers(2)))
+        plan = engine.RemapPlan.from_triplets(m.row, m.col, m.S, m.frac_b,
+                                              m.n_a, m.n_b, device=dev)
+        how = rng.choice(['auto', 'auto1d', 'none'])
+        if how == 'auto':
+            plan.auto_schedule((my, mx))
+        elif how == 'auto1d':
+            plan.auto_schedule((my * mx,))
+        rowptr, col, val = plan.to_host_csr()
+        csr = oracle.OracleCSR(rowptr, col, val, (m.n_b, m.n_a))
+        frac_b = m.frac_b.cpu().numpy()
+        # field layout: extra dims around the source axis
+        n_before = int(rng.integers(0, 3))
+        n_after = int(rng.integers(0, 3))
+        before = [int(rng.integers(1, 5)) for _ in range(n_before)]
+        after = [int(rng.choice([1, 2, 3, 7, 16, 33, 64, 65, 130, 256]))
+                 for _ in range(n_after)]
+        shape = before + [m.n_a] + after
+        axis = n_before
+        dtype = rng.choice([np.float64, np.float32])
+        field = rng.standard_normal(shape).astype(dtype)
+        mode = rng.choice(['fracb', 'masked', 'plain_thr'])
+        thr = None
+        arg = field
+        if mode != 'fracb':
+            thr = float(rng.choice([0.0, 0.01, 0.5]))
+        if mode == 'masked':
+            field[rng.random(shape) < 0.15] = np.nan
+            arg = np.ma.masked_array(field, mask=np.isnan(field))
+        ref = oracle.remap_numpy_array(csr, frac_b, (my, mx), arg, [axis],
+                                       thr)
+        ref = np.ma.filled(ref.astype(np.float64), np.nan) \
+            if np.ma.isMaskedArray(ref) else np.asarray(ref)
+        x = torch.from_numpy(field).to(dev)
+        masked = mode == 'masked' and thr is not None and \
+            bool(np.isnan(field).any())
+        y = engine.remap_tensor(
+            plan, (my, mx), x, [axis],
+            engine.MODE_MASKED if masked else engine.MODE_FRACB,
+            threshold=thr if masked else 0.0)
+        what = (f'seed {seed} case {case}: {kind} {m.n_a}->{my}x{mx} {how} '
+                f'shape {shape} {np.dtype(dtype).name} {mode} thr {thr}')
+        assert tuple(y.shape) == ref.shape, what
+        assert_bitwise(y.cpu().numpy(), ref, what)
+        if m.n_b >= 6:
+            # a row shard of the same plan, scheduling itself
+            r = int(rng.integers(0, 3))
+            shard = plan.shard(r, 3)
+            if how != 'none':
+                shard.auto_schedule((my, mx))
+            ys = engine.remap_tensor(
+                shard, None, x, [axis],
+                engine.MODE_MASKED if masked else engine.MODE_FRACB,
+                threshold=thr if masked else 0.0)
+            flat = ref.reshape(tuple(before) + (m.n_b,) + tuple(after))
+            lo = shard.row_offset
+            want = np.take(flat, np.arange(lo, lo + shard.n_b), axis=axis)
+            assert_bitwise(ys.cpu().numpy(), want, what + f' shard {r}/3')
