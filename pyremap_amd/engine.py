@@ -778,7 +778,10 @@ def remap_tensor(plan, dst_grid_dims, field, remap_axes, mode, threshold=0.0,
     k_inner = _prod(tail_shape)
     direct = contiguous_block and (k_inner >= 8 or n_batch == 1)
     sharded = plan.n_b != plan.n_b_global
-    dst_shape = [plan.n_b] if sharded else [int(d) for d in dst_grid_dims]
+    # rows stay flat for a shard (its rows are no whole grid) and when the
+    # caller names no destination grid
+    dst_shape = [plan.n_b] if sharded or dst_grid_dims is None \
+        else [int(d) for d in dst_grid_dims]
     if not sharded and _prod(dst_shape) != plan.n_b:
         raise ValueError(f'dst_grid_dims {dst_shape} do not hold n_b = '
                          f'{plan.n_b} cells')

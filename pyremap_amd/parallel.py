@@ -88,16 +88,24 @@ class ShardedRemap:
     """
     One rank's share of a row-sharded remap.
 
-    >>> sharded = ShardedRemap(full_plan)         # inside an initialised
-    >>> x = sharded.broadcast(x)                  # process group
-    >>> y_rows = sharded.apply(x, [0], mode)      # this rank's rows
-    >>> y = sharded.gather(y_rows)                # optional
+    >>> sharded = ShardedRemap(full_plan, grid_dims=(360, 720))
+    >>> x = sharded.broadcast(x)                  # inside an initialised
+    >>> y_rows = sharded.apply(x, [0], mode)      # process group: this
+    >>> y = sharded.gather(y_rows)                # rank's rows; optional
+
+    With ``grid_dims`` (the destination grid of the WHOLE mapping) every rank
+    picks the kernel schedule for its own rows (``RemapPlan.auto_schedule``),
+    as ``bench.py --gpus N`` does.
     """
 
-    def __init__(self, plan, group=None):
+    def __init__(self, plan, group=None, grid_dims=None, rank=None,
+                 world_size=None):
         import torch.distributed as dist
         self.group = group
-        if dist.is_available() and dist.is_initialized():
+        if rank is not None and world_size is not None:
+            # ranks managed by the caller (MPI launchers, tests)
+            self.rank, self.world_size = int(rank), int(world_size)
+        elif dist.is_available() and dist.is_initialized():
             self.rank = dist.get_rank(group)
             self.world_size = dist.get_world_size(group)
         else:
@@ -106,6 +114,8 @@ class ShardedRemap:
         self.plan = plan.row_slice(self.bounds[self.rank],
                                    self.bounds[self.rank + 1]) \
             if self.world_size > 1 else plan
+        self.schedule = self.plan.auto_schedule(grid_dims) \
+            if grid_dims is not None else None
 
     def broadcast(self, field, src=0):
         return broadcast_field(field, src=src, group=self.group)

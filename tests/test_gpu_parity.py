@@ -879,3 +879,37 @@ def test_random_cases_bitwise(dev, seed):
             lo = shard.row_offset
             want = np.take(flat, np.arange(lo, lo + shard.n_b), axis=axis)
             assert_bitwise(ys.cpu().numpy(), want, what + f' shard {r}/3')
+
+
+def test_sharded_remap_slabs_make_the_whole(dev):
+    """``parallel.ShardedRemap`` as three ranks would build it (ranks given
+    explicitly): every rank's slab, scheduled on its own, stacked = the
+    unsharded result, bit for bit; the work-balanced bounds cover all rows."""
+    from pyremap_amd import engine, synthetic
+    from pyremap_amd.parallel import ShardedRemap
+    m = synthetic.conservative_map(20000, (120, 150), 2, 7, seed=13,
+                                   device=dev)
+    plan = engine.RemapPlan.from_triplets(m.row, m.col, m.S, m.frac_b,
+                                          m.n_a, m.n_b, device=dev)
+    x = torch.randn((4, m.n_a, 96), device=dev, dtype=torch.float64)
+    x[:, torch.rand(m.n_a, device=dev) < 0.1, 40:] = float('nan')
+    whole = ShardedRemap(plan, grid_dims=m.dst_dims)        # no group: 1 rank
+    assert whole.world_size == 1 and whole.plan is plan
+    want = whole.apply(x, [1], engine.MODE_MASKED, threshold=0.01)
+    slabs, covered = [], 0
+    for rank in range(3):
+        part = ShardedRemap(plan, grid_dims=m.dst_dims, rank=rank,
+                            world_size=3)
+        assert part.bounds[0] == 0 and part.bounds[-1] == m.n_b
+        assert part.plan.n_b == part.bounds[rank + 1] - part.bounds[rank]
+        assert part.schedule is not None
+        covered += part.plan.n_b
+        slabs.append(part.apply(x, [1], engine.MODE_MASKED, threshold=0.01))
+    assert covered == m.n_b
+    got = torch.cat(slabs, dim=1)
+    assert_bitwise(got.cpu().numpy(),
+                   want.reshape(4, m.n_b, 96).cpu().numpy(), 'sharded')
+    # work balance: no rank carries more than 40 % of entries + 2 rows each
+    work = [int(plan.rowptr[b1] - plan.rowptr[b0]) + 2 * (b1 - b0)
+            for b0, b1 in zip(part.bounds[:-1], part.bounds[1:])]
+    assert max(work) < 0.4 * sum(work)
