@@ -87,6 +87,40 @@ class PolarStereographic:
         return lon, lat
 
 
+def projection_from_string(proj_str):
+    """
+    A projection object for a PROJ string (``remapper/descriptor.py:150-165``
+    hands the string to ``pyproj.Proj``).  With pyproj installed that is what
+    is returned; without it the polar stereographic aspect on WGS84
+    (``+proj=stere +lat_0=+-90 ...``, what the polar grids of MPAS analysis
+    use) is parsed into a :class:`PolarStereographic`; anything else needs
+    pyproj.
+    """
+    try:
+        import pyproj
+        return pyproj.Proj(proj_str)
+    except ImportError:
+        pass
+    params = {}
+    for token in str(proj_str).split():
+        if token.startswith('+'):
+            key, _, value = token[1:].partition('=')
+            params[key] = value
+    ellps_ok = params.get('ellps', params.get('datum', 'WGS84')) == 'WGS84'
+    if params.get('proj') == 'stere' and ellps_ok and \
+            abs(abs(float(params.get('lat_0', 0.0))) - 90.0) < 1e-12 and \
+            float(params.get('k_0', params.get('k', 1.0))) == 1.0:
+        lat_0 = float(params['lat_0'])
+        return PolarStereographic(
+            lat_ts=float(params.get('lat_ts', lat_0)), lat_0=lat_0,
+            lon_0=float(params.get('lon_0', 0.0)),
+            x_0=float(params.get('x_0', 0.0)),
+            y_0=float(params.get('y_0', 0.0)))
+    raise NotImplementedError(
+        f'projection {proj_str!r}: without pyproj only polar stereographic '
+        f'projections on WGS84 are available')
+
+
 def antarctic_stereographic():
     """``polar.py:39-49``: lat_ts = -71, lat_0 = -90, lon_0 = 0 (EPSG:3031)."""
     return PolarStereographic(lat_ts=-71.0, lat_0=-90.0, lon_0=0.0)

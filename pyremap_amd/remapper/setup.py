@@ -8,6 +8,7 @@ described without pyproj.
 import numpy as np
 
 from pyremap_amd.descriptor import (
+    LatLon2DGridDescriptor,
     LatLonGridDescriptor,
     MpasCellMeshDescriptor,
     MpasEdgeMeshDescriptor,
@@ -70,10 +71,7 @@ def _get_descriptor(info):
     if grid_type == 'points':
         return _points_descriptor(info)
     if grid_type == 'proj':
-        raise NotImplementedError(
-            'projection grids read from a file need pyproj, which this '
-            'engine does not depend on; pass a ProjectionGridDescriptor as '
-            'src_descriptor / dst_descriptor instead')
+        return _proj_descriptor(info)
     raise ValueError(f'Unexpected grid type {grid_type}')
 
 
@@ -95,26 +93,34 @@ def _lon_lat_descriptor(info):
     else:
         from pyremap_amd.io.netcdf import open_dataset
         ds = open_dataset(info['filename'])
-        lat = np.asarray(ds[info['lat']].values, dtype=np.float64)
-        lon = np.asarray(ds[info['lon']].values, dtype=np.float64)
-        if lat.ndim != 1 or lon.ndim != 1:
-            raise NotImplementedError(
-                '2-D lat/lon grids: pass a LatLon2DGridDescriptor directly')
-        units = ds[info['lat']].attrs.get('units', 'degrees')
-        if isinstance(units, bytes):
-            units = units.decode()
-        units = 'radians' if 'rad' in str(units) else 'degrees'
-        descriptor = LatLonGridDescriptor.create(
-            _edges(lat), _edges(lon), units=units,
-            regional=info.get('regional'))
-        # centres are exactly the file's coordinates
-        descriptor.lat, descriptor.lon = lat, lon
-        descriptor._set_coords(info['lat'], info['lon'],
-                               ds[info['lat']].dims[0],
-                               ds[info['lon']].dims[0])
+        lon, lat = info['lon'], info['lat']
+        ndims = (len(ds[lon].dims), len(ds[lat].dims))
+        if ndims not in ((1, 1), (2, 2)):
+            raise ValueError(
+                f'longitude and latitude coordinates {lon} and {lat} have '
+                f'unexpected sizes {ndims[0]} and {ndims[1]}.')
+        cls = LatLonGridDescriptor if ndims == (1, 1) else \
+            LatLon2DGridDescriptor
+        descriptor = cls.read(ds=ds, lon_var_name=lon, lat_var_name=lat,
+                              regional=info.get('regional'))
     if 'name' in info:
         descriptor.mesh_name = info['name']
     return descriptor
+
+
+def _proj_descriptor(info):
+    """``remapper/descriptor.py:136-166``: the PROJ string comes from the
+    call or from a global attribute of the grid file."""
+    from pyremap_amd.descriptor import ProjectionGridDescriptor
+    from pyremap_amd.descriptor.projection import projection_from_string
+    from pyremap_amd.io.netcdf import open_dataset
+    if 'proj_attr' in info:
+        proj_str = open_dataset(info['filename']).attrs[info['proj_attr']]
+    else:
+        proj_str = info['proj_str']
+    return ProjectionGridDescriptor.read(
+        projection_from_string(proj_str), info['filename'],
+        mesh_name=info['name'], x_var_name=info['x'], y_var_name=info['y'])
 
 
 def _points_descriptor(info):
@@ -128,12 +134,3 @@ def _points_descriptor(info):
         lat_var.values, ds[info['lon']].values, info['name'],
         units='radians' if 'rad' in str(units) else 'degrees',
         out_dimension=lat_var.dims[0])
-
-
-def _edges(centres):
-    c = np.asarray(centres, dtype=np.float64)
-    out = np.empty(len(c) + 1)
-    out[1:-1] = 0.5 * (c[:-1] + c[1:])
-    out[0] = 1.5 * c[0] - 0.5 * c[1]
-    out[-1] = 1.5 * c[-1] - 0.5 * c[-2]
-    return out

@@ -238,3 +238,87 @@ def test_to_from_polar_round_trip():
     xy = to_polar(pts.copy())
     back = from_polar(xy.copy())
     np.testing.assert_allclose(back, pts, atol=1e-10)
+
+
+def test_remapper_grid_info_becomes_descriptors(tmp_path):
+    """``src_from_* / dst_from_*`` only record where a grid is described
+    (remapper.py:139-421); ``_setup_remapper`` turns the records into
+    descriptors (remapper/descriptor.py:21-199): 1-D and 2-D lat-lon files,
+    projection files with a PROJ string (argument or file attribute), point
+    files, a generated global grid."""
+    from pyremap_amd import Remapper
+    from pyremap_amd.descriptor import PointCollectionDescriptor
+    from pyremap_amd.remapper.setup import _setup_remapper
+    lat = np.linspace(-88.0, 88.0, 45)
+    lon = np.linspace(-178.0, 178.0, 90)
+    ds = xr_lite.Dataset()
+    ds['lat'] = (('lat',), lat)
+    ds['lon'] = (('lon',), lon)
+    lon2d, lat2d = np.meshgrid(lon, lat)
+    ds['lat2d'] = (('y', 'x'), lat2d)
+    ds['lon2d'] = (('y', 'x'), lon2d)
+    for v in ('lat', 'lon', 'lat2d', 'lon2d'):
+        ds[v].attrs['units'] = 'degrees'
+    ds['odd'] = (('a', 'b', 'c'), np.zeros((2, 2, 2)))
+    ds['odd'].attrs['units'] = 'degrees'
+    latlon_file = str(tmp_path / 'latlon.nc')
+    write_netcdf(ds, latlon_file)
+
+    proj_str = ('+proj=stere +lat_ts=-71.0 +lat_0=-90 +lon_0=0.0 +k_0=1.0 '
+                '+x_0=0.0 +y_0=0.0 +ellps=WGS84')
+    dp = xr_lite.Dataset()
+    dp['x'] = (('x',), np.linspace(-5.0e5, 5.0e5, 11))
+    dp['y'] = (('y',), np.linspace(-3.0e5, 3.0e5, 7))
+    dp.attrs['proj4'] = proj_str
+    proj_file = str(tmp_path / 'stereo.nc')
+    write_netcdf(dp, proj_file)
+
+    dq = xr_lite.Dataset()
+    dq['plat'] = (('station',), np.array([10.0, -20.0, 45.0]))
+    dq['plon'] = (('station',), np.array([100.0, 20.0, -45.0]))
+    dq['plat'].attrs['units'] = 'degrees_north'
+    dq['plon'].attrs['units'] = 'degrees_east'
+    points_file = str(tmp_path / 'points.nc')
+    write_netcdf(dq, points_file)
+
+    r = Remapper(method='bilinear')
+    r.src_from_lon_lat(latlon_file, mesh_name='two_degree')
+    r.dst_from_proj(proj_file, 'stereo100km', proj_str=proj_str)
+    _setup_remapper(r)
+    assert isinstance(r.src_descriptor, LatLonGridDescriptor)
+    assert r.src_descriptor.mesh_name == 'two_degree'
+    assert r.src_descriptor.dim_sizes == [45, 90]
+    assert isinstance(r.dst_descriptor, ProjectionGridDescriptor)
+    assert r.dst_descriptor.dim_sizes == [7, 11]
+    assert r.dst_descriptor.coords['lat']['data'].shape == (7, 11)
+    assert r.map_filename == 'map_two_degree_to_stereo100km_esmfbilin.nc'
+
+    r = Remapper(method='bilinear')
+    r.src_from_lon_lat(latlon_file, lon_var='lon2d', lat_var='lat2d')
+    r.dst_from_proj(proj_file, 'stereo100km', proj_attr='proj4')
+    _setup_remapper(r)
+    assert isinstance(r.src_descriptor, LatLon2DGridDescriptor)
+    assert r.src_descriptor.dims == ['y', 'x']
+    assert r.dst_descriptor.mesh_name == 'stereo100km'
+
+    r = Remapper(method='bilinear')
+    r.src_from_lon_lat(latlon_file, lon_var='odd', lat_var='odd')
+    r.dst_global_lon_lat(2.0, 2.0, lon_min=0.0)
+    with pytest.raises(ValueError, match='unexpected sizes 3 and 3'):
+        _setup_remapper(r)
+
+    r = Remapper(method='bilinear')
+    r.src_from_lon_lat(latlon_file)
+    r.dst_from_points(points_file, 'stations', lon_var='plon',
+                      lat_var='plat')
+    _setup_remapper(r)
+    assert isinstance(r.dst_descriptor, PointCollectionDescriptor)
+    assert r.dst_descriptor.units == 'degrees'
+    assert r.dst_descriptor.dim_sizes == [3]
+
+    from pyremap_amd.descriptor.projection import projection_from_string
+    with pytest.raises(NotImplementedError, match='polar stereographic'):
+        projection_from_string('+proj=lcc +lat_1=30 +lat_2=60')
+    p = projection_from_string(proj_str)
+    x, y = p.forward(0.0, -71.0) if hasattr(p, 'forward') else p(0.0, -71.0)
+    assert abs(y - 2082760.1085) < 1e-3 and abs(x) < 1e-6
