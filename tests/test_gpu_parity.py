@@ -913,3 +913,134 @@ def test_sharded_remap_slabs_make_the_whole(dev):
     work = [int(plan.rowptr[b1] - plan.rowptr[b0]) + 2 * (b1 - b0)
             for b0, b1 in zip(part.bounds[:-1], part.bounds[1:])]
     assert max(work) < 0.4 * sum(work)
+
+
+def test_engine_odds_and_ends(dev, problem):
+    """Entry points the other tests do not reach: a plan from CSR arrays, a
+    hand-made row order, the Morton walk, the byte accounting of SURVEY 8(d),
+    the stream copy, ``out=`` on the permuting path, 0-based triplets, and
+    the argument errors of the Python layer."""
+    from oracle import oracle
+    from pyremap_amd import Remapper, engine, synthetic
+    from pyremap_amd.descriptor import MpasCellMeshDescriptor
+    m = synthetic.conservative_map(3000, (40, 50), 1, 6, seed=31, device=dev)
+    plan = engine.RemapPlan.from_triplets(m.row, m.col, m.S, m.frac_b,
+                                          m.n_a, m.n_b, device=dev)
+    rowptr, col, val = plan.to_host_csr()
+    frac_b = m.frac_b.cpu().numpy()
+    csr = oracle.OracleCSR(rowptr, col, val, (m.n_b, m.n_a))
+    x = torch.randn((m.n_a, 160), device=dev, dtype=torch.float64)
+    ref, mask = oracle.remap_flat(csr, frac_b, x.cpu().numpy(), False, 0.0)
+    ref[mask] = np.nan
+    # from_csr == from_triplets
+    again = engine.RemapPlan.from_csr(rowptr, col, val, frac_b, m.n_a,
+                                      device=dev)
+    assert (again.n_a, again.n_b, again.nnz) == (plan.n_a, plan.n_b,
+                                                 plan.nnz)
+    y = engine.remap_tensor(again, None, x, [0], engine.MODE_FRACB)
+    assert_bitwise(y.cpu().numpy(), ref, 'from_csr')
+    # processing orders never change results
+    plan.set_row_order(np.arange(m.n_b)[::-1].copy())
+    y = engine.remap_tensor(plan, m.dst_dims, x, [0], engine.MODE_FRACB)
+    assert_bitwise(y.cpu().numpy().reshape(m.n_b, -1), ref, 'reversed')
+    plan.set_grid_schedule(m.dst_dims, 'morton')
+    y = engine.remap_tensor(plan, m.dst_dims, x, [0], engine.MODE_FRACB)
+    assert_bitwise(y.cpu().numpy().reshape(m.n_b, -1), ref, 'morton')
+    plan.set_row_order(None)
+    assert plan.row_order is None
+    with pytest.raises(ValueError, match='row order must have'):
+        plan.set_row_order(np.arange(5))
+    with pytest.raises(ValueError, match='unknown schedule'):
+        plan.set_grid_schedule(m.dst_dims, 'hilbert')
+    with pytest.raises(ValueError, match='does not hold'):
+        plan.set_grid_schedule((7, 9), 'tile', (2, 2))
+    with pytest.raises(ValueError, match='do not hold n_b'):
+        engine.remap_tensor(plan, (7, 9), x, [0], engine.MODE_FRACB)
+    # SURVEY 8(d): S + col, rowptr, X once, Y once, frac_b
+    K = 160
+    assert plan.algorithmic_bytes(K) == plan.nnz * 12 + (m.n_b + 1) * 8 + \
+        m.n_a * K * 8 + m.n_b * K * 8 + m.n_b * 8
+    assert plan.algorithmic_bytes(K, 4, engine.MODE_MASKED) == \
+        plan.nnz * 12 + (m.n_b + 1) * 8 + m.n_a * K * 4 + m.n_b * K * 8
+    # the ceiling probe copies
+    src = torch.randint(0, 255, (1 << 20,), dtype=torch.uint8, device=dev)
+    dst = torch.zeros_like(src)
+    engine.stream_copy(dst, src)
+    assert torch.equal(dst, src)
+    # out= when the source axis is not leading enough to stride (permute path)
+    f = torch.randn((m.n_a, 3, 5), device=dev, dtype=torch.float64)
+    want = engine.remap_tensor(plan, m.dst_dims, f, [0], engine.MODE_FRACB)
+    g = f.permute(1, 0, 2).contiguous()              # (3, n_a, 5): k_inner 5
+    out = torch.empty((3,) + tuple(m.dst_dims) + (5,), device=dev,
+                      dtype=torch.float64)
+    got = engine.remap_tensor(plan, m.dst_dims, g, [1], engine.MODE_FRACB,
+                              out=out)
+    assert got.data_ptr() == out.data_ptr()
+    assert_bitwise(got.permute(1, 2, 0, 3).cpu().numpy(),
+                   want.cpu().numpy(), 'out= on the permute path')
+    # argument errors
+    with pytest.raises(ValueError, match='same length'):
+        engine.RemapPlan.from_triplets(m.row[:-1], m.col, m.S, m.frac_b,
+                                       m.n_a, m.n_b, device=dev)
+    with pytest.raises(ValueError, match='frac_b has'):
+        engine.RemapPlan.from_triplets(m.row, m.col, m.S, m.frac_b[:-1],
+                                       m.n_a, m.n_b, device=dev)
+    # other dtypes are upcast first, as scipy does; the raw entry refuses
+    xh = x.to(torch.float16)
+    yh = engine.remap_tensor(plan, m.dst_dims, xh, [0], engine.MODE_FRACB)
+    yd = engine.remap_tensor(plan, m.dst_dims, xh.to(torch.float64), [0],
+                             engine.MODE_FRACB)
+    assert_bitwise(yh.cpu().numpy(), yd.cpu().numpy(), 'f16 upcast')
+    with pytest.raises(TypeError, match='float64 or float32'):
+        engine.apply_strided(plan, xh, yd.reshape(m.n_b, K), n_batch=1,
+                             k_inner=K, x_row_stride=K, x_batch_stride=0,
+                             y_row_stride=K, y_batch_stride=0,
+                             mode=engine.MODE_FRACB)
+    # 0-based triplets through the Remapper front door
+    host = m.numpy()
+    src_d = MpasCellMeshDescriptor(mesh_name='toy', size=m.n_a)
+    from pyremap_amd import LatLonGridDescriptor
+    dst_d = LatLonGridDescriptor.create(np.linspace(-90, 90, 41),
+                                        np.linspace(-180, 180, 51))
+    r0 = Remapper.from_triplets(host['row'] - 1, host['col'] - 1, host['S'],
+                                host['frac_b'], src_d, dst_d, index_base=0)
+    y0 = r0.remap_array(x, [0])
+    assert_bitwise(y0.cpu().numpy().reshape(m.n_b, -1), ref, 'index_base 0')
+    with pytest.raises(ValueError, match='No mapping file'):
+        Remapper(src_descriptor=src_d, dst_descriptor=dst_d).remap_array(
+            x, [0])
+
+
+def test_ncremap_reads_netcdf4_input(tmp_path):
+    """A NetCDF-4 field file through ``ncremap``: read by the package's HDF5
+    reader, written as CDF-5 (the widest classic format; NetCDF-4 output
+    would need the netCDF4 library), same numbers as ``remap_numpy``."""
+    from pyremap_amd import (
+        LatLonGridDescriptor,
+        MpasCellMeshDescriptor,
+        Remapper,
+        synthetic,
+    )
+    from pyremap_amd.io.netcdf import file_format, open_dataset
+    src_file = os.path.join(os.path.dirname(__file__), 'golden', 'hdf5',
+                            'nc4_ref_latlon_to_mpas_cell.nc')
+    assert file_format(src_file) == 'NETCDF4'
+    n_cells = 7153
+    mm = synthetic.conservative_map(n_cells, (12, 24), 1, 5, seed=17)
+    map_path = str(tmp_path / 'map.nc')
+    mm.save(map_path)
+    r = Remapper(map_filename=map_path,
+                 src_descriptor=MpasCellMeshDescriptor(mesh_name='qu240',
+                                                       size=n_cells),
+                 dst_descriptor=LatLonGridDescriptor.create(
+                     np.linspace(-90, 90, 13), np.linspace(-180, 180, 25)))
+    out_path = str(tmp_path / 'out.nc')
+    r.ncremap(src_file, out_path, variable_list=['SST'])
+    assert file_format(out_path) == 'NETCDF3_64BIT_DATA'
+    on_disk = open_dataset(out_path)
+    in_mem = r.remap_numpy(open_dataset(src_file))
+    assert on_disk['SST'].dims == ('time', 'lat', 'lon')
+    assert_bitwise(on_disk['SST'].values, in_mem['SST'].values, 'nc4 in')
+    with pytest.raises(ValueError, match='are not in'):
+        r.ncremap(src_file, str(tmp_path / 'o2.nc'),
+                  variable_list=['no_such_variable'])

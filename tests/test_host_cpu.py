@@ -408,3 +408,114 @@ def test_utility_write_netcdf_fill_value_rules(tmp_path):
     d.write_netcdf(ds, str(tmp_path / 'desc.nc'))
     assert netcdf3.read(str(tmp_path / 'desc.nc')).variables['clean'] \
         .data.shape == (3, 4)
+
+
+def test_write_netcdf_strings_and_record_dimensions(tmp_path):
+    """Less-travelled corners of the writer: fixed-width string variables
+    become char arrays with a string dimension; only one record dimension
+    survives, and only if it leads every variable that uses it."""
+    import numpy as np
+
+    import pyremap_amd
+    from pyremap_amd.io import netcdf, netcdf3
+    ds = pyremap_amd.Dataset()
+    ds['names'] = pyremap_amd.DataArray(np.array(['alpha', 'be', 'gamma']),
+                                        dims=('n',))
+    ds['codes'] = pyremap_amd.DataArray(np.array([b'ab', b'cd', b'ef']),
+                                        dims=('n',))
+    ds['a'] = pyremap_amd.DataArray(np.arange(6.0).reshape(2, 3),
+                                    dims=('t', 'n'))
+    ds['b'] = pyremap_amd.DataArray(np.arange(6.0).reshape(3, 2),
+                                    dims=('n', 'u'))     # u never leads...
+    ds['c'] = pyremap_amd.DataArray(np.arange(2.0), dims=('u',))
+    path = str(tmp_path / 's.nc')
+    netcdf.write_netcdf(ds, path, format='NETCDF3_64BIT',
+                        unlimited_dims=['t', 'u'])
+    nc = netcdf3.read(path)
+    assert nc.variables['names'].data.shape == (3, 5)
+    assert nc.variables['names'].dims == ('n', 'string5')
+    assert bytes(nc.variables['names'].data[2]) == b'gamma'
+    assert nc.variables['codes'].dims == ('n', 'string2')
+    # ... so it is a fixed dimension in the file; 't' is the record one
+    assert nc.dimensions['u'] == 2 and nc.dimensions['t'] is None
+    back = netcdf.open_dataset(path)
+    assert back.encoding['unlimited_dims'] == ['t']
+    np.testing.assert_array_equal(back['a'].values, ds['a'].values)
+
+
+def test_mapping_file_errors(tmp_path):
+    import numpy as np
+
+    from pyremap_amd.io import mapfile, netcdf3
+    with pytest.raises(FileNotFoundError):
+        mapfile.read_mapping(str(tmp_path / 'nothing.nc'))
+    junk = tmp_path / 'junk.nc'
+    junk.write_bytes(b'this is not a mapping file at all')
+    with pytest.raises(ValueError, match='not a NetCDF, HDF5 or npz'):
+        mapfile.read_mapping(str(junk))
+    # a NetCDF file that lacks S
+    path = str(tmp_path / 'partial.nc')
+    netcdf3.write(path, {'n_s': 2, 'n_b': 2, 'n_a': 2, 'r': 1},
+                  [netcdf3.Variable('row', ('n_s',), np.array([1, 2], 'i4')),
+                   netcdf3.Variable('col', ('n_s',), np.array([1, 2], 'i4')),
+                   netcdf3.Variable('frac_b', ('n_b',), np.ones(2)),
+                   netcdf3.Variable('src_grid_dims', ('r',),
+                                    np.array([2], 'i4')),
+                   netcdf3.Variable('dst_grid_dims', ('r',),
+                                    np.array([2], 'i4'))])
+    with pytest.raises(ValueError, match=r"missing variables \['S'\]"):
+        mapfile.read_mapping(path)
+    # npz archives: n_a falls back to the product of the source grid dims
+    npz = str(tmp_path / 'm.npz')
+    np.savez(npz, row=np.array([1, 2], 'i4'), col=np.array([1, 6], 'i4'),
+             S=np.ones(2), frac_b=np.ones(2),
+             src_grid_dims=np.array([3, 2], 'i4'),
+             dst_grid_dims=np.array([2], 'i4'))
+    m = mapfile.read_mapping(npz)
+    assert (m.n_a, m.n_b, m.n_s) == (6, 2, 2)
+    np.savez(str(tmp_path / 'bad.npz'), row=np.array([1], 'i4'))
+    with pytest.raises(ValueError, match='missing variables'):
+        mapfile.read_mapping(str(tmp_path / 'bad.npz'))
+
+
+def test_mpas_grid_info_and_setup_errors(tmp_path):
+    """``src_from_mpas`` / ``dst_from_mpas`` (remapper.py:375-421): cell, edge
+    and vertex descriptors from an MPAS mesh file; unknown kinds and tools."""
+    import numpy as np
+
+    import pyremap_amd
+    from pyremap_amd.io.netcdf import write_netcdf
+    from pyremap_amd.remapper.setup import _get_descriptor, _setup_remapper
+    rng = np.random.default_rng(3)
+    ds = pyremap_amd.Dataset(attrs={'mesh_name': 'from_file'})
+    for kind, n in (('Cell', 7), ('Edge', 11), ('Vertex', 5)):
+        dim = {'Cell': 'nCells', 'Edge': 'nEdges', 'Vertex': 'nVertices'}[kind]
+        ds[f'lat{kind}'] = pyremap_amd.DataArray(rng.random(n), dims=(dim,))
+        ds[f'lon{kind}'] = pyremap_amd.DataArray(rng.random(n), dims=(dim,))
+    mesh = str(tmp_path / 'mesh.nc')
+    write_netcdf(ds, mesh)
+    r = pyremap_amd.Remapper()
+    r.src_from_mpas(mesh, 'tiny', mesh_type='edge')
+    r.dst_from_mpas(mesh, 'tiny_v', mesh_type='vertex')
+    r.method = 'bilinear'
+    _setup_remapper(r)
+    assert r.src_descriptor.dims == ['nEdges']
+    assert r.src_descriptor.dim_sizes == [11]
+    assert r.dst_descriptor.dims == ['nVertices']
+    assert sorted(r.dst_descriptor.coords) == ['lat_vertex', 'lon_vertex']
+    assert r.map_filename == 'map_tiny_to_tiny_v_esmfbilin.nc'
+    d = pyremap_amd.MpasCellMeshDescriptor(mesh)          # name from the file
+    assert d.mesh_name == 'from_file' and d.dim_sizes == [7]
+    with pytest.raises(ValueError, match='Unexpected MPAS mesh type'):
+        _get_descriptor({'type': 'mpas', 'filename': mesh, 'name': 'x',
+                         'mpas_mesh_type': 'face'})
+    with pytest.raises(ValueError, match='Unexpected grid type'):
+        _get_descriptor({'type': 'hexagons'})
+    bad = pyremap_amd.Remapper(map_tool='scrip')
+    bad.src_from_mpas(mesh, 'tiny')
+    bad.dst_global_lon_lat(10.0, 10.0)
+    with pytest.raises(KeyError):
+        _setup_remapper(bad)          # default name needs a known tool
+    bad.map_filename = 'given.nc'
+    with pytest.raises(ValueError, match='Unexpected map_tool scrip'):
+        _setup_remapper(bad)
