@@ -31,6 +31,8 @@ def record(tag, path):
             if isinstance(obj, h5py.Group):
                 visit(obj, f'{prefix}{name}/')
                 continue
+            if not isinstance(obj, h5py.Dataset):
+                continue                       # a committed datatype
             for k, v in obj.attrs.items():
                 note(f'{tag}:{prefix}{name}@{k}', v)
             if obj.shape is not None:
@@ -93,6 +95,30 @@ def classic():
         for i in range(300):
             big.create_dataset(f'v{i:03d}', data=np.int16(i))
         f.create_dataset('empty', shape=(0, 4), dtype='f8')
+        # 70 chunks: more than one level in the chunk B-tree
+        f.create_dataset('many_chunks',
+                         data=rng.integers(0, 1000, 700).astype('i4'),
+                         chunks=(10,))
+        # compact layout (data inside the object header)
+        space = h5py.h5s.create_simple((6,))
+        dcpl = h5py.h5p.create(h5py.h5p.DATASET_CREATE)
+        dcpl.set_layout(h5py.h5d.COMPACT)
+        did = h5py.h5d.create(f.id, b'compact_i2', h5py.h5t.STD_I16LE, space,
+                              dcpl=dcpl)
+        did.write(h5py.h5s.ALL, h5py.h5s.ALL,
+                  np.arange(-3, 3, dtype='i2'))
+        # an enumerated type (read as its integer base) and a committed
+        # (shared) datatype
+        enum = h5py.enum_dtype({'LAND': 0, 'OCEAN': 1, 'ICE': 2},
+                               basetype='i1')
+        f.create_dataset('enum_mask', data=np.array([0, 1, 1, 2], 'i1'),
+                         dtype=enum)
+        f['a_named_type'] = np.dtype('<f4')
+        f.create_dataset('uses_named_type', data=np.arange(5, dtype='f4'),
+                         dtype=f['a_named_type'])
+        f.create_dataset('space_padded',
+                         data=np.array([b'ab', b'c'], dtype='S4'),
+                         dtype=h5py.string_dtype('ascii', 4))
     record('classic', path)
 
 
@@ -117,6 +143,14 @@ def latest():
                          data=rng.random((10, 10)).astype('f4'),
                          chunks=(4, 4), fillvalue=np.float32(9.0))
         f.create_dataset('compact', data=np.arange(8, dtype='i1'))
+        # implicit chunk index: unfiltered chunks allocated up front
+        space = h5py.h5s.create_simple((8, 6))
+        dcpl = h5py.h5p.create(h5py.h5p.DATASET_CREATE)
+        dcpl.set_chunk((4, 3))
+        dcpl.set_alloc_time(h5py.h5d.ALLOC_TIME_EARLY)
+        did = h5py.h5d.create(f.id, b'implicit_early', h5py.h5t.IEEE_F64LE,
+                              space, dcpl=dcpl)
+        did.write(h5py.h5s.ALL, h5py.h5s.ALL, rng.random((8, 6)))
         wide = f.create_group('wide')            # deeper v2 B-tree
         for i in range(400):
             wide.create_dataset(f'dataset_with_a_long_name_{i:04d}',

@@ -519,3 +519,60 @@ def test_mpas_grid_info_and_setup_errors(tmp_path):
     bad.map_filename = 'given.nc'
     with pytest.raises(ValueError, match='Unexpected map_tool scrip'):
         _setup_remapper(bad)
+
+
+def test_xr_lite_container_api():
+    """The stand-in for xarray's Dataset / DataArray: what the remapping
+    path and user code touch."""
+    import numpy as np
+
+    from pyremap_amd import DataArray, Dataset
+    a = DataArray(np.arange(6.0).reshape(2, 3))
+    assert a.dims == ('dim_0', 'dim_1') and a.ndim == 2
+    assert a.sizes == {'dim_0': 2, 'dim_1': 3}
+    with pytest.raises(ValueError, match='different number of dimensions'):
+        DataArray(np.zeros((2, 3)), dims=('x',))
+    b = DataArray(np.ma.masked_array([1.0, 2.0, 3.0], mask=[0, 1, 0]),
+                  dims='x', name='b', attrs={'units': 'm'},
+                  coords={'x': [10, 20, 30]})
+    assert np.isnan(b.values[1]) and b.values[0] == 1.0   # masked -> NaN
+    assert b.units == 'm' and b.x.values.tolist() == [10, 20, 30]
+    with pytest.raises(AttributeError):
+        b.nothing
+    assert 'DataArray' in repr(b) and np.asarray(b).shape == (3,)
+    c = b.copy()
+    c.values[0] = 99.0
+    assert b.values[0] == 1.0
+    d = DataArray.from_dict(b.to_dict())
+    assert d.dims == ('x',) and d.attrs == {'units': 'm'}
+    assert d.coords['x'].values.tolist() == [10, 20, 30]
+
+    ds = Dataset({'t': (('time', 'x'), np.zeros((2, 3)), {'long_name': 'T'}),
+                  'flag': {'dims': ('x',), 'data': [1, 0, 1]}},
+                 coords={'x': [10, 20, 30]}, attrs={'title': 'demo'})
+    ds['raw'] = np.arange(2.0)                  # bare array: default dims
+    assert list(ds.data_vars) == ['t', 'flag', 'raw']
+    assert 't' in ds.data_vars and 'x' not in ds.data_vars
+    assert 'x' in ds.coords and 't' not in ds.coords
+    assert ds.data_vars['t'].attrs['long_name'] == 'T'
+    assert [k for k, _ in ds.data_vars.items()] == ['t', 'flag', 'raw']
+    assert len(ds.data_vars.values()) == 3 and ds.data_vars.keys()[0] == 't'
+    with pytest.raises(KeyError):
+        ds.data_vars['x']
+    with pytest.raises(KeyError):
+        ds['missing']
+    assert ds.title == 'demo' and ds.t.shape == (2, 3)
+    with pytest.raises(AttributeError):
+        ds.nothing
+    assert 'time' in repr(ds) and list(iter(ds)) == ['t', 'flag', 'raw']
+    assert ds['t'].coords['x'].values.tolist() == [10, 20, 30]
+    with pytest.raises(ValueError, match='conflicting sizes'):
+        ds['bad'] = (('x',), np.zeros(4))
+    less = ds.drop_vars('flag')
+    assert 'flag' not in less and 'flag' in ds
+    with pytest.raises(ValueError, match='not in the dataset'):
+        ds.drop_vars(['flag', 'nope'])
+    doubled = ds.map(lambda v: v.values * 2 if v.name == 'raw' else v)
+    assert doubled['raw'].values.tolist() == [0.0, 2.0]
+    ds['t'].attrs['units'] = 'K'                # attrs are shared, not copied
+    assert ds['t'].attrs['units'] == 'K'
