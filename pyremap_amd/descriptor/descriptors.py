@@ -64,12 +64,9 @@ class MeshDescriptor:
 
     def write_netcdf(self, ds, filename):
         """``mesh_descriptor.py:93-112``: write ``ds`` in this descriptor's
-        ``format`` (NetCDF-4 is not writable here: the widest classic format
-        is used instead)."""
+        ``format``."""
         from pyremap_amd.utility import write_netcdf
-        fmt = self.format if self.format.startswith('NETCDF3') else \
-            'NETCDF3_64BIT_DATA'
-        write_netcdf(ds, filename, format=fmt, engine=self.engine,
+        write_netcdf(ds, filename, format=self.format, engine=self.engine,
                      logger=self.logger)
 
     def mesh_name_from_attr(self, ds):

@@ -9,8 +9,9 @@ written only for numeric variables that actually hold NaNs, with netCDF4's
 default fill value for the dtype (:38-51).
 
 Classic formats (CDF-1/2/5) are handled by :mod:`pyremap_amd.io.netcdf3`,
-NetCDF-4/HDF5 input by :mod:`pyremap_amd.io.netcdf4_lite` (this package's own
-read-only HDF5 reader); classic formats are written.
+NetCDF-4/HDF5 by :mod:`pyremap_amd.io.netcdf4_lite` (read) and
+:mod:`pyremap_amd.io.hdf5_write` (write): this package's own HDF5 code, as the
+images have neither netCDF4 nor h5py.
 """
 import os
 from collections import OrderedDict
@@ -140,11 +141,12 @@ def write_netcdf(ds, filename, format='NETCDF3_64BIT', fillvalues=None,
     ``_FillValue`` = the default fill of their dtype and have their NaNs
     stored as that value; all other variables get no ``_FillValue``.
     """
-    if format not in netcdf3.FORMATS:
+    nc4 = format in ('NETCDF4', 'NETCDF4_CLASSIC')
+    if not nc4 and format not in netcdf3.FORMATS:
         raise NotImplementedError(
-            f'format {format!r}: only the classic formats '
-            f'{sorted(netcdf3.FORMATS)} can be written without netCDF4')
-    version = netcdf3.FORMATS[format]
+            f'format {format!r}: expected NETCDF4, NETCDF4_CLASSIC or one '
+            f'of the classic formats {sorted(netcdf3.FORMATS)}')
+    version = None if nc4 else netcdf3.FORMATS[format]
     if fillvalues is None:
         fillvalues = DEFAULT_FILLVALS
     if unlimited_dims is None:
@@ -199,5 +201,17 @@ def write_netcdf(ds, filename, format='NETCDF3_64BIT', fillvalues=None,
         attrs[key] = value if isinstance(value, (str, bytes, np.ndarray,
                                                  int, float, np.generic)) \
             else str(value)
+    if nc4:
+        from pyremap_amd.io.hdf5_write import write_netcdf4
+        sizes = OrderedDict()
+        for var in out_vars:
+            for dim, size in zip(var.dims, var.data.shape):
+                sizes.setdefault(dim, int(size))
+        write_netcdf4(filename, sizes,
+                      [(v.name, v.dims, v.data, v.attrs) for v in out_vars],
+                      attrs=attrs,
+                      unlimited=[d for d, n in dimensions.items()
+                                 if n is None])
+        return
     netcdf3.write(filename, dimensions, out_vars, attrs=attrs,
                   version=version)

@@ -69,8 +69,8 @@ def _remap_file(remapper, in_filename, out_filename, variable_list,
     encoding = getattr(ds, 'encoding', {})
     ds_out = _remap_numpy(remapper, ds, renormalize)
     fmt = encoding.get('format') or file_format(in_filename)
-    if fmt not in FORMATS:
-        fmt = 'NETCDF3_64BIT_DATA'   # HDF5 input: write the widest classic
+    if fmt not in FORMATS and fmt != 'NETCDF4':
+        fmt = 'NETCDF3_64BIT_DATA'
     write_netcdf(ds_out, out_filename, format=fmt,
                  unlimited_dims=encoding.get('unlimited_dims', []))
     if logger is not None:

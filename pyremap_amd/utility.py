@@ -14,12 +14,11 @@ def write_netcdf(ds, filename, format, engine=None, logger=None,
     hold NaNs get ``_FillValue`` = the default fill value of their type, all
     other variables none (``utility.py:38-51``).
 
-    ``format`` is one of the classic formats (``NETCDF3_CLASSIC``,
-    ``NETCDF3_64BIT``, ``NETCDF3_64BIT_DATA``); the reference writes the last
-    one through NetCDF-4 + ``ncks -5`` (:53-72), here it is written directly.
-    ``NETCDF4`` / ``NETCDF4_CLASSIC`` need the netCDF4 library, which the GPU
-    images do not have: a ``NotImplementedError`` says so.  ``engine`` is
-    accepted for compatibility and ignored.
+    ``format``: ``NETCDF4`` / ``NETCDF4_CLASSIC`` (this package's HDF5
+    writer) or a classic format (``NETCDF3_CLASSIC``, ``NETCDF3_64BIT``,
+    ``NETCDF3_64BIT_DATA``; the reference writes the last one through
+    NetCDF-4 + ``ncks -5``, :53-72, here it is written directly).  ``engine``
+    is accepted for compatibility and ignored.
     """
     if fillvalues is not None:
         import numpy as np

@@ -1013,8 +1013,8 @@ def test_engine_odds_and_ends(dev, problem):
 
 def test_ncremap_reads_netcdf4_input(tmp_path):
     """A NetCDF-4 field file through ``ncremap``: read by the package's HDF5
-    reader, written as CDF-5 (the widest classic format; NetCDF-4 output
-    would need the netCDF4 library), same numbers as ``remap_numpy``."""
+    reader and answered in NetCDF-4 by its HDF5 writer (as NCO keeps the
+    input's format), same numbers as ``remap_numpy``."""
     from pyremap_amd import (
         LatLonGridDescriptor,
         MpasCellMeshDescriptor,
@@ -1036,7 +1036,7 @@ def test_ncremap_reads_netcdf4_input(tmp_path):
                      np.linspace(-90, 90, 13), np.linspace(-180, 180, 25)))
     out_path = str(tmp_path / 'out.nc')
     r.ncremap(src_file, out_path, variable_list=['SST'])
-    assert file_format(out_path) == 'NETCDF3_64BIT_DATA'
+    assert file_format(out_path) == 'NETCDF4'
     on_disk = open_dataset(out_path)
     in_mem = r.remap_numpy(open_dataset(src_file))
     assert on_disk['SST'].dims == ('time', 'lat', 'lon')

@@ -127,3 +127,99 @@ def test_read_mapping_netcdf4(expected):
         np.testing.assert_array_equal(got, expected[f'map_nc4:/{name}'])
         assert got.dtype.isnative
     assert m.src_grid_rank == 2 and m.dst_grid_rank == 2
+
+
+def test_netcdf4_writer_round_trip(tmp_path):
+    """``io/hdf5_write.py``: what it writes, the reader reads back -- values,
+    dtypes, dimension names (through ``DIMENSION_LIST`` object references in
+    the global heap), coordinate variables as dimension scales, placeholder
+    scales for dimensions without a variable, attributes of every kind."""
+    from collections import OrderedDict
+
+    from pyremap_amd.io.hdf5_write import write_netcdf4
+    rng = np.random.default_rng(0)
+    dims = OrderedDict([('time', 2), ('lat', 3), ('lon', 4), ('nchar', 5),
+                        ('big', 300)])
+    label = np.array([list(b'hello'), list(b'world')],
+                     dtype='u1').view('S1').reshape(2, 5)
+    variables = [
+        ('lat', ('lat',), np.linspace(-60, 60, 3), {'units': 'degrees_north'}),
+        ('lon', ('lon',), np.linspace(0, 270, 4).astype('>f8'), {}),
+        ('temp', ('time', 'lat', 'lon'),
+         rng.standard_normal((2, 3, 4)).astype('f4'),
+         {'units': 'K', '_FillValue': np.float32(9.96921e36),
+          'valid_range': np.array([-5.0, 5.0], 'f4'),
+          'flag_values': np.array([1, 2, 3], 'i1')}),
+        ('count', ('time',), np.array([3, 4], 'i4'), {}),
+        ('wide', ('big', 'lon'), rng.integers(0, 1 << 40, (300, 4)), {}),
+        ('u16', ('lat',), np.array([1, 2, 65535], 'u2'), {}),
+        ('scalar', (), np.float64(2.5), {'long_name': 'a scalar variable'}),
+        ('zeros', ('time', 'lat'), np.zeros((2, 3)), {}),
+        ('label', ('time', 'nchar'), label, {}),
+    ]
+    for i in range(60):           # many links: one wide symbol-table node
+        variables.append((f'v{i:02d}', ('lat',), rng.random(3), {}))
+    attrs = OrderedDict([('title', 'written here'),
+                         ('history', 'line 1\nline 2'),
+                         ('version', np.int32(3)),
+                         ('scale', 0.5), ('levels', [1, 2, 3])])
+    path = str(tmp_path / 'w.nc')
+    write_netcdf4(path, dims, variables, attrs=attrs, unlimited=['time'])
+    with NetCDF4File(path) as nc:
+        assert dict(nc.dimensions) == dict(dims)
+        assert list(nc.dimensions) == list(dims)          # _Netcdf4Dimid
+        for name in ('time', 'nchar', 'big'):
+            assert name not in nc.variables               # pure dimensions
+        for name, vdims, data, vattrs in variables:
+            var = nc.variables[name]
+            assert var.dims == tuple(vdims), name
+            got = var.read()
+            want = np.asarray(data)
+            assert got.dtype == want.dtype.newbyteorder('='), name
+            np.testing.assert_array_equal(got, want, err_msg=name)
+            for k, v in vattrs.items():
+                np.testing.assert_array_equal(np.asarray(var.attrs[k]),
+                                              np.asarray(v), err_msg=k)
+        assert nc.attrs['title'] == 'written here'
+        assert nc.attrs['history'] == 'line 1\nline 2'
+        assert nc.attrs['version'] == 3 and nc.attrs['scale'] == 0.5
+        assert np.asarray(nc.attrs['levels']).tolist() == [1, 2, 3]
+    with hdf5_lite.File(path) as f:
+        assert f.superblock_version == 0
+        assert len(f.root.keys()) == len(variables) + 3
+    # a variable named like a dimension must be that dimension's coordinate
+    with pytest.raises(ValueError, match='shares its name'):
+        write_netcdf4(path, {'x': 2, 'y': 3},
+                      [('x', ('y',), np.zeros(3), {})])
+    with pytest.raises(ValueError, match='does not match'):
+        write_netcdf4(path, {'x': 2}, [('v', ('x',), np.zeros(3), {})])
+
+
+def test_dataset_to_netcdf4_and_back(tmp_path):
+    """``write_netcdf(format='NETCDF4')`` -> ``open_dataset``: a Dataset with
+    NaNs, a coordinate, text and a record dimension survives the round trip
+    (the record dimension becomes a fixed one: contiguous storage)."""
+    import pyremap_amd
+    from pyremap_amd.io.netcdf import file_format, write_netcdf
+    ds = pyremap_amd.Dataset(attrs={'title': 'round trip'})
+    t = np.arange(24.0).reshape(2, 3, 4)
+    t[0, 1, 2] = np.nan
+    ds['lat'] = pyremap_amd.DataArray(np.array([-10.0, 0.0, 10.0]),
+                                      dims=('lat',), attrs={'units': 'deg'})
+    ds['t'] = pyremap_amd.DataArray(t, dims=('Time', 'lat', 'lon'),
+                                    attrs={'units': 'K'})
+    ds['xtime'] = pyremap_amd.DataArray(
+        np.frombuffer(b'0001-01-010001-01-02', dtype='S1').reshape(2, 10),
+        dims=('Time', 'StrLen'))
+    path = str(tmp_path / 'ds4.nc')
+    write_netcdf(ds, path, format='NETCDF4', unlimited_dims=['Time'])
+    assert file_format(path) == 'NETCDF4'
+    back = netcdf.open_dataset(path)
+    assert back['t'].dims == ('Time', 'lat', 'lon')
+    np.testing.assert_array_equal(back['t'].values, t)       # NaN restored
+    assert back['t'].attrs['units'] == 'K'
+    assert 'lat' in back.coords and back['lat'].attrs['units'] == 'deg'
+    assert bytes(back['xtime'].values[1]) == b'0001-01-02'
+    assert back.attrs['title'] == 'round trip'
+    raw = netcdf.open_dataset(path, mask_and_scale=False)
+    assert raw['t'].values[0, 1, 2] == 9.969209968386869e+36

@@ -401,7 +401,24 @@ def test_utility_write_netcdf_fill_value_rules(tmp_path):
     assert nc.variables['holes'].attrs['_FillValue'] == -1e30
     import pytest
     with pytest.raises(NotImplementedError, match='classic formats'):
-        utility.write_netcdf(ds, path, format='NETCDF4')
+        utility.write_netcdf(ds, path, format='NETCDF5')
+    # NetCDF-4 through the package's own HDF5 writer: same fill-value rules
+    p4 = str(tmp_path / 'out4.nc')
+    utility.write_netcdf(ds, p4, format='NETCDF4')
+    assert pyremap_amd.io.netcdf.file_format(p4) == 'NETCDF4'
+    from pyremap_amd.io.netcdf4_lite import NetCDF4File
+    with NetCDF4File(p4) as nc4:
+        assert dict(nc4.dimensions) == {'y': 3, 'x': 4}
+        assert '_FillValue' not in nc4.variables['clean'].attrs
+        assert nc4.variables['holes'].attrs['_FillValue'] == \
+            9.969209968386869e+36
+        assert nc4.variables['holes'].dims == ('y', 'x')
+        assert nc4.variables['count'].dtype == np.int32
+    back4 = pyremap_amd.io.netcdf.open_dataset(p4)
+    assert np.isnan(back4['holes'].values[1, 2])
+    np.testing.assert_array_equal(back4['clean'].values, a)
+    np.testing.assert_array_equal(back4['holes32'].values[0],
+                                  b.astype(np.float32)[0])
     # the descriptor method of the same name
     d = pyremap_amd.get_lat_lon_descriptor(30.0, 30.0)
     d.format = 'NETCDF3_64BIT'
