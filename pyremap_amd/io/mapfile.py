@@ -9,10 +9,11 @@ Here the same members are read without xarray:
 
 * NetCDF-3 (CDF-1 / CDF-2 / CDF-5) with :mod:`pyremap_amd.io.netcdf3`;
 * NetCDF-4 / HDF5 (what ESMF writes with ``--netcdf4``,
-  ``build_map.py:166``) with ``h5py`` or ``netCDF4`` when importable;
+  ``build_map.py:166``) with :mod:`pyremap_amd.io.netcdf4_lite`;
 * ``.npz`` with the same variable names (handy for synthetic maps).
 """
 import os
+from collections import OrderedDict
 
 import numpy as np
 
@@ -119,10 +120,13 @@ def _read_hdf5(filename):
 
 
 def write_mapping(filename, n_a, n_b, src_grid_dims, dst_grid_dims, row, col,
-                  S, frac_b, attrs=None):
+                  S, frac_b, attrs=None, format=None):
     """
     Write a mapping file with the schema of SURVEY.md Appendix A.
-    ``*.npz`` -> numpy archive; anything else -> NetCDF-3 64-bit offset.
+    ``*.npz`` -> numpy archive; otherwise ``format`` is ``'NETCDF4'`` (what
+    ``ESMF_RegridWeightGen --netcdf4`` writes, ``build_map.py:166``), or a
+    classic format; the default is NetCDF-3 64-bit offset, switching to the
+    64-bit-data flavour when a variable outgrows 4 GiB.
     ``src_grid_dims`` / ``dst_grid_dims`` are in FILE (Fortran) order and
     ``row`` / ``col`` are 1-based, exactly as ESMF writes them.
     """
@@ -138,17 +142,30 @@ def write_mapping(filename, n_a, n_b, src_grid_dims, dst_grid_dims, row, col,
                  row=row, col=col, S=S, frac_b=frac_b)
         return
     from pyremap_amd.io import netcdf3
-    dims = {'n_a': int(n_a), 'n_b': int(n_b), 'n_s': int(S.shape[0]),
-            'src_grid_rank': int(src_grid_dims.shape[0]),
-            'dst_grid_rank': int(dst_grid_dims.shape[0])}
+    dims = OrderedDict([
+        ('n_a', int(n_a)), ('n_b', int(n_b)), ('n_s', int(S.shape[0])),
+        ('src_grid_rank', int(src_grid_dims.shape[0])),
+        ('dst_grid_rank', int(dst_grid_dims.shape[0]))])
     variables = [
-        netcdf3.Variable('src_grid_dims', ('src_grid_rank',), src_grid_dims),
-        netcdf3.Variable('dst_grid_dims', ('dst_grid_rank',), dst_grid_dims),
-        netcdf3.Variable('col', ('n_s',), col),
-        netcdf3.Variable('row', ('n_s',), row),
-        netcdf3.Variable('S', ('n_s',), S),
-        netcdf3.Variable('frac_b', ('n_b',), frac_b),
+        ('src_grid_dims', ('src_grid_rank',), src_grid_dims),
+        ('dst_grid_dims', ('dst_grid_rank',), dst_grid_dims),
+        ('col', ('n_s',), col),
+        ('row', ('n_s',), row),
+        ('S', ('n_s',), S),
+        ('frac_b', ('n_b',), frac_b),
         # keeps n_a a used dimension, as in ESMF files
-        netcdf3.Variable('area_a', ('n_a',), np.zeros(int(n_a))),
+        ('area_a', ('n_a',), np.zeros(int(n_a))),
     ]
-    netcdf3.write(filename, dims, variables, attrs=attrs or {}, version=2)
+    if format is None:
+        big = max(v[2].nbytes for v in variables) >= (1 << 32) - 4
+        format = 'NETCDF3_64BIT_DATA' if big else 'NETCDF3_64BIT'
+    if format in ('NETCDF4', 'NETCDF4_CLASSIC'):
+        from pyremap_amd.io.hdf5_write import write_netcdf4
+        write_netcdf4(filename, dims, [v + ({},) for v in variables],
+                      attrs=attrs or {})
+        return
+    if format not in netcdf3.FORMATS:
+        raise ValueError(f'unknown mapping-file format {format!r}')
+    netcdf3.write(filename, dims,
+                  [netcdf3.Variable(*v) for v in variables],
+                  attrs=attrs or {}, version=netcdf3.FORMATS[format])

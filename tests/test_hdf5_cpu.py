@@ -223,3 +223,27 @@ def test_dataset_to_netcdf4_and_back(tmp_path):
     assert back.attrs['title'] == 'round trip'
     raw = netcdf.open_dataset(path, mask_and_scale=False)
     assert raw['t'].values[0, 1, 2] == 9.969209968386869e+36
+
+
+def test_mapping_file_written_as_netcdf4(tmp_path, expected):
+    """``write_mapping(format='NETCDF4')``: the layout ESMF --netcdf4 uses,
+    read back by ``read_mapping`` unchanged."""
+    m = mapfile.read_mapping(os.path.join(HERE, 'map_nc4.nc'))
+    for fmt in ('NETCDF4', 'NETCDF3_64BIT_DATA', None):
+        path = str(tmp_path / f'copy_{fmt}.nc')
+        mapfile.write_mapping(path, m.n_a, m.n_b, m.src_grid_dims,
+                              m.dst_grid_dims, m.row, m.col, m.S, m.frac_b,
+                              attrs={'normalization': 'destarea'},
+                              format=fmt)
+        want = {'NETCDF4': 'NETCDF4', None: 'NETCDF3_64BIT'}.get(fmt, fmt)
+        assert netcdf.file_format(path) == want
+        back = mapfile.read_mapping(path)
+        assert (back.n_a, back.n_b, back.n_s) == (m.n_a, m.n_b, m.n_s)
+        for name in ('row', 'col', 'S', 'frac_b', 'src_grid_dims',
+                     'dst_grid_dims'):
+            np.testing.assert_array_equal(getattr(back, name),
+                                          getattr(m, name))
+    with pytest.raises(ValueError, match='unknown mapping-file format'):
+        mapfile.write_mapping(str(tmp_path / 'x.nc'), m.n_a, m.n_b,
+                              m.src_grid_dims, m.dst_grid_dims, m.row, m.col,
+                              m.S, m.frac_b, format='GRIB')
