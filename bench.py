@@ -87,6 +87,11 @@ def init_dist(args):
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl', rank=rank, world_size=world,
                                 device_id=torch.device('cuda', local))
+        # the first collective makes RCCL connect (and print its version
+        # banner on stdout): have that happen here, not after the JSON line
+        dist.barrier()
+        torch.cuda.synchronize()
+        sys.stdout.flush()
     return rank, world, local, dist
 
 
@@ -505,10 +510,21 @@ def main():
         'bcast_ms': res['bcast_ms'],
         'extra': extra,
     }
-    print(json.dumps(line))
+    # the JSON line is the LAST thing on stdout: every rank is done first
+    # (RCCL prints a version banner on stdout when its communicator comes up
+    # or goes down, whichever happens to be later)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    try:
+        # ... through C stdio, which a pipe makes fully buffered: flush it,
+        # or the banner lands behind the JSON line at exit
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    sys.stdout.flush()
+    print(json.dumps(line), flush=True)
 
 
 if __name__ == '__main__':
