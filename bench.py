@@ -78,6 +78,11 @@ def init_dist(args):
                 f'python -m torch.distributed.run --nproc-per-node '
                 f'{args.gpus} bench.py --gpus {args.gpus}')
         raise SystemExit(f'WORLD_SIZE={world} but --gpus {args.gpus}')
+    if rank != 0:
+        # only rank 0 reports: nothing another rank (or the libraries it
+        # loads) writes may land behind rank 0's JSON line
+        sys.stdout.flush()
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
     torch.cuda.set_device(local)
     dist = None
     if world > 1 or args.force_dist:
