@@ -60,6 +60,10 @@ def parse_args():
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-extra', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
+    ap.add_argument('--backend', default='nccl',
+                    help="torch.distributed backend: 'nccl' (= RCCL, the "
+                         "real thing) or 'gloo' to rehearse the N > 1 code "
+                         "path with several ranks sharing one GPU")
     ap.add_argument('--force-dist', action='store_true',
                     help='initialise RCCL even with one rank (exercises '
                          'the N > 1 code path on a 1-GPU box)')
@@ -83,6 +87,8 @@ def init_dist(args):
         # loads) writes may land behind rank 0's JSON line
         sys.stdout.flush()
         os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
+    if args.backend != 'nccl':
+        local = local % max(torch.cuda.device_count(), 1)   # rehearsal
     torch.cuda.set_device(local)
     dist = None
     if world > 1 or args.force_dist:
@@ -90,8 +96,12 @@ def init_dist(args):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', rank=rank, world_size=world,
-                                device_id=torch.device('cuda', local))
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world,
+                                    device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(args.backend, rank=rank,
+                                    world_size=world)
         # the first collective makes RCCL connect (and print its version
         # banner on stdout): have that happen here, not after the JSON line
         dist.barrier()
