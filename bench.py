@@ -52,7 +52,7 @@ def parse_args():
     ap.add_argument('--locality', default='raster',
                     choices=['raster', 'none'])
     ap.add_argument('--shard', default='rows', choices=['rows', 'fields'])
-    ap.add_argument('--sets', type=int, default=2,
+    ap.add_argument('--sets', type=int, default=3,
                     help='distinct X/Y buffer sets rotated over the steps')
     ap.add_argument('--tune', default='',
                     help='comma-separated remap_apply_args.tune values')
@@ -246,6 +246,7 @@ def run_workload(name, args, rank, world, dist, K=None, mode=None,
     launch(0)
     torch.cuda.synchronize()
     wall, mean_ms, per_launch = time_steps(launch, steps, warmup, dist)
+    in_order = [round(t, 4) for t in per_launch[:20]]
     per_launch.sort()
     # algorithmic bytes of ONE launch on this rank; a row
     # shard reads at most the whole of X
@@ -257,7 +258,9 @@ def run_workload(name, args, rank, world, dist, K=None, mode=None,
         ms_per_step=wall * 1e3 / steps,
         kernel_ms_mean=mean_ms, kernel_ms_median=per_launch[len(per_launch)
                                                             // 2],
-        kernel_ms_min=per_launch[0],
+        kernel_ms_min=per_launch[0], kernel_ms_max=per_launch[-1],
+        kernel_ms_second_pass_in_order=in_order,
+        touched_frac=plan.touched_sources() / max(plan.n_a, 1),
         cell_fields_per_s=m.n_b * K * steps / wall,
         dst_cells_per_s_per_batch=m.n_b * steps / wall,
         bytes_alg=bytes_alg, bytes_alg_read=bytes_alg - plan.n_b * K_local * 8,
@@ -491,6 +494,7 @@ def main():
             'nnz_csr': res['nnz_csr'], 'fields_K': K,
             'mode': res['mode'], 'layout': res['layout'],
             'locality': args.locality,
+            'touched_frac': res['touched_frac'],
             'sharding': 'none' if world == 1 else
             (f'dst rows over {world} GPUs, X broadcast once (RCCL) before '
              f'the timed region' if args.shard == 'rows' else
@@ -514,6 +518,9 @@ def main():
             'kernel_ms_mean': kernel_ms,
             'kernel_ms_median': res['kernel_ms_median'],
             'kernel_ms_min': res['kernel_ms_min'],
+            'kernel_ms_max': res['kernel_ms_max'],
+            'kernel_ms_second_pass_in_order':
+            res['kernel_ms_second_pass_in_order'],
             'bytes_alg_per_launch': res['bytes_alg'],
             'bytes_alg_read_per_launch': res['bytes_alg_read'],
             'read_frac_of_peak': res['bytes_alg_read'] /

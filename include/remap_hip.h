@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define REMAP_ABI_VERSION 9
+#define REMAP_ABI_VERSION 10
 
 enum {
     REMAP_OK = 0,
@@ -189,10 +189,9 @@ typedef struct remap_apply_args {
      * tune[2] K tiles per wave (1, 2 or 4)
      * tune[3] consecutive rows per wave
      * tune[4] block -> work map: 1 = as dispatched, 2 = XCD-contiguous
-     * tune[5] reserved
-     * tune[6] diagnostics: 1 = no Y stores, 2 = gather from the first 1024
-     *         source rows (results are wrong; for bottleneck analysis)
-     * tune[7] KiB of unused dynamic LDS per block (occupancy throttle) */
+     * tune[5..7] reserved, must be 0 (a -DREMAP_DIAG build of the library,
+     *         tools/build_diag.py, reads bottleneck-analysis switches from
+     *         tune[6] and tune[7]; this build rejects them) */
     int32_t tune[8];
 } remap_apply_args;
 

@@ -200,6 +200,26 @@ int launch_rowscalar(const remap_apply_args *a, const KParams &p, int vec,
     return REMAP_OK;
 }
 
+// Diagnostic build only (tune[7]): KiB of unused dynamic LDS per block, an
+// occupancy throttle for bottleneck experiments.  The product build launches
+// with no dynamic LDS.
+hipError_t diag_lds_throttle(const remap_apply_args *a, const void *fn,
+                             uint32_t &lds_bytes)
+{
+#ifdef REMAP_DIAG
+    if (a->tune[7] > 0 && (uint32_t)a->tune[7] * 1024u > lds_bytes)
+        lds_bytes = a->tune[7] * 1024u;
+    if (lds_bytes > 64 * 1024)
+        return hipFuncSetAttribute(
+            fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+#else
+    (void)a;
+    (void)fn;
+    (void)lds_bytes;
+#endif
+    return hipSuccess;
+}
+
 template <typename XT>
 struct GroupFn {
     typedef void (*type)(const KParams, const uint32_t, const int64_t *,
@@ -230,15 +250,11 @@ int launch_rowgroup(const remap_apply_args *a, const KParams &p, int tiles,
     typename GroupFn<XT>::type fn =
         tiles == 1 ? pick_rowgroup_mode<XT, 1>(a->mode, fma)
                    : pick_rowgroup_mode<XT, 2>(a->mode, fma);
-    // tune[7]: KiB of (unused) dynamic LDS per block -- an occupancy throttle
-    const uint32_t lds_bytes = a->tune[7] > 0 ? a->tune[7] * 1024u : 0u;
-    if (lds_bytes > 64 * 1024)
-        REMAP_HIP_CHECK(hipFuncSetAttribute(
-            reinterpret_cast<const void *>(fn),
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    uint32_t lds_bytes = 0;
+    REMAP_HIP_CHECK(diag_lds_throttle(a, reinterpret_cast<const void *>(fn),
+                                      lds_bytes));
     hipLaunchKernelGGL(fn, dim3(static_cast<uint32_t>(grid)), dim3(kBlock),
-                       lds_bytes,
-                       stream, p, a->flags, a->group_ptr, a->group_col,
+                       lds_bytes, stream, p, a->flags, a->group_ptr, a->group_col,
                        a->group_w, a->group_mask, a->row_order, a->frac_b,
                        static_cast<const XT *>(a->X));
     REMAP_HIP_CHECK(hipGetLastError());
@@ -305,6 +321,12 @@ int check_args(const remap_apply_args *a, Call &c)
         return fail(REMAP_ERR_UNSUPPORTED,
                     "remap_apply_f64: K = %lld fields per call exceeds 2^31",
                     (long long)c.K);
+#ifndef REMAP_DIAG
+    if (a->tune[6] != 0 || a->tune[7] != 0)
+        return fail(REMAP_ERR_UNSUPPORTED,
+                    "remap_apply_f64: tune[6] / tune[7] are switches of the "
+                    "diagnostic build (-DREMAP_DIAG), absent from this one");
+#endif
     c.fma = (a->flags & REMAP_FLAG_FMA) != 0;
     c.f32 = a->x_dtype == REMAP_DTYPE_F32;
     const size_t xelem = c.f32 ? 4 : 8;
@@ -335,7 +357,9 @@ KParams base_params(const remap_apply_args *a, const Call &c)
     p.frac_b = a->frac_b;
     p.mask_out = a->mask_out;
     p.row_order = a->row_order;
-    p.debug = a->tune[6];
+#ifdef REMAP_DIAG
+    p.diag = a->tune[6];
+#endif
     p.x_range = p.y_range = 0;
     p.row_begin = a->row_begin;
     p.row_end = a->row_end;
@@ -443,11 +467,11 @@ int run_patch(const remap_apply_args *a, const Call &c, KParams p,
         return rc;
     uint32_t lds_bytes = patch_lds_bytes(a->patch_umax, a->patch_emax,
                                          a->patch_rows, a->patch_row_bytes);
-    if (a->tune[7] > 0 && (uint32_t)a->tune[7] * 1024u > lds_bytes)
-        lds_bytes = a->tune[7] * 1024u;  // occupancy experiments
     if (lds_bytes < 1024)
         lds_bytes = 1024;
     patch_fn pf = pick_patch(a->mode, c.fma, a->patch_row_bytes);
+    REMAP_HIP_CHECK(diag_lds_throttle(a, reinterpret_cast<const void *>(pf),
+                                      lds_bytes));
     if (lds_bytes > 64 * 1024)
         REMAP_HIP_CHECK(hipFuncSetAttribute(
             reinterpret_cast<const void *>(pf),
@@ -462,16 +486,12 @@ int run_patch(const remap_apply_args *a, const Call &c, KParams p,
     return REMAP_OK;
 }
 
-// tune[7]: KiB of (unused) dynamic LDS per block -- an occupancy throttle for
-// experiments: 160 KiB per CU / this = resident blocks per CU
 int launch_plain(kernel_fn fn, const remap_apply_args *a, const KParams &p,
                  int64_t grid, hipStream_t stream)
 {
-    const uint32_t lds_bytes = a->tune[7] > 0 ? a->tune[7] * 1024u : 0u;
-    if (lds_bytes > 64 * 1024)
-        REMAP_HIP_CHECK(hipFuncSetAttribute(
-            reinterpret_cast<const void *>(fn),
-            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    uint32_t lds_bytes = 0;
+    REMAP_HIP_CHECK(diag_lds_throttle(a, reinterpret_cast<const void *>(fn),
+                                      lds_bytes));
     hipLaunchKernelGGL(fn, dim3(static_cast<uint32_t>(grid)), dim3(kBlock),
                        lds_bytes, stream, p, a->flags);
     REMAP_HIP_CHECK(hipGetLastError());

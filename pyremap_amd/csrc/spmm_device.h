@@ -23,9 +23,25 @@ struct KParams {
     int32_t xcd_map;
     uint32_t x_range;      // bytes addressable from a source row base
     uint32_t y_range;      // bytes addressable from a destination row base
-    int32_t debug;         // diagnostics only (tune[6]): 1 = no Y stores,
-                           // 2 = gather from the first 1024 source rows
+#ifdef REMAP_DIAG
+    int32_t diag;          // diagnostic build only (tune[6]): 1 = no Y
+                           // stores, 2 = gather from the first 1024 rows
+#endif
 };
+
+// Bottleneck-analysis switches exist only in the diagnostic build
+// (-DREMAP_DIAG, tools/build_diag.py); the product build compiles them away.
+#ifdef REMAP_DIAG
+#define REMAP_DIAG_COL(p, c)                                                 \
+    do {                                                                     \
+        if ((p).diag & 2)                                                   \
+            (c) &= 1023;                                                     \
+    } while (0)
+#define REMAP_DIAG_SKIP_STORE(p, y0) (((p).diag & 1) && (y0) != 1.2345e300)
+#else
+#define REMAP_DIAG_COL(p, c) do { } while (0)
+#define REMAP_DIAG_SKIP_STORE(p, y0) false
+#endif
 
 template <bool FMA>
 __device__ __forceinline__ double mul_add(double a, double x, double acc)
@@ -105,7 +121,7 @@ template <typename XT, int VEC, int TILES, int MODE, bool FMA, int UNROLL>
 __device__ __forceinline__ void accumulate_entries(
     const XT *__restrict__ X, int64_t ldx, const int64_t (&xoff)[TILES],
     int32_t my_col, double my_val, int n, double (&acc)[TILES][VEC],
-    double (&den)[TILES][VEC], int debug = 0)
+    double (&den)[TILES][VEC], const KParams &p)
 {
     typedef typename XVec<XT, VEC>::type xvec_t;
     for (int u0 = 0; u0 < n; u0 += UNROLL) {
@@ -114,8 +130,7 @@ __device__ __forceinline__ void accumulate_entries(
         for (int uu = 0; uu < UNROLL; ++uu) {
             if (u0 + uu < n) {
                 int32_t c = __builtin_amdgcn_readlane(my_col, u0 + uu);
-                if (debug & 2)
-                    c &= 1023;
+                REMAP_DIAG_COL(p, c);
                 const XT *xr = X + static_cast<int64_t>(c) * ldx;
 #pragma unroll
                 for (int t = 0; t < TILES; ++t)
@@ -177,7 +192,7 @@ __device__ __forceinline__ void finish_row(
             }
         }
         const int64_t o = i * p.ldy + yoff[t];
-        if ((p.debug & 1) && y[0] != 1.2345e300)
+        if (REMAP_DIAG_SKIP_STORE(p, y[0]))
             continue;
         store_y<VEC>(p.Y + o, y);
 #ifndef REMAP_STAMPS

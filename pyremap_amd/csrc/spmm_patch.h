@@ -145,8 +145,7 @@ __global__ __launch_bounds__(kPatchBlock) void spmm_patch(
         // (lands in the spare slot behind the list)
         const int jj = (j + sub < U) ? j + sub : j;
         int32_t c = ucol[u0 + jj];
-        if (p.debug & 2)
-            c &= 1023;
+        REMAP_DIAG_COL(p, c);
         const double *g = X + static_cast<int64_t>(c) * p.ldx + goff;
         __builtin_amdgcn_global_load_lds(
             (const __attribute__((address_space(1))) void *)g,
@@ -172,7 +171,12 @@ __global__ __launch_bounds__(kPatchBlock) void spmm_patch(
         if constexpr (MODE == REMAP_MODE_FRACB)
             lds_fb[tid] = my_fb;
     }
-    // 2. everything landed, visible to every wave
+    // 2. everything landed, visible to every wave.  The LDS-DMA rows are
+    //    tracked by vmcnt, and a workgroup barrier on gfx950 drains only
+    //    lgkmcnt: drain this wave's DMA explicitly (the compiler happens to
+    //    emit this wait today, from register dependencies; nothing obliges it
+    //    to), so no wave passes the barrier with rows still in flight.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     // 3. compute the patch's rows from LDS

@@ -109,8 +109,7 @@ __global__ __launch_bounds__(kBlock) void spmm_rowscalar(
             for (int uu = 0; uu < 8; ++uu) {
                 if (uu < n) {
                     int32_t c = c8[uu];
-                    if (p.debug & 2)
-                        c &= 1023;
+                    REMAP_DIAG_COL(p, c);
                     const __amdgpu_buffer_rsrc_t xr =
                         row_rsrc(X + static_cast<int64_t>(c) * p.ldx);
 #pragma unroll

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(kBlock) void spmm_rowwave(const KParams p,
                 my_val = p.val[base + lane];
             }
             accumulate_entries<XT, VEC, TILES, MODE, FMA, UNROLL>(
-                X, p.ldx, xoff, my_col, my_val, n, acc, den, p.debug);
+                X, p.ldx, xoff, my_col, my_val, n, acc, den, p);
         }
 
         double fb = 0.0;

@@ -32,7 +32,7 @@ FLAG_TUNE_HINT = 4
 DTYPE_F64 = 0
 DTYPE_F32 = 1
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 #: readable pad entries kept behind col/val (remap_csr.csr_pad)
 CSR_PAD = 8
@@ -234,6 +234,7 @@ class RemapPlan:
         #: entries of the longest row (kernel selection)
         self.max_row_nnz = int((rowptr[1:] - rowptr[:-1]).max()) \
             if self.n_b > 0 else 0
+        self._touched = None
         #: launch tuning used when a call passes none (set by auto_schedule)
         self.default_tune = None
         #: optional LDS-staging schedule (see build_patches)
@@ -258,10 +259,27 @@ class RemapPlan:
         if device is None:
             device = torch.device('cuda', torch.cuda.current_device())
         device = torch.device(device)
-        row_d = torch.as_tensor(np.ascontiguousarray(row) if isinstance(
-            row, np.ndarray) else row).to(device=device, dtype=torch.int32)
-        col_d = torch.as_tensor(np.ascontiguousarray(col) if isinstance(
-            col, np.ndarray) else col).to(device=device, dtype=torch.int32)
+        if n_a >= 2 ** 31 - 1 or n_b >= 2 ** 31 - 1:
+            raise ValueError('the engine indexes cells with 32 bits: n_a and '
+                             'n_b must stay below 2**31 - 1')
+
+        def index32(v, name, extent):
+            # Range-check BEFORE narrowing to int32: an int64 index of 2**31
+            # or more would otherwise wrap into the valid range.
+            t = torch.as_tensor(np.ascontiguousarray(v) if isinstance(
+                v, np.ndarray) else v)
+            if t.dtype != torch.int32 and t.numel():
+                lo, hi = int(t.min()), int(t.max())
+                if lo < index_base or hi >= extent + index_base:
+                    bad = int(((t < index_base) |
+                               (t >= extent + index_base)).sum())
+                    raise ValueError(
+                        f'{bad} mapping triplets have a {name} index outside '
+                        f'[{index_base}, {extent + index_base - 1}]')
+            return t.to(device=device, dtype=torch.int32)
+
+        row_d = index32(row, 'row', n_b)
+        col_d = index32(col, 'col', n_a)
         s_d = torch.as_tensor(np.ascontiguousarray(S) if isinstance(
             S, np.ndarray) else S).to(device=device, dtype=torch.float64)
         row_d, col_d, s_d = (row_d.contiguous(), col_d.contiguous(),
@@ -303,16 +321,37 @@ class RemapPlan:
 
     @classmethod
     def from_csr(cls, indptr, indices, data, frac_b, n_a, device=None):
-        """Wrap an existing (host or device) CSR; arrays are copied."""
+        """
+        Take an existing (host or device) CSR.  The kernels and the schedule
+        builders rely on the canonical form scipy produces (``rowptr``
+        monotone from 0 to ``len(indices)``, columns in range, ascending and
+        unique within a row), so the input is validated and then rebuilt
+        through the same device COO -> CSR path as a mapping file: unsorted
+        rows are sorted and duplicate entries summed, as
+        ``csr_matrix.sum_duplicates`` would.
+        """
         torch = require_gpu()
         if device is None:
             device = torch.device('cuda', torch.cuda.current_device())
         rowptr = torch.as_tensor(indptr).to(device=device, dtype=torch.int64)
-        col = torch.as_tensor(indices).to(device=device, dtype=torch.int32)
+        n_b = int(rowptr.shape[0]) - 1
+        col = torch.as_tensor(indices).to(device=device)
         val = torch.as_tensor(data).to(device=device, dtype=torch.float64)
-        frac = torch.as_tensor(frac_b).to(device=device, dtype=torch.float64)
-        return cls(n_a, rowptr.shape[0] - 1, rowptr.contiguous(),
-                   col.contiguous(), val.contiguous(), frac.contiguous())
+        if n_b < 0 or col.shape[0] != val.shape[0]:
+            raise ValueError('indptr must hold n_b + 1 entries and indices, '
+                             'data the same number of entries')
+        if n_b >= 0 and rowptr.numel():
+            lens = rowptr[1:] - rowptr[:-1]
+            if int(rowptr[0]) != 0 or int(rowptr[-1]) != col.shape[0] or \
+                    (lens.numel() and int(lens.min()) < 0):
+                raise ValueError(
+                    'indptr must rise monotonically from 0 to len(indices)')
+        else:
+            lens = rowptr[:0]
+        row = torch.repeat_interleave(
+            torch.arange(n_b, device=device, dtype=torch.int32), lens)
+        return cls.from_triplets(row, col, val, frac_b, n_a, n_b,
+                                 index_base=0, device=device)
 
     # -- sharding -----------------------------------------------------------
     def shard_bounds(self, world_size):
@@ -625,13 +664,26 @@ class RemapPlan:
         return {'family': 'rowscalar', 'reason': 'little source-row reuse'}
 
     # -- accounting ---------------------------------------------------------
+    def touched_sources(self):
+        """Number of DISTINCT source cells this plan's rows reference."""
+        if self._touched is None:
+            torch = _torch()
+            hit = torch.zeros(self.n_a, dtype=torch.bool, device=self.device)
+            if self.nnz:
+                hit[self.col.to(torch.int64)] = True
+            self._touched = int(hit.sum())
+        return self._touched
+
     def algorithmic_bytes(self, K, x_itemsize=8, mode=MODE_FRACB):
         """
         SURVEY.md section 8(d): S + col read once, rowptr, X read once,
-        Y written once, frac_b in the unmasked mode.
+        Y written once, frac_b in the unmasked mode.  Only source rows that
+        some entry references count towards X (a whole mapping touches every
+        source cell, so this is ``n_a`` there; a row shard or a map with
+        unreferenced cells moves fewer bytes and is priced accordingly).
         """
         b = self.nnz * 12 + (self.n_b + 1) * 8
-        b += self.n_a * K * x_itemsize + self.n_b * K * 8
+        b += self.touched_sources() * K * x_itemsize + self.n_b * K * 8
         if mode == MODE_FRACB:
             b += self.n_b * 8
         return b
@@ -786,6 +838,17 @@ def remap_tensor(plan, dst_grid_dims, field, remap_axes, mode, threshold=0.0,
         raise ValueError(f'dst_grid_dims {dst_shape} do not hold n_b = '
                          f'{plan.n_b} cells')
     out_shape = lead_shape + dst_shape + tail_shape
+    if out is not None:
+        # the kernel writes through out.data_ptr(): anything but a float64,
+        # contiguous tensor of exactly the result's shape on the plan's
+        # device would be an out-of-bounds device write
+        if out.dtype != torch.float64 or out.device != plan.device or \
+                tuple(out.shape) != tuple(out_shape) or \
+                not out.is_contiguous():
+            raise ValueError(
+                f'out must be a contiguous float64 tensor of shape '
+                f'{tuple(out_shape)} on {plan.device}, got '
+                f'{out.dtype} {tuple(out.shape)} on {out.device}')
 
     if direct:
         # strides do the permute/flatten of remap_numpy.py:254-256
