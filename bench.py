@@ -12,14 +12,26 @@ batch of 512 synthetic fields that are already resident in HBM.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): destination
 rows are sharded over the ranks (nnz-balanced contiguous ranges), rank 0's
-source field is broadcast ONCE over RCCL/xGMI before the timed region (timed
-separately, `bcast_ms`), and the timed steps contain no collective.  The
-problem size is fixed, so this is strong scaling.
+source field reaches the ranks ONCE before the timed region (timed
+separately: `multi_gpu.broadcast_ms` for one RCCL broadcast,
+`multi_gpu.bands_ms` when each rank receives only the band of source rows its
+shard references), and the timed steps contain no collective.  The problem
+size is fixed, so this is strong scaling.  `multi_gpu.pipelined_*` is the
+whole job WITH the exchange, K-chunks pipelined behind the kernel.
 
 Prints ONE JSON line on rank 0.  `value` = destination cell-fields per second
 for the whole job; `roofline` prices the kernel against HBM bandwidth using
 SURVEY.md section 8(d)'s algorithmic bytes; `cpu_baseline` is the CPU oracle
 (a C port of the reference's scipy path) timed on this box's host cores.
+
+Order of the measurements (all of them are reported): the metric workload is
+PREPARED first (plan, fields, output buffers), then the copy ceiling and the
+`extra` workloads are measured, then -- last, with the GPU in the steady power
+state those runs leave it in -- the W warm-up and K timed steps of the metric
+workload.  Why: tools/clock_ramp.py and BENCH_STEP_MARKS show that an MI355X
+coming out of an idle period (plan building is host work) runs the same
+kernel 4-15 % slower for its first 25-30 launches (~12 ms), longer than a
+5 + 20 launch run lasts; see DESIGN.md section 5.
 """
 import argparse
 import json
@@ -47,8 +59,9 @@ def parse_args():
                     help='override the number of batched fields K')
     ap.add_argument('--mode', default='fracb',
                     choices=['fracb', 'masked', 'raw'])
-    ap.add_argument('--layout', default='nk', choices=['nk', 'tnl'],
-                    help="'nk': field (n_a, K); 'tnl': (T=8, n_a, K/8)")
+    ap.add_argument('--layout', default='nk', choices=['nk', 'tnl', 'tn'],
+                    help="'nk': field (n_a, K); 'tnl': (T=8, n_a, K/8); "
+                         "'tn': (T=K, n_a)")
     ap.add_argument('--locality', default='raster',
                     choices=['raster', 'none'])
     ap.add_argument('--shard', default='rows', choices=['rows', 'fields'])
@@ -64,6 +77,9 @@ def parse_args():
                     help="torch.distributed backend: 'nccl' (= RCCL, the "
                          "real thing) or 'gloo' to rehearse the N > 1 code "
                          "path with several ranks sharing one GPU")
+    ap.add_argument('--metric-first', action='store_true',
+                    help='time the metric workload BEFORE the extras (A/B '
+                         'of the idle-state effect; see the module docstring)')
     ap.add_argument('--force-dist', action='store_true',
                     help='initialise RCCL even with one rank (exercises '
                          'the N > 1 code path on a 1-GPU box)')
@@ -135,14 +151,25 @@ def time_steps(launch, steps, warmup, dist):
         launch(i)
     first = torch.cuda.Event(enable_timing=True)
     last = torch.cuda.Event(enable_timing=True)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps)] \
+        if os.environ.get('BENCH_STEP_MARKS') else None
     barrier(dist)
     t0 = time.perf_counter()
     first.record()
     for i in range(steps):
         launch(warmup + i)
+        if marks:
+            marks[i].record()     # diagnosis only: where the region's time is
     last.record()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
+    if marks:
+        prev = first
+        gaps = []
+        for ev in marks:
+            gaps.append(round(prev.elapsed_time(ev), 4))
+            prev = ev
+        print('BENCH_STEP_MARKS', gaps, file=sys.stderr)
     if dist is not None:
         t = torch.tensor([wall], device='cuda', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -167,38 +194,41 @@ def make_fields(n_a, K, layout, sets, seed, device, nan_frac=0.0):
     out = []
     for _ in range(sets):
         if layout == 'nk':
-            x = torch.randn((n_a, K), generator=g, device=device,
-                            dtype=torch.float64)
+            shape, cell_axis = (n_a, K), 0
+        elif layout == 'tn':
+            shape, cell_axis = (K, n_a), 1
         else:
-            x = torch.randn((8, n_a, K // 8), generator=g, device=device,
-                            dtype=torch.float64)
+            shape, cell_axis = (8, n_a, K // 8), 1
+        x = torch.randn(shape, generator=g, device=device,
+                        dtype=torch.float64)
         if nan_frac:
             # whole source cells missing in every field (land / ice shelf)
             dead = torch.rand(n_a, generator=g, device=device) < nan_frac
-            if layout == 'nk':
-                x[dead, :] = float('nan')
-            else:
-                x[:, dead, :] = float('nan')
+            x.index_fill_(cell_axis, dead.nonzero().squeeze(1), float('nan'))
         out.append(x)
     return out
 
 
-def run_workload(name, args, rank, world, dist, K=None, mode=None,
-                 layout=None, steps=None, warmup=None, sets=None):
-    """Build plan + fields for one workload and time it."""
+class Workload:
+    """One prepared workload: plan, resident fields, output buffers."""
+
+
+def prepare(name, args, rank, world, dist, K=None, mode=None, layout=None,
+            sets=None):
+    """Build plan + fields + output buffers for one workload."""
     import torch
 
     from pyremap_amd import engine, synthetic
     device = torch.device('cuda', torch.cuda.current_device())
+    w = Workload()
     cfg = synthetic.CONFIGS[name]
-    K = K or args.fields or cfg['K']
-    mode = mode or args.mode
-    layout = layout or args.layout
-    steps = steps or args.steps
-    warmup = args.warmup if warmup is None else warmup
-    sets = sets or args.sets
-    emode = {'fracb': engine.MODE_FRACB, 'masked': engine.MODE_MASKED,
-             'raw': engine.MODE_RAW}[mode]
+    w.name, w.title = name, cfg['title']
+    w.K = K or args.fields or cfg['K']
+    w.mode = mode or args.mode
+    w.layout = layout or args.layout
+    w.sets = sets or args.sets
+    w.emode = {'fracb': engine.MODE_FRACB, 'masked': engine.MODE_MASKED,
+               'raw': engine.MODE_RAW}[w.mode]
     tune = [int(t) for t in args.tune.split(',')] if args.tune else None
 
     t0 = time.perf_counter()
@@ -206,73 +236,168 @@ def run_workload(name, args, rank, world, dist, K=None, mode=None,
     full = engine.RemapPlan.from_triplets(
         m.row, m.col, m.S, m.frac_b, m.n_a, m.n_b, index_base=1,
         device=device)
-    K_local = K
-    plan = full
-    bcast_ms = None
-    sharded = dist is not None and args.shard == 'rows'
-    if sharded:
-        plan = full.shard(rank, world)
+    w.m, w.full = m, full
+    w.K_local = w.K
+    w.plan = full
+    w.sharded = dist is not None and args.shard == 'rows'
+    w.remap = None
+    if w.sharded:
+        from pyremap_amd.parallel import ShardedRemap
+        w.remap = ShardedRemap(full, grid_dims=None)
+        w.plan = w.remap.plan
     elif dist is not None:
-        K_local = K // world
+        w.K_local = w.K // world
     # what Remapper does after loading a mapping: pick the schedule for the
     # rows this rank owns
     if not args.tune:
-        schedule = plan.auto_schedule(m.dst_dims)
+        w.schedule = w.plan.auto_schedule(m.dst_dims)
     else:
-        schedule = {'family': 'explicit tune', 'tune': args.tune}
+        w.schedule = {'family': 'explicit tune', 'tune': args.tune}
     torch.cuda.synchronize()
-    plan_s = time.perf_counter() - t0
-    fields = make_fields(m.n_a, K_local, layout, sets, 1234 + 0 * rank,
-                         device, nan_frac=0.25 if mode == 'masked' else 0.0)
-    if sharded:
-        # the ONE exchange step of the path: rank 0's fields go to all ranks
-        barrier(dist)
-        tb = time.perf_counter()
-        for x in fields:
-            dist.broadcast(x, src=0)
-        torch.cuda.synchronize()
-        bcast_ms = (time.perf_counter() - tb) * 1e3 / len(fields)
+    w.plan_s = time.perf_counter() - t0
+    w.fields = make_fields(m.n_a, w.K_local, w.layout, w.sets, 1234, device,
+                           nan_frac=0.25 if w.mode == 'masked' else 0.0)
+    w.exchange = None
+    if w.sharded:
+        w.exchange = time_exchange(w, dist)
 
-    dst = None if plan.n_b != plan.n_b_global else m.dst_dims
-    outs = [None] * sets
+    dst = None if w.plan.n_b != w.plan.n_b_global else m.dst_dims
+    w.outs = [None] * w.sets
+    axes = [0] if w.layout == 'nk' else [1]
 
     def launch(i):
-        s = i % sets
-        outs[s] = engine.remap_tensor(plan, dst, fields[s],
-                                      [0] if layout == 'nk' else [1], emode,
-                                      threshold=0.01, flags=args.flags,
-                                      tune=tune, out=outs[s])
+        s = i % w.sets
+        w.outs[s] = engine.remap_tensor(
+            w.plan, dst, w.fields[s], axes, w.emode, threshold=0.01,
+            flags=args.flags, tune=tune, out=w.outs[s])
 
-    launch(0)
+    w.launch = launch
+    # every output buffer exists before anything else is allocated (buffers
+    # that recycled the copy-ceiling's freed blocks once measured 4 % slower
+    # for the whole process: placement in HBM)
+    for s in range(w.sets):
+        launch(s)
     torch.cuda.synchronize()
-    wall, mean_ms, per_launch = time_steps(launch, steps, warmup, dist)
+    return w
+
+
+def time_exchange(w, dist):
+    """
+    The ONE exchange step of the sharded path, timed on its own, two ways:
+    one RCCL broadcast of the whole field, and only the band of source rows
+    each shard references (point to point).  Leaves every rank holding rank
+    0's fields.
+    """
+    import torch
+    out = {}
+    x = w.fields[0]
+    rows_first = w.layout == 'nk'
+    for how in ('broadcast', 'bands'):
+        if how == 'bands' and (not rows_first or
+                               dist.get_backend() != 'nccl'):
+            continue   # (gloo moves GPU tensors point to point via the host)
+        times = []
+        try:
+            for _ in range(3):
+                barrier(dist)
+                t0 = time.perf_counter()
+                if how == 'broadcast':
+                    dist.broadcast(x, src=0)
+                else:
+                    w.remap.distribute(x, src=0, how='bands')
+                torch.cuda.synchronize()
+                times.append((time.perf_counter() - t0) * 1e3)
+            out[f'{how}_ms'] = min(times)
+        except RuntimeError as exc:   # gloo rehearsal: no GPU send/recv
+            out[f'{how}_ms'] = None
+            out[f'{how}_error'] = str(exc).splitlines()[0][:200]
+    for x in w.fields:            # every set resident everywhere
+        dist.broadcast(x, src=0)
+    torch.cuda.synchronize()
+    from pyremap_amd.parallel import band_fraction
+    out['band_fraction_of_broadcast'] = band_fraction(w.remap.src_ranges,
+                                                      w.plan.n_a)
+    out['field_bytes'] = x.numel() * x.element_size()
+    return out
+
+
+def time_pipelined(w, args, dist, reps=5, n_batches=4):
+    """
+    The whole sharded job WITH its exchange: the K fields as `n_batches`
+    column batches; batch b + 1 travels (bands, or one broadcast) while batch
+    b is computed.  Milliseconds per K fields, max over ranks.
+    """
+    import torch
+    if w.remap is None or w.layout != 'nk':
+        return None
+    kb = w.K_local // n_batches
+    src = w.fields[0]
+    batches = [src[:, b * kb:(b + 1) * kb].contiguous()
+               for b in range(n_batches)]
+    outs = [torch.empty((w.plan.n_b, kb), dtype=torch.float64,
+                        device=src.device) for _ in range(n_batches)]
+    out = {}
+    for how in ('bands', 'broadcast'):
+        if how == 'bands' and dist.get_backend() != 'nccl':
+            continue
+        try:
+            w.remap.apply_pipelined(batches, w.emode, how=how,
+                                    threshold=0.01, flags=args.flags,
+                                    outs=outs)
+        except RuntimeError as exc:   # gloo rehearsal: no GPU send/recv
+            out[f'pipelined_{how}_error'] = str(exc).splitlines()[0][:200]
+            continue
+        times = []
+        for _ in range(reps):
+            barrier(dist)
+            t0 = time.perf_counter()
+            w.remap.apply_pipelined(batches, w.emode, how=how,
+                                    threshold=0.01, flags=args.flags,
+                                    outs=outs)
+            torch.cuda.synchronize()
+            t = torch.tensor([time.perf_counter() - t0], device='cuda',
+                             dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            times.append(float(t.item()) * 1e3)
+        out[f'pipelined_{how}_ms_per_K_fields'] = min(times)
+    out['n_column_batches'] = n_batches
+    return out
+
+
+def measure(w, args, dist, steps=None, warmup=None):
+    """W warm-up + K timed steps of a prepared workload."""
+    steps = steps or args.steps
+    warmup = args.warmup if warmup is None else warmup
+    wall, mean_ms, per_launch = time_steps(w.launch, steps, warmup, dist)
     in_order = [round(t, 4) for t in per_launch[:20]]
     per_launch.sort()
-    # algorithmic bytes of ONE launch on this rank; a row
-    # shard reads at most the whole of X
-    bytes_alg = plan.algorithmic_bytes(K_local, 8, emode)
-    res = dict(
-        name=name, title=cfg['title'], n_a=m.n_a, n_b=m.n_b,
-        n_s_file=m.n_s, nnz_csr=full.nnz, K=K, mode=mode, layout=layout,
-        steps=steps, warmup=warmup, wall_s=wall,
+    m, plan = w.m, w.plan
+    # algorithmic bytes of ONE launch on this rank (SURVEY.md 8(d)); only
+    # source rows some entry references count towards X
+    bytes_alg = plan.algorithmic_bytes(w.K_local, 8, w.emode)
+    return dict(
+        name=w.name, title=w.title, n_a=m.n_a, n_b=m.n_b,
+        n_s_file=m.n_s, nnz_csr=w.full.nnz, K=w.K, mode=w.mode,
+        layout=w.layout, steps=steps, warmup=warmup, wall_s=wall,
         ms_per_step=wall * 1e3 / steps,
-        kernel_ms_mean=mean_ms, kernel_ms_median=per_launch[len(per_launch)
-                                                            // 2],
+        kernel_ms_mean=mean_ms,
+        kernel_ms_median=per_launch[len(per_launch) // 2],
         kernel_ms_min=per_launch[0], kernel_ms_max=per_launch[-1],
         kernel_ms_second_pass_in_order=in_order,
         touched_frac=plan.touched_sources() / max(plan.n_a, 1),
-        cell_fields_per_s=m.n_b * K * steps / wall,
+        cell_fields_per_s=m.n_b * w.K * steps / wall,
         dst_cells_per_s_per_batch=m.n_b * steps / wall,
-        bytes_alg=bytes_alg, bytes_alg_read=bytes_alg - plan.n_b * K_local * 8,
+        bytes_alg=bytes_alg,
+        bytes_alg_read=bytes_alg - plan.n_b * w.K_local * 8,
         achieved_GBps=bytes_alg / (mean_ms * 1e-3) / 1e9,
-        plan_build_s=plan_s, bcast_ms=bcast_ms,
-        rows_this_rank=plan.n_b, nnz_this_rank=plan.nnz, schedule=schedule,
+        plan_build_s=w.plan_s, exchange=w.exchange,
+        rows_this_rank=plan.n_b, nnz_this_rank=plan.nnz,
+        schedule=w.schedule,
     )
-    return res, full, m, fields, outs
 
 
-def copy_ceiling(device):
-    """The box's achievable HBM rate: 1 GiB device copy, read + write."""
+def copy_ceiling(device, reps=60):
+    """The box's achievable HBM rate: 1 GiB device copies, read + write."""
     import torch
 
     from pyremap_amd import engine
@@ -284,7 +409,6 @@ def copy_ceiling(device):
         engine.stream_copy(dst, src)
     a = torch.cuda.Event(enable_timing=True)
     b = torch.cuda.Event(enable_timing=True)
-    reps = 10
     a.record()
     for _ in range(reps):
         engine.stream_copy(dst, src)
@@ -386,16 +510,19 @@ def pcie_inclusive(args):
     x = np.random.default_rng(0).standard_normal((m.n_a, cfg['K']))
     r.remap_array(x[:, :8], [0])                     # loads the weights
     times = []
-    for _ in range(3):
+    y = None
+    for _ in range(4):
+        del y
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         y = r.remap_array(x, [0])
         times.append(time.perf_counter() - t0)
     t = min(times)
-    return dict(seconds=t, cell_fields_per_s=m.n_b * cfg['K'] / t,
+    return dict(seconds=t, seconds_first_call=times[0],
+                cell_fields_per_s=m.n_b * cfg['K'] / t,
                 bytes_over_pcie=x.nbytes + y.data.nbytes + y.mask.nbytes,
-                note='numpy in -> numpy masked array out, pageable host '
-                     'memory, best of 3')
+                note='numpy in -> numpy masked array out through '
+                     'Remapper.remap_array, best of 4')
 
 
 def load_traffic(name, K, mode):
@@ -410,6 +537,53 @@ def load_traffic(name, K, mode):
     return t.get('hbm_bytes_per_launch'), t.get('source')
 
 
+EXTRA_KEYS = ('title', 'n_a', 'n_b', 'nnz_csr', 'K', 'mode', 'layout',
+              'schedule', 'touched_frac', 'ms_per_step', 'kernel_ms_mean',
+              'kernel_ms_median', 'cell_fields_per_s', 'bytes_alg',
+              'achieved_GBps')
+
+
+def extras_todo(args, world):
+    """The other reported workloads: (tag, prepare() keywords, steps)."""
+    if args.no_extra or args.workload != 'config3':
+        return []
+    if world == 1:
+        return [
+            ('headline_3.7M_to_1.0M', dict(name='headline', sets=2), 30),
+            ('K1_one_2d_field', dict(name='config3', K=1), 50),
+            ('K12_monthly_time_nCells', dict(name='config3', K=12,
+                                             layout='tn'), 50),
+            ('layout_T8_nCells_L64', dict(name='config3', layout='tnl'), 50),
+            ('masked_renormalised', dict(name='config3', mode='masked'), 50),
+        ]
+    return [('masked_renormalised', dict(name='config3', mode='masked'), 50)]
+
+
+def prepare_extras(args, rank, world, dist, extra):
+    """Build every extra workload (host work: the GPU idles meanwhile)."""
+    ready = []
+    for tag, kw, steps in extras_todo(args, world):
+        try:
+            ready.append((tag, prepare(kw.pop('name'), args, rank, world,
+                                       dist, **kw), steps))
+        except Exception as exc:  # noqa: BLE001 - report, keep the line
+            extra[tag] = {'error': f'{type(exc).__name__}: {exc}'}
+    return ready
+
+
+def measure_extras(ready, args, dist, extra):
+    """Time the prepared extras back to back (no host work in between)."""
+    for tag, w, steps in ready:
+        try:
+            r = measure(w, args, dist, steps=steps, warmup=5)
+            extra[tag] = {k: r[k] for k in EXTRA_KEYS}
+            extra[tag]['frac_of_peak'] = r['achieved_GBps'] / HBM_PEAK_GBPS
+            traffic, _ = load_traffic(w.name, w.K, w.mode)
+            extra[tag]['traffic'] = traffic
+        except Exception as exc:  # noqa: BLE001
+            extra[tag] = {'error': f'{type(exc).__name__}: {exc}'}
+
+
 def main():
     args = parse_args()
     import torch
@@ -418,46 +592,46 @@ def main():
     from pyremap_amd import engine
     engine.require_gpu()
 
-    res, full, m, fields, outs = run_workload(args.workload, args, rank,
-                                              world, dist)
+    extra = {}
+    # everything is PREPARED first (host work, GPU mostly idle), then all
+    # measurements run back to back; the metric workload last
+    main_w = prepare(args.workload, args, rank, world, dist)
+    ready = prepare_extras(args, rank, world, dist, extra)
+    ceiling = copy_ceiling(device)
+    pipelined = None
+    res = None
+    if args.metric_first:
+        res = measure(main_w, args, dist)
+    measure_extras(ready, args, dist, extra)
+    if res is None:
+        res = measure(main_w, args, dist)
     K = res['K']
+    # a long run behind it, for the record: the steady-state launch time
+    a = torch.cuda.Event(enable_timing=True)
+    b = torch.cuda.Event(enable_timing=True)
+    a.record()
+    for i in range(100):
+        main_w.launch(i)
+    b.record()
+    torch.cuda.synchronize()
+    res['kernel_ms_steady_100_more'] = a.elapsed_time(b) / 100
+    if main_w.sharded:
+        pipelined = time_pipelined(main_w, args, dist)
     # per-rank kernel numbers -> the slowest rank prices the roofline
     if dist is not None:
         t = torch.tensor([res['kernel_ms_mean']], device=device,
                          dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         res['kernel_ms_mean_max_rank'] = float(t.item())
+    del ready
 
-    extra = {}
     cpu = None
-    ceiling = None
-    if rank == 0:
-        ceiling = copy_ceiling(device)
     if rank == 0 and world == 1 and not args.no_cpu:
-        cpu = cpu_baseline(full, m, fields[0], res['mode'], args.cpu_seconds)
+        cpu = cpu_baseline(main_w.full, main_w.m, main_w.fields[0],
+                           res['mode'], args.cpu_seconds)
     if world == 1 and not args.no_extra and args.workload == 'config3':
-        del fields, outs, full
+        main_w.fields = main_w.outs = None
         torch.cuda.empty_cache()
-        for tag, kw in (
-                ('masked_renormalised', dict(name='config3', mode='masked')),
-                ('layout_T8_nCells_L64', dict(name='config3', layout='tnl')),
-                ('headline_3.7M_to_1.0M', dict(name='headline')),
-        ):
-            try:
-                r, f2, m2, x2, y2 = run_workload(
-                    kw.pop('name'), args, rank, world, dist, steps=50,
-                    warmup=5, **kw)
-                extra[tag] = {k: r[k] for k in (
-                    'title', 'n_a', 'n_b', 'nnz_csr', 'K', 'mode', 'layout',
-                    'schedule',
-                    'ms_per_step', 'kernel_ms_mean', 'cell_fields_per_s',
-                    'bytes_alg', 'achieved_GBps')}
-                extra[tag]['frac_of_peak'] = r['achieved_GBps'] / \
-                    HBM_PEAK_GBPS
-                del f2, m2, x2, y2
-                torch.cuda.empty_cache()
-            except Exception as exc:  # noqa: BLE001 - report, keep the line
-                extra[tag] = {'error': f'{type(exc).__name__}: {exc}'}
         try:
             extra['host_buffers_pcie_inclusive'] = pcie_inclusive(args)
         except Exception as exc:  # noqa: BLE001
@@ -473,6 +647,11 @@ def main():
     traffic, traffic_src = load_traffic(args.workload, K, res['mode'])
     kernel_ms = res.get('kernel_ms_mean_max_rank', res['kernel_ms_mean'])
     achieved = res['bytes_alg'] / (kernel_ms * 1e-3) / 1e9
+    multi = None
+    if res['exchange'] is not None:
+        multi = dict(res['exchange'])
+        multi.update(pipelined or {})
+        multi['kernel_phase_ms'] = kernel_ms
     line = {
         'metric': 'dst cell-fields/s (dst cells x batched fields per second)'
                   ' + HBM GB/s, EC30to60 MPAS -> 0.5deg lat-lon, 512 batched '
@@ -496,12 +675,15 @@ def main():
             'locality': args.locality,
             'touched_frac': res['touched_frac'],
             'sharding': 'none' if world == 1 else
-            (f'dst rows over {world} GPUs, X broadcast once (RCCL) before '
+            (f'dst rows over {world} GPUs, X distributed once (RCCL) before '
              f'the timed region' if args.shard == 'rows' else
              f'fields over {world} GPUs, no collective'),
             'buffer_sets_rotated': args.sets,
             'bitwise_mode': not (args.flags & 1),
             'schedule': res['schedule'],
+            'measurement_order': 'metric first' if args.metric_first else
+            'everything prepared first; then copy ceiling, extras, metric '
+            'workload timed back to back',
         },
         'dst_cells_per_s_per_512_batch': res['dst_cells_per_s_per_batch'],
         'roofline': {
@@ -521,6 +703,7 @@ def main():
             'kernel_ms_max': res['kernel_ms_max'],
             'kernel_ms_second_pass_in_order':
             res['kernel_ms_second_pass_in_order'],
+            'kernel_ms_steady_100_more': res['kernel_ms_steady_100_more'],
             'bytes_alg_per_launch': res['bytes_alg'],
             'bytes_alg_read_per_launch': res['bytes_alg_read'],
             'read_frac_of_peak': res['bytes_alg_read'] /
@@ -529,7 +712,7 @@ def main():
         },
         'cpu_baseline': cpu,
         'plan_build_s': res['plan_build_s'],
-        'bcast_ms': res['bcast_ms'],
+        'multi_gpu': multi,
         'extra': extra,
     }
     # the JSON line is the LAST thing on stdout: every rank is done first

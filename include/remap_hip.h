@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define REMAP_ABI_VERSION 10
+#define REMAP_ABI_VERSION 12
 
 enum {
     REMAP_OK = 0,
@@ -74,7 +74,13 @@ enum {
     /* `tune` is a preference, not a demand: if the requested kernel family
      * cannot serve this call (K <= 32, odd strides, a partial row range, a
      * missing schedule ...) choose automatically instead of failing */
-    REMAP_FLAG_TUNE_HINT = 1u << 2
+    REMAP_FLAG_TUNE_HINT = 1u << 2,
+    /* few-fields calls (K <= 32, kernel family 3) may add a row's products
+     * by lane-private partial sums and a butterfly across lanes instead of
+     * one after the other in CSR order: a different association, within
+     * 1e-13 relative of the default -- for callers that do not need the
+     * bits.  Ignored by the other kernel families. */
+    REMAP_FLAG_TREE = 1u << 3
 };
 
 /* CSR weight matrix of shape (n_rows, n_cols) = (n_b, n_a), or a row shard of
@@ -162,26 +168,38 @@ typedef struct remap_apply_args {
     int32_t patch_row_bytes;     /* staged bytes per source row and K-chunk:
                                     1024 (128 columns) or 512 (64 columns)   */
     int64_t n_patches;
-    /* Optional row-group schedule (all NULL/0 = absent): work slots
-     * [row_begin + 8 g, + 8) form group g (with row_order: a 2 x 4 tile of
-     * the destination grid).  group_col lists, per group, the sorted UNION of
-     * its rows' columns (group_ptr delimits it); group_w[u * 8 + m] is the
-     * weight of union entry u in the group's m-th row (0.0 if that row has no
-     * such entry) and bit m of group_mask[u] says whether it has one.  A wave
-     * then loads every distinct source row of 8 neighbouring destination
-     * rows ONCE and feeds up to 8 accumulators from it; each row still adds
-     * its entries in ascending column order, so results are unchanged.     */
-    const int64_t *group_ptr;   /* (device) n_groups + 1                    */
+    /* Optional row-group schedule (all NULL/0 = absent): with G =
+     * group_rows (8 or 4), work slots [row_begin + G g, + G) form group g
+     * (with row_order: a 2 x 4 or 2 x 2 tile of the destination grid).
+     * group_col lists, per group, the sorted UNION of its rows' columns;
+     * bit m of group_mask[u] says whether the group's m-th row owns union
+     * entry u; group_w holds the weights of exactly those present (entry,
+     * member) pairs, in (entry, member) order -- nnz doubles in all;
+     * group_meta[2 g] / [2 g + 1] index group g's first union entry / first
+     * weight (entry n_groups closes the lists).  group_rid / group_frac give
+     * the row id / frac_b of every work slot, padded to whole groups (the
+     * pad names any valid row).  A wave then loads every distinct source
+     * row of G neighbouring destination rows ONCE and feeds up to G
+     * accumulators from it; each row still adds its entries in ascending
+     * column order, so results are unchanged.                              */
+    const int64_t *group_meta;  /* (device) 2 * (n_groups + 1)              */
     const int32_t *group_col;   /* (device) union entries (+ 8 readable)    */
-    const double *group_w;      /* (device) union entries * 8 (+ 64)        */
+    const double *group_w;      /* (device) present weights (+ 64 readable) */
     const int32_t *group_mask;  /* (device) union entries (+ 8)             */
+    const int32_t *group_rid;   /* (device) n_groups * group_rows           */
+    const double *group_frac;   /* (device) n_groups * group_rows           */
     int64_t n_groups;
+    int32_t group_rows;         /* G: 8 or 4                                */
+    int32_t group_reserved;     /* must be 0                                */
     uint32_t flags;         /* REMAP_FLAG_*                                  */
     /* launch tuning, 0 = choose automatically:
      * tune[0] kernel family   1 = wave per row (lanes across K),
      *                         2 = lane per (row, k) (small K),
+     *                         3 = a sub-group of lanes per row, lanes across
+     *                             the row's entries (K <= 32: the default
+     *                             there; tune[1] = lanes per row, 8 or 4),
      *                         5 = LDS-staged patches (needs a patch plan),
-     *                         10 = 8 rows per wave over the union of their
+     *                         10 = G rows per wave over the union of their
      *                              columns (needs the row-group schedule),
      *                         6 = 1 with row metadata through the scalar
      *                             cache (needs csr_pad >= 8; the default)
@@ -189,9 +207,10 @@ typedef struct remap_apply_args {
      * tune[2] K tiles per wave (1, 2 or 4)
      * tune[3] consecutive rows per wave
      * tune[4] block -> work map: 1 = as dispatched, 2 = XCD-contiguous
-     * tune[5..7] reserved, must be 0 (a -DREMAP_DIAG build of the library,
+     * tune[5] family 10: union entries in flight per wave (8, or 4)
+     * tune[6..7] reserved, must be 0 (a -DREMAP_DIAG build of the library,
      *         tools/build_diag.py, reads bottleneck-analysis switches from
-     *         tune[6] and tune[7]; this build rejects them) */
+     *         them; this build rejects them) */
     int32_t tune[8];
 } remap_apply_args;
 

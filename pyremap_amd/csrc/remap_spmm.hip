@@ -52,6 +52,7 @@ namespace {
 #include "spmm_rowscalar.h"
 #include "spmm_rowgroup.h"
 #include "spmm_rowlane.h"
+#include "spmm_rowsub.h"
 
 // ---------------------------------------------------------------------------
 // host-side dispatch
@@ -103,6 +104,32 @@ kernel_fn pick_rowlane(int mode, bool fma)
         return fma ? spmm_rowlane<XT, REMAP_MODE_MASKED, true>
                    : spmm_rowlane<XT, REMAP_MODE_MASKED, false>;
     }
+}
+
+template <typename XT, int SUB, bool TREE>
+kernel_fn pick_rowsub_mode(int mode, bool fma)
+{
+    switch (mode) {
+    case REMAP_MODE_RAW:
+        return fma ? spmm_rowsub<XT, REMAP_MODE_RAW, true, SUB, TREE>
+                   : spmm_rowsub<XT, REMAP_MODE_RAW, false, SUB, TREE>;
+    case REMAP_MODE_FRACB:
+        return fma ? spmm_rowsub<XT, REMAP_MODE_FRACB, true, SUB, TREE>
+                   : spmm_rowsub<XT, REMAP_MODE_FRACB, false, SUB, TREE>;
+    default:
+        return fma ? spmm_rowsub<XT, REMAP_MODE_MASKED, true, SUB, TREE>
+                   : spmm_rowsub<XT, REMAP_MODE_MASKED, false, SUB, TREE>;
+    }
+}
+
+template <typename XT>
+kernel_fn pick_rowsub(int sub, bool tree, int mode, bool fma)
+{
+    if (sub == 4)
+        return tree ? pick_rowsub_mode<XT, 4, true>(mode, fma)
+                    : pick_rowsub_mode<XT, 4, false>(mode, fma);
+    return tree ? pick_rowsub_mode<XT, 8, true>(mode, fma)
+                : pick_rowsub_mode<XT, 8, false>(mode, fma);
 }
 
 typedef void (*patch_fn)(const KParams, const uint32_t, const int32_t *,
@@ -227,36 +254,54 @@ struct GroupFn {
                          const int32_t *, const double *, const XT *);
 };
 
-template <typename XT, int TILES>
+template <typename XT, int TILES, int G, int UNR>
 typename GroupFn<XT>::type pick_rowgroup_mode(int mode, bool fma)
 {
     switch (mode) {
     case REMAP_MODE_RAW:
-        return fma ? spmm_rowgroup<XT, TILES, REMAP_MODE_RAW, true>
-                   : spmm_rowgroup<XT, TILES, REMAP_MODE_RAW, false>;
+        return fma ? spmm_rowgroup<XT, TILES, REMAP_MODE_RAW, true, G, UNR>
+                   : spmm_rowgroup<XT, TILES, REMAP_MODE_RAW, false, G, UNR>;
     case REMAP_MODE_FRACB:
-        return fma ? spmm_rowgroup<XT, TILES, REMAP_MODE_FRACB, true>
-                   : spmm_rowgroup<XT, TILES, REMAP_MODE_FRACB, false>;
+        return fma ? spmm_rowgroup<XT, TILES, REMAP_MODE_FRACB, true, G, UNR>
+                   : spmm_rowgroup<XT, TILES, REMAP_MODE_FRACB, false, G, UNR>;
     default:
-        return fma ? spmm_rowgroup<XT, TILES, REMAP_MODE_MASKED, true>
-                   : spmm_rowgroup<XT, TILES, REMAP_MODE_MASKED, false>;
+        return fma ? spmm_rowgroup<XT, TILES, REMAP_MODE_MASKED, true, G, UNR>
+                   : spmm_rowgroup<XT, TILES, REMAP_MODE_MASKED, false, G, UNR>;
     }
+}
+
+template <typename XT, int G, int UNR>
+typename GroupFn<XT>::type pick_rowgroup_tiles(int tiles, int mode, bool fma)
+{
+    return tiles == 1 ? pick_rowgroup_mode<XT, 1, G, UNR>(mode, fma)
+                      : pick_rowgroup_mode<XT, 2, G, UNR>(mode, fma);
+}
+
+template <typename XT, int G>
+typename GroupFn<XT>::type pick_rowgroup_shape(int unr, int tiles, int mode,
+                                               bool fma)
+{
+    return unr == 4 ? pick_rowgroup_tiles<XT, G, 4>(tiles, mode, fma)
+                    : pick_rowgroup_tiles<XT, G, 8>(tiles, mode, fma);
 }
 
 template <typename XT>
 int launch_rowgroup(const remap_apply_args *a, const KParams &p, int tiles,
-                    bool fma, int64_t grid, hipStream_t stream)
+                    int unr, bool fma, int64_t grid, hipStream_t stream)
 {
     typename GroupFn<XT>::type fn =
-        tiles == 1 ? pick_rowgroup_mode<XT, 1>(a->mode, fma)
-                   : pick_rowgroup_mode<XT, 2>(a->mode, fma);
+        a->group_rows == 16
+            ? pick_rowgroup_shape<XT, 16>(unr, tiles, a->mode, fma)
+        : a->group_rows == 8
+            ? pick_rowgroup_shape<XT, 8>(unr, tiles, a->mode, fma)
+            : pick_rowgroup_shape<XT, 4>(unr, tiles, a->mode, fma);
     uint32_t lds_bytes = 0;
     REMAP_HIP_CHECK(diag_lds_throttle(a, reinterpret_cast<const void *>(fn),
                                       lds_bytes));
     hipLaunchKernelGGL(fn, dim3(static_cast<uint32_t>(grid)), dim3(kBlock),
-                       lds_bytes, stream, p, a->flags, a->group_ptr, a->group_col,
-                       a->group_w, a->group_mask, a->row_order, a->frac_b,
-                       static_cast<const XT *>(a->X));
+                       lds_bytes, stream, p, a->flags, a->group_meta,
+                       a->group_col, a->group_w, a->group_mask, a->group_rid,
+                       a->group_frac, static_cast<const XT *>(a->X));
     REMAP_HIP_CHECK(hipGetLastError());
     return REMAP_OK;
 }
@@ -340,9 +385,13 @@ int check_args(const remap_apply_args *a, Call &c)
         ((a->n_batch - 1) * a->x_batch_stride + a->k_inner) *
             (int64_t)xelem < (int64_t(1) << 31);
     c.patch_ok = patch_usable(a, c.K, c.f32, c.can_vec2);
-    c.group_ok = a->group_ptr && a->group_col && a->group_w &&
-                 a->group_mask &&
-                 a->n_groups == (c.n_rows + kGroup - 1) / kGroup;
+    c.group_ok = a->group_meta && a->group_col && a->group_w &&
+                 a->group_mask && a->group_rid && a->group_frac &&
+                 (a->group_rows == 16 || a->group_rows == 8 ||
+                  a->group_rows == 4) &&
+                 a->group_reserved == 0 &&
+                 a->n_groups ==
+                     (c.n_rows + a->group_rows - 1) / a->group_rows;
     return REMAP_OK;
 }
 
@@ -380,7 +429,7 @@ KParams base_params(const remap_apply_args *a, const Call &c)
 bool hint_usable(const remap_apply_args *a, const Call &c)
 {
     if (c.K <= 32)
-        return false;  // the lane-per-(row, k) kernel owns small K
+        return false;  // the sub-group-per-row kernel owns small K
     switch (a->tune[0]) {
     case 10:
         return c.group_ok && c.can_vec2 && c.small_offsets;
@@ -402,7 +451,7 @@ bool hint_usable(const remap_apply_args *a, const Call &c)
 int automatic_family(const remap_apply_args *a, const Call &c)
 {
     if (c.K <= 32)
-        return 2;
+        return 3;
     if (c.patch_ok && c.K >= 64)
         return 5;
     return a->A.csr_pad >= 8 ? 6 : 1;
@@ -440,6 +489,7 @@ int run_rowgroup(const remap_apply_args *a, const Call &c, KParams p,
     if (tiles != 2 || c.K <= 128)
         tiles = 1;
     const int gpw = a->tune[3] > 0 ? a->tune[3] : 2;   // groups per wave
+    const int unr = a->tune[5] == 4 ? 4 : 8;   // union entries in flight
     p.rows_per_wave = gpw;
     int64_t grid;
     const int rc = shape_grid(
@@ -447,8 +497,10 @@ int run_rowgroup(const remap_apply_args *a, const Call &c, KParams p,
         ceil_div(c.K, (int64_t)kWave * 2 * tiles), a->tune[4] != 1, grid);
     if (rc != REMAP_OK)
         return rc;
-    return c.f32 ? launch_rowgroup<float>(a, p, tiles, c.fma, grid, stream)
-                 : launch_rowgroup<double>(a, p, tiles, c.fma, grid, stream);
+    return c.f32 ? launch_rowgroup<float>(a, p, tiles, unr, c.fma, grid,
+                                          stream)
+                 : launch_rowgroup<double>(a, p, tiles, unr, c.fma, grid,
+                                           stream);
 }
 
 int run_patch(const remap_apply_args *a, const Call &c, KParams p,
@@ -509,6 +561,28 @@ int run_rowlane(const remap_apply_args *a, const Call &c, const KParams &p,
     return launch_plain(c.f32 ? pick_rowlane<float>(a->mode, c.fma)
                               : pick_rowlane<double>(a->mode, c.fma),
                         a, p, grid, stream);
+}
+
+// family 3: a sub-group of 8 (4 for rows of at most 4 entries: bilinear
+// maps) lanes per row; tune[1] overrides the sub-group size
+int run_rowsub(const remap_apply_args *a, const Call &c, const KParams &p,
+               hipStream_t stream)
+{
+    int sub = a->tune[1];
+    if (sub == 0)
+        sub = (a->A.max_row_nnz > 0 && a->A.max_row_nnz <= 4) ? 4 : 8;
+    if (sub != 4 && sub != 8)
+        return fail(REMAP_ERR_ARG, "remap_apply_f64: tune[1] = %d", sub);
+    const int64_t grid = ceil_div(c.n_rows, kBlock / sub);
+    if (grid <= 0 || grid > 0x7fffffffLL)
+        return fail(REMAP_ERR_UNSUPPORTED,
+                    "remap_apply_f64: grid of %lld blocks; split the rows",
+                    (long long)grid);
+    const bool tree = (a->flags & REMAP_FLAG_TREE) != 0;
+    return launch_plain(
+        c.f32 ? pick_rowsub<float>(sub, tree, a->mode, c.fma)
+              : pick_rowsub<double>(sub, tree, a->mode, c.fma),
+        a, p, grid, stream);
 }
 
 // families 1 (vector-memory metadata) and 6 (scalar-cache metadata)
@@ -593,6 +667,8 @@ int apply(const remap_apply_args *a, hipStream_t stream)
         return run_patch(a, c, p, stream);
     case 2:
         return run_rowlane(a, c, p, stream);
+    case 3:
+        return run_rowsub(a, c, p, stream);
     case 1:
     case 6:
         return run_rowwave(a, c, p, family, stream);

@@ -1,33 +1,73 @@
-// spmm_rowgroup.h -- family 10: 8 destination rows per wave over the union of their columns.
+// spmm_rowgroup.h -- family 10: G destination rows per wave over the union of their columns.
 // Part of remap_spmm.hip: included there inside namespace remap::(anonymous),
 // in the order given there; not a stand-alone header.
 // ---------------------------------------------------------------------------
-// rowgroup: one wave computes 8 destination rows at once (8 consecutive work
-// slots: a 2 x 4 tile of a 2-D destination grid) over the sorted UNION of
-// their columns.  Each distinct source-row chunk is loaded ONCE per group and
-// feeds up to 8 accumulators; neighbouring rows share most of their source
-// rows (2-3x fewer loads on wide stencils), and the L1-fill stream -- the
-// resource that bounds the entry-rich mappings --
-// shrinks by that factor.  Every row still adds its own entries in ascending
-// column order: bit-identical to the other families.
+// rowgroup: one wave computes G (8 or 4) destination rows at once -- G
+// consecutive work slots: a 2 x 4 (2 x 2) tile of a 2-D destination grid --
+// over the sorted UNION of their columns.  Each distinct source-row chunk is
+// loaded ONCE per group and feeds up to G accumulators; neighbouring rows
+// share most of their source rows (2-3x fewer loads on wide stencils), and
+// the L1-fill stream -- the resource that bounds the entry-rich mappings
+//  -- shrinks by that factor.  Every row still adds its
+// own entries in ascending column order: bit-identical to the other families.
 //
-// Per step of 8 union entries: columns and presence masks through the scalar
-// cache (2 x s_load_dwordx8), the 8 x 8 weights with ONE coalesced vector
-// load (lane = entry * 8 + member) broadcast by v_readlane with constant lane
-// numbers, X via buffer descriptors as in rowscalar.
+// Schedule layout (built once per mapping, remap_apply_args.group_*):
+//   group_meta  int64 pairs (first union entry, first weight) per group
+//   group_col   the union's source rows, ascending within a group
+//   group_mask  bit m set = the group's m-th row owns this union entry
+//   group_w     the weights of the PRESENT (union entry, member) pairs only,
+//               in (entry, member) order: exactly nnz doubles -- a dense
+//               G-wide block per union entry cost 64 B where ~13 B are real
+//   group_rid   row id of every work slot, group_frac its frac_b
+//
+// Per step of UNR union entries: columns and presence masks through the
+// scalar cache (s_load_dwordx8), the step's weights with ONE coalesced vector
+// load (lane j = j-th present pair of the step) handed to the scalar side by
+// v_readlane with a running scalar index, X via buffer descriptors as in
+// rowscalar.  Row ids and frac_b of the G rows arrive by two wide s_loads.
 // ---------------------------------------------------------------------------
-constexpr int kGroup = 8;
+template <int N>
+struct I32Vec;
+template <>
+struct I32Vec<4> {
+    typedef int32_t type __attribute__((ext_vector_type(4), aligned(4)));
+};
+template <>
+struct I32Vec<8> {
+    typedef int32_t type __attribute__((ext_vector_type(8), aligned(4)));
+};
+template <>
+struct I32Vec<16> {
+    typedef int32_t type __attribute__((ext_vector_type(16), aligned(4)));
+};
+template <int N>
+struct F64Vec;
+template <>
+struct F64Vec<16> {
+    typedef double type __attribute__((ext_vector_type(16), aligned(8)));
+};
+template <>
+struct F64Vec<4> {
+    typedef double type __attribute__((ext_vector_type(4), aligned(8)));
+};
+template <>
+struct F64Vec<8> {
+    typedef double type __attribute__((ext_vector_type(8), aligned(8)));
+};
 
-template <typename XT, int TILES, int MODE, bool FMA>
+template <typename XT, int TILES, int MODE, bool FMA, int G, int UNR>
 __global__ __launch_bounds__(kBlock) void spmm_rowgroup(
     const KParams p, const uint32_t flags,
-    const int64_t *__restrict__ gptr, const int32_t *__restrict__ gcol,
+    const int64_t *__restrict__ gmeta, const int32_t *__restrict__ gcol,
     const double *__restrict__ gw, const int32_t *__restrict__ gmask,
-    const int32_t *__restrict__ row_order, const double *__restrict__ frac_b,
+    const int32_t *__restrict__ grid, const double *__restrict__ gfrac,
     const XT *__restrict__ X)
 {
     constexpr int VEC = 2;
     typedef typename XVec<XT, VEC>::type xvec_t;
+    typedef typename I32Vec<UNR>::type ivec_t;
+    typedef typename I32Vec<G>::type rvec_t;
+    typedef typename F64Vec<G>::type fvec_t;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t L = logical_block(p);
@@ -43,33 +83,26 @@ __global__ __launch_bounds__(kBlock) void spmm_rowgroup(
 #pragma unroll
     for (int t = 0; t < TILES; ++t)
         xo[t] = static_cast<uint32_t>(xoff[t] * sizeof(XT));
-    const int64_t n_groups_here =
-        (p.row_end - p.row_begin + kGroup - 1) / kGroup;
+    const int64_t n_groups_here = (p.row_end - p.row_begin + G - 1) / G;
     const int64_t block_g0 = rb * (int64_t)(kWavesPerBlock * p.rows_per_wave);
 
     for (int r = 0; r < p.rows_per_wave; ++r) {
         const int64_t g = block_g0 + (int64_t)r * kWavesPerBlock + wave;
         if (g >= n_groups_here)
             break;
-        const int64_t slot0 = p.row_begin + g * kGroup;
-        const int nmem = (p.row_end - slot0) < kGroup
-                             ? static_cast<int>(p.row_end - slot0) : kGroup;
-        // member m <-> lane m: row id and frac_b of the group's rows
-        int32_t my_rid = 0;
-        double my_fb = 0.0;
-        if (lane < nmem) {
-            my_rid = row_order ? row_order[slot0 + lane]
-                               : static_cast<int32_t>(slot0 + lane);
-            if constexpr (MODE == REMAP_MODE_FRACB)
-                my_fb = frac_b[my_rid];
-        }
-        const int64_t s = gptr[g];
-        const int64_t e = gptr[g + 1];
+        const int64_t slot0 = g * G;  // relative to row_begin
+        const int nmem = (p.row_end - p.row_begin - slot0) < G
+                             ? static_cast<int>(p.row_end - p.row_begin -
+                                                slot0)
+                             : G;
+        const int64_t s = gmeta[2 * g];
+        int64_t woff = gmeta[2 * g + 1];
+        const int64_t e = gmeta[2 * g + 2];
 
-        double acc[kGroup][TILES][VEC];
-        double den[kGroup][TILES][VEC];
+        double acc[G][TILES][VEC];
+        double den[G][TILES][VEC];
 #pragma unroll
-        for (int m = 0; m < kGroup; ++m)
+        for (int m = 0; m < G; ++m)
 #pragma unroll
             for (int t = 0; t < TILES; ++t)
 #pragma unroll
@@ -78,17 +111,21 @@ __global__ __launch_bounds__(kBlock) void spmm_rowgroup(
                     den[m][t][v] = 0.0;
                 }
 
-        for (int64_t base = s; base < e; base += 8) {
-            const int n = (e - base) < 8 ? static_cast<int>(e - base) : 8;
-            const i32x8 c8 = *reinterpret_cast<const i32x8 *>(gcol + base);
-            const i32x8 m8 = *reinterpret_cast<const i32x8 *>(gmask + base);
-            // weights of 8 union entries x 8 members: lane = entry * 8 + m
-            const double my_w = gw[base * kGroup + lane];
-            xvec_t xv[8][TILES];
+        // one step: UNR union entries, their X loads all in flight, then the
+        // present (entry, member) pairs in order
+        auto step = [&](const ivec_t &cv, const ivec_t &mv, const int n) {
+            // the step's present weights, one per lane, in (entry, member)
+            // order (lanes past the step's count read the next step's)
+            constexpr int NW = (UNR * G + kWave - 1) / kWave;
+            double my_w[NW];
 #pragma unroll
-            for (int uu = 0; uu < 8; ++uu) {
+            for (int q = 0; q < NW; ++q)
+                my_w[q] = gw[woff + q * kWave + lane];
+            xvec_t xv[UNR][TILES];
+#pragma unroll
+            for (int uu = 0; uu < UNR; ++uu) {
                 if (uu < n) {
-                    int32_t c = c8[uu];
+                    int32_t c = cv[uu];
                     REMAP_DIAG_COL(p, c);
                     const __amdgpu_buffer_rsrc_t xr =
                         row_rsrc(X + static_cast<int64_t>(c) * p.ldx);
@@ -98,15 +135,22 @@ __global__ __launch_bounds__(kBlock) void spmm_rowgroup(
                 }
             }
             asm volatile("" ::: "memory");  // loads stay ahead of their uses
+            int idx = 0;  // scalar: next weight of the step
 #pragma unroll
-            for (int uu = 0; uu < 8; ++uu) {
+            for (int uu = 0; uu < UNR; ++uu) {
                 if (uu < n) {
-                    const int32_t bits = m8[uu];
+                    const int32_t bits = mv[uu];
 #pragma unroll
-                    for (int m = 0; m < kGroup; ++m) {
+                    for (int m = 0; m < G; ++m) {
                         if (bits & (1 << m)) {
-                            const double a =
-                                readlane_f64(my_w, uu * kGroup + m);
+                            double a;
+                            if constexpr (NW == 1)
+                                a = readlane_f64(my_w[0], idx);
+                            else
+                                a = idx < kWave
+                                        ? readlane_f64(my_w[0], idx)
+                                        : readlane_f64(my_w[1], idx - kWave);
+                            ++idx;
 #pragma unroll
                             for (int t = 0; t < TILES; ++t)
 #pragma unroll
@@ -129,15 +173,32 @@ __global__ __launch_bounds__(kBlock) void spmm_rowgroup(
                     }
                 }
             }
+            woff += idx;
+        };
+
+        for (int64_t base = s; base < e; base += UNR) {
+            const int n = (e - base) < UNR ? static_cast<int>(e - base) : UNR;
+            const ivec_t cv = *reinterpret_cast<const ivec_t *>(gcol + base);
+            const ivec_t mv = *reinterpret_cast<const ivec_t *>(gmask + base);
+            step(cv, mv, n);
         }
 
+        // the group's row ids and frac_b, in slot order (padded to whole
+        // groups by the host): two wide scalar loads.  (Gathering them, the
+        // list bounds and the first 8 entries in one header record per group
+        // -- one scalar trip instead of four -- was built and measured:
+        // 0.3691 vs 0.3683 ms on config 3, no gain; removed.)
+        const rvec_t rid = *reinterpret_cast<const rvec_t *>(grid + slot0);
+        fvec_t fbv;
+        if constexpr (MODE == REMAP_MODE_FRACB)
+            fbv = *reinterpret_cast<const fvec_t *>(gfrac + slot0);
 #pragma unroll
-        for (int m = 0; m < kGroup; ++m) {
+        for (int m = 0; m < G; ++m) {
             if (m < nmem) {
-                const int64_t i = __builtin_amdgcn_readlane(my_rid, m);
+                const int64_t i = rid[m];
                 double fb = 0.0;
                 if constexpr (MODE == REMAP_MODE_FRACB)
-                    fb = readlane_f64(my_fb, m);
+                    fb = fbv[m];
                 finish_row<VEC, TILES, MODE>(p, i, fb, act, yoff, acc[m],
                                              den[m]);
             }

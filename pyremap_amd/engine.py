@@ -28,11 +28,12 @@ MODE_MASKED = 2
 
 FLAG_FMA = 1
 FLAG_TUNE_HINT = 4
+FLAG_TREE = 8
 
 DTYPE_F64 = 0
 DTYPE_F32 = 1
 
-ABI_VERSION = 10
+ABI_VERSION = 12
 
 #: readable pad entries kept behind col/val (remap_csr.csr_pad)
 CSR_PAD = 8
@@ -87,11 +88,15 @@ class _ApplyArgs(ctypes.Structure):
         ('patch_emax', ctypes.c_int32),
         ('patch_row_bytes', ctypes.c_int32),
         ('n_patches', ctypes.c_int64),
-        ('group_ptr', ctypes.c_void_p),
+        ('group_meta', ctypes.c_void_p),
         ('group_col', ctypes.c_void_p),
         ('group_w', ctypes.c_void_p),
         ('group_mask', ctypes.c_void_p),
+        ('group_rid', ctypes.c_void_p),
+        ('group_frac', ctypes.c_void_p),
         ('n_groups', ctypes.c_int64),
+        ('group_rows', ctypes.c_int32),
+        ('group_reserved', ctypes.c_int32),
         ('flags', ctypes.c_uint32),
         ('tune', ctypes.c_int32 * 8),
     ]
@@ -512,22 +517,28 @@ class RemapPlan:
             row_bytes=int(row_bytes))
         return uniq.shape[0] / self.nnz
 
-    GROUP = 8   # rows per group (remap_apply_args.group_*)
+    GROUP = 8   # default rows per group (remap_apply_args.group_rows)
 
-    def build_groups(self, grid_dims=None, super_tile=32):
+    def build_groups(self, grid_dims=None, super_tile=32, rows=None):
         """
-        Build the row-group schedule (``remap_apply_args.group_*``): 8
-        consecutive work slots -- a 2 x 4 tile of a 2-D destination grid --
-        share one sorted list of the distinct source rows they reference.
-        Returns union entries / entries (small = many shared source rows).
+        Build the row-group schedule (``remap_apply_args.group_*``): ``rows``
+        (8 or 4) consecutive work slots -- a 2 x 4 or 2 x 2 tile of a 2-D
+        destination grid -- share one sorted list of the distinct source rows
+        they reference; the weights are stored for the present (union entry,
+        member) pairs only, in that order.  Returns union entries / entries
+        (small = many shared source rows).
         """
         torch = _torch()
-        G = self.GROUP
+        G = int(rows or self.GROUP)
+        if G not in (4, 8, 16):
+            raise ValueError('row groups hold 4, 8 or 16 rows')
+        gy = 4 if G == 16 else 2     # the group is a gy x gx tile
+        gx = G // gy
         self.groups = None
         if self.nnz == 0 or self.n_b == 0:
             return None
         if grid_dims is not None and len(grid_dims) == 2:
-            # 2 x 4 groups, walked row-major INSIDE super_tile x super_tile
+            # 2 x gx groups, walked row-major INSIDE super_tile x super_tile
             # blocks of the grid (keeps a group's neighbours -- and the
             # stencil band they share -- in the XCD's L2)
             my, mx = (int(d) for d in grid_dims)
@@ -535,14 +546,14 @@ class RemapPlan:
                 raise ValueError(f'grid {grid_dims} does not hold '
                                  f'{self.n_b_global} cells')
             st = int(super_tile)
-            rows = torch.arange(self.row_offset, self.row_offset + self.n_b,
-                                device=self.device, dtype=torch.int64)
-            jy = rows // mx
-            jx = rows - jy * mx
+            rows_i = torch.arange(self.row_offset, self.row_offset + self.n_b,
+                                  device=self.device, dtype=torch.int64)
+            jy = rows_i // mx
+            jx = rows_i - jy * mx
             nsx = (mx + st - 1) // st
             key = ((jy // st) * nsx + jx // st) * (st * st) + \
-                (((jy % st) // 2) * (st // 4) + (jx % st) // 4) * 8 + \
-                (jy % 2) * 4 + jx % 4
+                (((jy % st) // gy) * (st // gx) + (jx % st) // gx) * G + \
+                (jy % gy) * gx + jx % gx
             self.row_order = torch.argsort(key, stable=True).to(torch.int32)
             order = self.row_order
             slot_of_row = torch.empty(self.n_b, dtype=torch.int64,
@@ -561,18 +572,31 @@ class RemapPlan:
         key = group_of_entry * self.n_a + self.col.to(torch.int64)
         uniq, inverse = torch.unique(key, sorted=True, return_inverse=True)
         nu = int(uniq.shape[0])
-        ptr = torch.zeros(n_groups + 1, dtype=torch.int64,
-                          device=self.device)
-        ptr[1:] = torch.cumsum(torch.bincount(uniq // self.n_a,
-                                              minlength=n_groups), 0)
-        w = torch.zeros((nu + 8) * G, dtype=torch.float64,
+        meta = torch.zeros((n_groups + 1, 2), dtype=torch.int64,
+                           device=self.device)
+        meta[1:, 0] = torch.cumsum(torch.bincount(uniq // self.n_a,
+                                                  minlength=n_groups), 0)
+        meta[1:, 1] = torch.cumsum(torch.bincount(group_of_entry,
+                                                  minlength=n_groups), 0)
+        # weights of the present pairs in (union entry, member) order; a
+        # canonical CSR (unique (row, col) pairs: from_triplets / from_csr
+        # guarantee it) gives every pair one weight and one mask bit
+        perm = torch.argsort(inverse * G + member)
+        w = torch.zeros(self.nnz + 64, dtype=torch.float64,
                         device=self.device)
-        w[inverse * G + member] = self.val
+        w[:self.nnz] = self.val[perm]
         mask = torch.zeros(nu + 8, dtype=torch.int32, device=self.device)
         mask.index_add_(0, inverse, (1 << member).to(torch.int32))
         col = torch.zeros(nu + 8, dtype=torch.int32, device=self.device)
         col[:nu] = (uniq % self.n_a).to(torch.int32)
-        self.groups = dict(ptr=ptr, col=col, w=w, mask=mask, n=n_groups,
+        # row id and frac_b of every work slot, padded to whole groups
+        rid = torch.full((n_groups * G,), max(self.n_b - 1, 0),
+                         dtype=torch.int32, device=self.device)
+        rid[:self.n_b] = order if order is not None else torch.arange(
+            self.n_b, device=self.device, dtype=torch.int32)
+        frac = self.frac_b[rid.to(torch.int64)].contiguous()
+        self.groups = dict(meta=meta.contiguous(), col=col, w=w, mask=mask,
+                           rid=rid, frac=frac, n=n_groups, rows=G,
                            order=order, union=nu)
         return nu / self.nnz
 
@@ -627,19 +651,22 @@ class RemapPlan:
                 break
         self.patches = None
         self.row_order = None
-        # Row groups: 8 neighbouring rows per wave over the union of their
+        # Row groups: G neighbouring rows per wave over the union of their
         # columns (family 10).  Measured:
-        #  * entry-rich rows (>= 10 entries: wide stencils, config 5): groups
-        #    nested in 32 x 32 supertiles so the stencil band stays in the
-        #    XCD's L2 -- 1.9x in frac_b mode (2 K-tiles), 1.2x masked (1);
-        #  * other mappings: groups in row-major order, +3..6 % in frac_b /
-        #    raw mode; masked mode keeps the rowscalar kernel (the group
-        #    kernel's 120 VGPRs cost occupancy there).
-        # Only when rows really share columns (union / entries <= 0.85).
+        #  * entry-rich rows (>= 10 entries: wide stencils, config 5): 2 x 4
+        #    groups nested in 32 x 32 supertiles so the stencil band stays in
+        #    the XCD's L2, 2 K-tiles x 2 groups per wave (1 K-tile masked);
+        #  * other mappings: 2 x 2 groups in row-major order, one group per
+        #    wave -- config 3: 0.362-0.369 ms in every mode against 0.392
+        #    for the wave-per-row kernel; 2 x 4 groups tie in frac_b mode
+        #    and lose 5 % in the masked mode (their second accumulator set
+        #    costs two waves per SIMD).
+        # Only when rows share columns at all (union / entries <= 0.95).
         two_d = len(dims) == 2
         ratio = self.build_groups(dims if two_d else None,
-                                  super_tile=32 if entry_rich else 1 << 30)
-        if ratio is not None and ratio <= 0.85:
+                                  super_tile=32 if entry_rich else 1 << 30,
+                                  rows=8 if entry_rich else 4)
+        if ratio is not None and ratio <= 0.95:
             if entry_rich:
                 self.default_tune = {MODE_RAW: [10, 0, 2, 2],
                                      MODE_FRACB: [10, 0, 2, 2],
@@ -647,11 +674,12 @@ class RemapPlan:
             else:
                 self.default_tune = {MODE_RAW: [10, 0, 0, 1],
                                      MODE_FRACB: [10, 0, 0, 1],
-                                     MODE_MASKED: None}
+                                     MODE_MASKED: [10, 0, 0, 1]}
             return {'family': 'rowgroup', 'union_ratio': ratio,
+                    'rows_per_group': self.groups['rows'],
                     'order': '2x4 groups in 32x32 supertiles' if entry_rich
-                    else '2x4 groups, row-major' if two_d else
-                    '8 consecutive rows', 'tune': self.default_tune}
+                    else '2x2 groups, row-major' if two_d else
+                    '4 consecutive rows', 'tune': self.default_tune}
         self.groups = None
         self.row_order = None
         if two_d and entry_rich:
@@ -766,11 +794,14 @@ def apply_strided(plan, X, Y, *, n_batch, k_inner, x_row_stride,
             and (plan.row_order is None) == (groups['order'] is None) \
             and (plan.row_order is None or
                  plan.row_order.data_ptr() == groups['order'].data_ptr()):
-        args.group_ptr = groups['ptr'].data_ptr()
+        args.group_meta = groups['meta'].data_ptr()
         args.group_col = groups['col'].data_ptr()
         args.group_w = groups['w'].data_ptr()
         args.group_mask = groups['mask'].data_ptr()
+        args.group_rid = groups['rid'].data_ptr()
+        args.group_frac = groups['frac'].data_ptr()
         args.n_groups = groups['n']
+        args.group_rows = groups['rows']
     args.flags = flags
     if not tune:
         # the plan's preference (auto_schedule); the library falls back to
@@ -828,7 +859,12 @@ def remap_tensor(plan, dst_grid_dims, field, remap_axes, mode, threshold=0.0,
     tail_shape = [int(field.shape[ax]) for ax in extra_axes if ax > lead]
     n_batch = _prod(lead_shape)
     k_inner = _prod(tail_shape)
-    direct = contiguous_block and (k_inner >= 8 or n_batch == 1)
+    # In-place addressing (strides instead of permute copies) whenever the
+    # source axes are adjacent: the wave-per-row kernels want a run of >= 8
+    # contiguous fields, the few-fields kernel (K <= 32: one 2-D field,
+    # monthly (Time, nCells) data) takes any strides
+    direct = contiguous_block and (
+        k_inner >= 8 or n_batch == 1 or n_batch * k_inner <= 32)
     sharded = plan.n_b != plan.n_b_global
     # rows stay flat for a shard (its rows are no whole grid) and when the
     # caller names no destination grid

@@ -8,8 +8,11 @@ the source rows it references (``remap_numpy.py:264-268``) -- so:
 
 * every rank holds the CSR rows of ONE contiguous, work-balanced range
   (:func:`row_shard_bounds`) and writes only its slab of Y;
-* the only exchange is ONE broadcast of the source field per batch
-  (:func:`broadcast_field`); there is no reduction collective;
+* the only exchange is the source field reaching the ranks once per batch:
+  ONE broadcast (:func:`broadcast_field`) or, cheaper on point-to-point xGMI,
+  each rank receiving only the band of source rows its shard references
+  (:func:`distribute_rows`); successive batches are pipelined behind the
+  kernel (:meth:`ShardedRemap.apply_pipelined`); no reduction collective;
 * :func:`gather_rows` assembles the slabs where a single tensor is wanted
   (reported separately from the compute phase).
 
@@ -58,6 +61,83 @@ def broadcast_field(field, src=0, group=None):
             dist.get_world_size(group) > 1:
         dist.broadcast(field, src=src, group=group)
     return field
+
+
+def source_row_range(col, n_a=None):
+    """
+    ``(lo, hi)``: the half-open range of source rows a shard's entries
+    reference (``col`` = the shard's column indices, any device).  On
+    mappings whose destination order follows the source mesh -- every
+    regridding map does, to the extent both grids cover the same sphere in a
+    similar order -- a contiguous destination-row shard needs a contiguous
+    band of about ``n_a / world`` source rows plus a halo, not all of X.
+    """
+    if col.numel() == 0:
+        return 0, 0
+    return int(col.min()), int(col.max()) + 1
+
+
+def exchange_row_ranges(lo, hi, device=None, group=None):
+    """Every rank's ``(lo, hi)`` (one small all_gather, at set-up time)."""
+    torch = _torch()
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or \
+            dist.get_world_size(group) == 1:
+        return [(int(lo), int(hi))]
+    world = dist.get_world_size(group)
+    mine = torch.tensor([int(lo), int(hi)], dtype=torch.int64, device=device)
+    got = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(got, mine, group=group)
+    return [tuple(int(v) for v in t.cpu()) for t in got]
+
+
+def distribute_rows(field, ranges, src=0, group=None, async_op=False):
+    """
+    The exchange step without a broadcast: ``src`` sends every other rank
+    ONLY the band of source rows its shard references (``ranges`` from
+    :func:`exchange_row_ranges`; rows are axis 0 of ``field``, which every
+    rank allocates at full size -- rows outside a rank's band are never read
+    by its kernel and stay as they are).
+
+    Why: xGMI is point to point (7 links x ~153 GB/s per GPU).  A broadcast
+    ring moves the whole field over every hop, so it costs ``bytes(X) / one
+    link``; the bands leave ``src`` over seven links at once and sum to about
+    ``bytes(X) * (1 + halo)``, i.e. ~``bytes(X) / 7`` per link.
+
+    Returns the list of outstanding requests when ``async_op`` (wait on them
+    before the first launch that reads ``field``), else ``None``.
+    """
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or \
+            dist.get_world_size(group) == 1:
+        return [] if async_op else None
+    rank = dist.get_rank(group)
+    world = dist.get_world_size(group)
+    ops = []
+    if rank == src:
+        for r in range(world):
+            lo, hi = ranges[r]
+            if r != src and hi > lo:
+                ops.append(dist.P2POp(dist.isend, field[lo:hi], r,
+                                      group=group))
+    else:
+        lo, hi = ranges[rank]
+        if hi > lo:
+            ops.append(dist.P2POp(dist.irecv, field[lo:hi], src,
+                                  group=group))
+    reqs = dist.batch_isend_irecv(ops) if ops else []
+    if async_op:
+        return reqs
+    for req in reqs:
+        req.wait()
+    return None
+
+
+def band_fraction(ranges, n_a):
+    """Bytes the bands move, as a fraction of one whole field per rank."""
+    if not ranges or n_a <= 0:
+        return 1.0
+    return sum(hi - lo for lo, hi in ranges) / (len(ranges) * n_a)
 
 
 def gather_rows(y_local, bounds, row_axis=0, group=None):
@@ -116,9 +196,71 @@ class ShardedRemap:
             if self.world_size > 1 else plan
         self.schedule = self.plan.auto_schedule(grid_dims) \
             if grid_dims is not None else None
+        #: band of source rows this rank's rows reference, and everyone's
+        self.src_range = source_row_range(self.plan.col)
+        in_group = dist.is_available() and dist.is_initialized() and \
+            dist.get_world_size(group) == self.world_size
+        if self.world_size == 1:
+            self.src_ranges = [self.src_range]
+        elif in_group:
+            self.src_ranges = exchange_row_ranges(
+                *self.src_range, device=self.plan.device, group=group)
+        else:
+            self.src_ranges = None   # ranks managed by the caller: no group
 
     def broadcast(self, field, src=0):
         return broadcast_field(field, src=src, group=self.group)
+
+    def distribute(self, field, src=0, how='auto', async_op=False):
+        """
+        The path's one exchange step.  ``how``: ``'broadcast'`` (the whole
+        field to every rank, one RCCL broadcast), ``'bands'`` (each rank gets
+        only the source rows its shard references, point to point) or
+        ``'auto'``: bands when they move less than 60 % of what a broadcast
+        delivers (on a raster-ordered mapping over 8 ranks: ~15 %).
+        ``field``: rows on axis 0, allocated at full size on every rank.
+        """
+        if self.world_size == 1:
+            return [] if async_op else field
+        if self.src_ranges is None:
+            raise RuntimeError('distribute() needs an initialised process '
+                               'group spanning the ranks of this remap')
+        if how == 'auto':
+            how = 'bands' if band_fraction(
+                self.src_ranges, self.plan.n_a) < 0.6 else 'broadcast'
+        if how == 'bands':
+            reqs = distribute_rows(field, self.src_ranges, src=src,
+                                   group=self.group, async_op=async_op)
+            return reqs if async_op else field
+        import torch.distributed as dist
+        work = dist.broadcast(field, src=src, group=self.group,
+                              async_op=async_op)
+        return [work] if async_op else field
+
+    def apply_pipelined(self, batches, mode, src=0, how='auto',
+                        threshold=0.0, flags=0, outs=None):
+        """
+        Remap a sequence of field batches (each ``(n_a, K_b)``, rows on axis
+        0, allocated on every rank; only ``src`` holds the data) with the
+        exchange of batch b + 1 in flight while batch b is computed: RCCL
+        works on its own streams, the kernel on torch's current stream, and
+        each launch waits only for its own batch's requests.  Returns the
+        list of this rank's output slabs.
+        """
+        from pyremap_amd import engine
+        results = []
+        pending = self.distribute(batches[0], src=src, how=how,
+                                  async_op=True) if batches else []
+        for b, x in enumerate(batches):
+            for req in pending:
+                req.wait()          # stream-orders the launch behind batch b
+            pending = self.distribute(batches[b + 1], src=src, how=how,
+                                      async_op=True) \
+                if b + 1 < len(batches) else []
+            results.append(engine.remap_tensor(
+                self.plan, None, x, [0], mode, threshold=threshold,
+                flags=flags, out=None if outs is None else outs[b]))
+        return results
 
     def apply(self, field, remap_axes, mode, threshold=0.0, flags=0,
               tune=None, out=None):

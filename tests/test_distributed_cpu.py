@@ -1,10 +1,12 @@
 """
-The N > 1 path on CPU: two processes, gloo backend.  What is exercised is the
-distributed plumbing of pyremap_amd.parallel -- work-balanced row sharding,
-the single broadcast of the source field, the row gather -- with the CPU
-oracle standing in for the HIP kernel as the per-rank compute (the kernel
-itself is covered by the -m gpu tests; shards there are checked in
-test_gpu_parity.py::test_row_range_and_shards).
+The N > 1 path on CPU: several processes, gloo backend.  What is exercised is
+the distributed plumbing of pyremap_amd.parallel -- work-balanced row
+sharding (uneven shards included), the exchange of the source field (one
+broadcast, or only the band of source rows each shard references, point to
+point), pipelined batches, the row gather, and the zero-collective
+field-sharded mode -- with the CPU oracle standing in for the HIP kernel as
+the per-rank compute (the kernel itself is covered by the -m gpu tests;
+shards there are checked in test_gpu_parity.py::test_row_range_and_shards).
 """
 import os
 import socket
@@ -26,57 +28,150 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, tmpdir):
+def _problem():
+    from oracle import oracle
+    from pyremap_amd import synthetic
+    m = synthetic.conservative_map(900, (20, 30), 1, 6, seed=5)
+    mm = m.numpy()
+    # a solid band of land (rows 0-199 empty): shards of equal WORK then
+    # hold unequal numbers of rows
+    keep = mm['row'] > 200
+    for key in ('row', 'col', 'S'):
+        mm[key] = mm[key][keep]
+    mm['frac_b'][:200] = 0.0
+    csr = oracle.coo_to_csr(mm['row'] - 1, mm['col'] - 1, mm['S'], m.n_b,
+                            m.n_a)
+    return m, mm, csr
+
+
+def _shard(csr, r0, r1, n_a):
+    from oracle import oracle
+    return oracle.OracleCSR(csr.indptr[r0:r1 + 1] - csr.indptr[r0],
+                            csr.indices[csr.indptr[r0]:csr.indptr[r1]],
+                            csr.data[csr.indptr[r0]:csr.indptr[r1]],
+                            (r1 - r0, n_a))
+
+
+def _worker(rank, world, port, tmpdir, how):
     sys.path.insert(0, REPO)
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         from oracle import oracle
-        from pyremap_amd import parallel, synthetic
-        m = synthetic.conservative_map(900, (20, 30), 1, 6, seed=5)
-        mm = m.numpy()
-        csr = oracle.coo_to_csr(mm['row'] - 1, mm['col'] - 1, mm['S'],
-                                m.n_b, m.n_a)
+        from pyremap_amd import parallel
+        m, mm, csr = _problem()
         K = 24
-        # only rank 0 has the field; everyone allocates the buffer
-        x = torch.zeros((m.n_a, K), dtype=torch.float64)
-        if rank == 0:
-            x = torch.from_numpy(
-                np.random.default_rng(0).standard_normal((m.n_a, K)))
-        parallel.broadcast_field(x, src=0)
-        bounds = parallel.row_shard_bounds(torch.from_numpy(csr.indptr),
-                                           world)
-        r0, r1 = bounds[rank], bounds[rank + 1]
-        shard = oracle.OracleCSR(csr.indptr[r0:r1 + 1] - csr.indptr[r0],
-                                 csr.indices[csr.indptr[r0]:csr.indptr[r1]],
-                                 csr.data[csr.indptr[r0]:csr.indptr[r1]],
-                                 (r1 - r0, m.n_a))
-        y_local, mask = oracle.remap_flat(shard, mm['frac_b'][r0:r1],
-                                          x.numpy(), False, 0.0)
-        y_local[mask] = np.nan
-        y = parallel.gather_rows(torch.from_numpy(y_local), bounds)
-        ref, ref_mask = oracle.remap_flat(csr, mm['frac_b'], x.numpy(),
-                                          False, 0.0)
+        rng = np.random.default_rng(0)
+        full_x = rng.standard_normal((m.n_a, K))
+        ref, ref_mask = oracle.remap_flat(csr, mm['frac_b'], full_x, False,
+                                          0.0)
         ref[ref_mask] = np.nan
-        ok = np.array_equal(y.numpy(), ref, equal_nan=True)
-        balanced = abs((r1 - r0) - m.n_b / world) < 0.35 * m.n_b
+        notes = {}
+        if how == 'fields':
+            # zero-collective mode: replicated weights, K split over ranks,
+            # every rank loads its own fields -- no communication at all
+            k0, k1 = rank * K // world, (rank + 1) * K // world
+            y, mask = oracle.remap_flat(csr, mm['frac_b'],
+                                        full_x[:, k0:k1], False, 0.0)
+            y[mask] = np.nan
+            ok = np.array_equal(y, ref[:, k0:k1], equal_nan=True)
+            r0 = r1 = 0
+        else:
+            bounds = parallel.row_shard_bounds(
+                torch.from_numpy(csr.indptr), world)
+            r0, r1 = bounds[rank], bounds[rank + 1]
+            shard = _shard(csr, r0, r1, m.n_a)
+            # only rank 0 has the field; everyone allocates the buffer, and
+            # poisons it so a row that never arrived cannot go unnoticed
+            x = torch.full((m.n_a, K), float('nan'), dtype=torch.float64)
+            if rank == 0:
+                x = torch.from_numpy(full_x.copy())
+            if how == 'broadcast':
+                parallel.broadcast_field(x, src=0)
+            else:
+                lo, hi = parallel.source_row_range(
+                    torch.from_numpy(shard.indices))
+                ranges = parallel.exchange_row_ranges(lo, hi)
+                assert ranges[rank] == (lo, hi) and len(ranges) == world
+                if how == 'bands':
+                    parallel.distribute_rows(x, ranges, src=0)
+                else:   # 'bands_async': two batches, second one in flight
+                    x2 = torch.full((m.n_a, K), float('nan'),
+                                    dtype=torch.float64)
+                    if rank == 0:
+                        x2 = torch.from_numpy(2.0 * full_x)
+                    reqs1 = parallel.distribute_rows(x, ranges, src=0,
+                                                     async_op=True)
+                    reqs2 = parallel.distribute_rows(x2, ranges, src=0,
+                                                     async_op=True)
+                    for req in reqs1 + reqs2:
+                        req.wait()
+                    y2, mask2 = oracle.remap_flat(
+                        shard, mm['frac_b'][r0:r1], x2.numpy(), False, 0.0)
+                    y2[mask2] = np.nan
+                    notes['second'] = int(np.array_equal(
+                        y2, 2.0 * ref[r0:r1], equal_nan=True))
+                notes['band_frac'] = parallel.band_fraction(ranges, m.n_a)
+                if rank != 0 and hi - lo < m.n_a:
+                    # rows outside the band were not sent
+                    outside = np.ones(m.n_a, bool)
+                    outside[lo:hi] = False
+                    notes['outside_nan'] = int(
+                        np.isnan(x.numpy()[outside]).all())
+            y_local, mask = oracle.remap_flat(shard, mm['frac_b'][r0:r1],
+                                              x.numpy(), False, 0.0)
+            y_local[mask] = np.nan
+            y = parallel.gather_rows(torch.from_numpy(y_local), bounds)
+            ok = np.array_equal(y.numpy(), ref, equal_nan=True)
+            work = [int(csr.indptr[bounds[i + 1]] - csr.indptr[bounds[i]]) +
+                    2 * (bounds[i + 1] - bounds[i]) for i in range(world)]
+            notes['balanced'] = int(max(work) <=
+                                    1.15 * sum(work) / world + 20)
+            notes['uneven'] = int(
+                max(bounds[i + 1] - bounds[i] for i in range(world)) >
+                1.1 * m.n_b / world)
         with open(os.path.join(tmpdir, f'rank{rank}.txt'), 'w') as f:
-            f.write(f'{int(ok)} {int(balanced)} {r0} {r1}')
+            f.write(repr(dict(ok=int(ok), r0=r0, r1=r1, **notes)))
     finally:
         dist.destroy_process_group()
 
 
-def test_row_sharded_remap_world_size_2(tmp_path):
-    world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)),
+def _run(tmp_path, world, how):
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), how),
              nprocs=world, join=True)
-    spans = []
-    for rank in range(world):
-        ok, balanced, r0, r1 = open(
-            tmp_path / f'rank{rank}.txt').read().split()
-        assert ok == '1', f'rank {rank}: gathered result differs'
-        assert balanced == '1'
-        spans.append((int(r0), int(r1)))
-    assert spans[0][0] == 0 and spans[0][1] == spans[1][0]
-    assert spans[1][1] == 600
+    out = [eval(open(tmp_path / f'rank{rank}.txt').read())
+           for rank in range(world)]
+    for rank, o in enumerate(out):
+        assert o['ok'] == 1, f'rank {rank} ({how}): result differs'
+    return out
+
+
+def test_row_sharded_remap_world_size_2(tmp_path):
+    out = _run(tmp_path, 2, 'broadcast')
+    assert all(o['balanced'] == 1 for o in out)
+    assert out[0]['r0'] == 0 and out[0]['r1'] == out[1]['r0']
+    assert out[1]['r1'] == 600
+
+
+def test_row_sharded_world_size_4_uneven_shards_bands(tmp_path):
+    """Four ranks, shards of equal work but unequal row counts, and each rank
+    receiving only the band of source rows it references."""
+    out = _run(tmp_path, 4, 'bands')
+    assert all(o['balanced'] == 1 for o in out)
+    assert any(o['uneven'] == 1 for o in out)
+    spans = [(o['r0'], o['r1']) for o in out]
+    assert spans[0][0] == 0 and spans[-1][1] == 600
+    assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    # the bands move clearly less than four whole fields would
+    assert out[0]['band_frac'] < 0.75
+    assert all(o.get('outside_nan', 1) == 1 for o in out)
+
+
+def test_row_sharded_pipelined_batches(tmp_path):
+    out = _run(tmp_path, 3, 'bands_async')
+    assert all(o['second'] == 1 for o in out)
+
+
+def test_field_sharded_needs_no_collective(tmp_path):
+    _run(tmp_path, 4, 'fields')

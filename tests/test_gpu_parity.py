@@ -740,12 +740,13 @@ def test_auto_schedule_picks_by_reuse(dev):
 
 
 # ---------------------------------------------------------------------------
-# row-group family: 8 rows per wave over the union of their columns
+# row-group family: 8 or 4 rows per wave over the union of their columns
 # ---------------------------------------------------------------------------
 
+@pytest.mark.parametrize('rows', [16, 8, 4])
 @pytest.mark.parametrize('grid', ['2d', '1d'])
 @pytest.mark.parametrize('K', [64, 128, 130, 320, 512])
-def test_rowgroup_kernel_bitwise(dev, grid, K):
+def test_rowgroup_kernel_bitwise(dev, grid, K, rows):
     from oracle import oracle
     from pyremap_amd import engine, synthetic
     # 1502 destination rows: the last group is partial; wide stencils
@@ -756,9 +757,13 @@ def test_rowgroup_kernel_bitwise(dev, grid, K):
     plan = engine.RemapPlan.from_triplets(mm['row'], mm['col'], mm['S'],
                                           mm['frac_b'], m.n_a, m.n_b,
                                           device=dev)
-    ratio = plan.build_groups(m.dst_dims if grid == '2d' else None)
+    ratio = plan.build_groups(m.dst_dims if grid == '2d' else None,
+                              rows=rows)
     assert 0 < ratio <= 1
     assert (plan.row_order is not None) == (grid == '2d')
+    assert plan.groups['rows'] == rows
+    # the weights are stored once each: nnz of them (+ the readable pad)
+    assert plan.groups['w'].numel() == plan.nnz + 64
     csr = oracle.coo_to_csr(mm['row'] - 1, mm['col'] - 1, mm['S'], m.n_b,
                             m.n_a)
     rng = np.random.default_rng(K)
@@ -775,7 +780,8 @@ def test_rowgroup_kernel_bitwise(dev, grid, K):
             ref, ref_mask = oracle.remap_flat(csr, mm['frac_b'], x, masked,
                                               0.1)
             ref[ref_mask] = np.nan
-        for tune in ([10], [10, 0, 2, 1], [10, 0, 1, 3, 1]):
+        for tune in ([10], [10, 0, 2, 1], [10, 0, 1, 3, 1],
+                     [10, 0, 1, 2, 0, 4], [10, 0, 2, 1, 0, 4]):
             y = torch.full((m.n_b, K), 3.0, dtype=torch.float64, device=dev)
             mask = torch.full((m.n_b, K), 7, dtype=torch.uint8, device=dev)
             engine.apply_strided(plan, xd, y, n_batch=1, k_inner=K,
@@ -1149,7 +1155,10 @@ def test_config1_end_to_end(dev, tmp_path):
                    attrs={'units': 'K'})
     out = r.remap_numpy(da)
     assert out.dims == ('lat', 'lon') and out.values.shape == (360, 720)
-    assert out.values.dtype == np.float64 and out.attrs == {'units': 'K'}
+    assert out.values.dtype == np.float64
+    # remap_numpy.py:60-69: history and mesh_name are added to the result
+    assert out.attrs['units'] == 'K' and \
+        out.attrs['mesh_name'] == '0.5x0.5degree' and 'history' in out.attrs
     ref = oracle.remap_numpy_array(csr, mm['frac_b'], m.dst_dims, field,
                                    [0, 1], None)
     assert_bitwise(out.values, np.ma.filled(ref, np.nan), 'config1 2-D')
@@ -1193,3 +1202,91 @@ def test_config1_end_to_end(dev, tmp_path):
     for name in ('sst', 'ice', 'monthly', 'month'):
         assert_bitwise(back[name].values, out[name].values,
                        f'config1 file {name}')
+
+
+# ---------------------------------------------------------------------------
+# the few-fields path (K <= 32): one 2-D field, (Time, nCells) monthly data
+# ---------------------------------------------------------------------------
+
+FEW_LAYOUTS = [
+    # shape builder (n_a -> shape), remap axis
+    ('n', lambda n: (n,), 0),                    # one field, K = 1
+    ('nk5', lambda n: (n, 5), 0),
+    ('tn12', lambda n: (12, n), 1),              # (Time, nCells)
+    ('tnl', lambda n: (3, n, 7), 1),             # (Time, nCells, 7 levels)
+    ('nk32', lambda n: (n, 32), 0),
+]
+
+
+@pytest.mark.parametrize('tune', [None, [2], [3], [3, 4], [3, 8]])
+@pytest.mark.parametrize('layout', FEW_LAYOUTS, ids=[f[0] for f in
+                                                    FEW_LAYOUTS])
+def test_few_fields_kernels_bitwise(problem, dev, layout, tune):
+    """
+    remap_numpy.py:240-256 with few batched fields: both small-K kernel
+    families (lane per (row, k); sub-group of 8 or 4 lanes per row with the
+    products added in CSR order), f32 and f64, three modes, every layout
+    addressed IN PLACE -- bit for bit the reference's values.
+    """
+    from oracle import oracle
+    from pyremap_amd import engine
+    p = problem
+    _, shape_of, axis = layout
+    rng = np.random.default_rng(len(shape_of(3)) * 7 + axis)
+    for dtype in (np.float64, np.float32):
+        x = rng.standard_normal(shape_of(p['n_a'])).astype(dtype)
+        dead = rng.random(p['n_a']) < 0.2
+        xm = x.copy()
+        xm[(slice(None),) * axis + (dead,)] = np.nan
+        for emode, masked, field in ((engine.MODE_FRACB, False, x),
+                                     (engine.MODE_MASKED, True, xm)):
+            arg = np.ma.masked_array(field, np.isnan(field)) if masked \
+                else field
+            ref = oracle.remap_numpy_array(
+                p['csr'], p['frac_b'], (p['n_b'],), arg, [axis],
+                0.1 if masked else None)
+            y = engine.remap_tensor(p['plan'], (p['n_b'],),
+                                    torch.from_numpy(field).to(dev), [axis],
+                                    emode, threshold=0.1, tune=tune)
+            assert_bitwise(y.cpu().numpy(), np.ma.filled(ref, np.nan),
+                           f'{layout[0]} {dtype.__name__} {emode} {tune}')
+
+
+def test_few_fields_are_addressed_in_place(problem, dev, monkeypatch):
+    """A (Time, nCells) field takes ONE launch and no permute copy."""
+    from pyremap_amd import engine
+    p = problem
+    calls = []
+    real = engine.apply_strided
+
+    def spy(plan, X, Y, **kw):
+        calls.append((X.data_ptr(), kw['n_batch'], kw['k_inner'],
+                      kw['x_row_stride'], kw['x_batch_stride']))
+        return real(plan, X, Y, **kw)
+    monkeypatch.setattr(engine, 'apply_strided', spy)
+    x = torch.randn((12, p['n_a']), dtype=torch.float64, device=dev)
+    engine.remap_tensor(p['plan'], (p['n_b'],), x, [1], engine.MODE_FRACB)
+    assert calls == [(x.data_ptr(), 12, 1, 1, p['n_a'])]
+
+
+def test_tree_flag_is_close_not_identical(problem, dev):
+    """REMAP_FLAG_TREE (opt-in): butterfly sums, rtol 1e-13, not the bits."""
+    from oracle import oracle
+    from pyremap_amd import engine
+    p = problem
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((p['n_a'], 3))
+    ref, ref_mask = oracle.remap_flat(p['csr'], p['frac_b'], x, False, 0.0)
+    xd = torch.from_numpy(x).to(dev)
+    ys = {}
+    for flags in (0, engine.FLAG_TREE):
+        y = engine.remap_tensor(p['plan'], (p['n_b'],), xd, [0],
+                                engine.MODE_FRACB, flags=flags)
+        ys[flags] = y.cpu().numpy()
+    ok = ~ref_mask
+    assert_bitwise(np.where(ok, ys[0], 0.0), np.where(ok, ref, 0.0))
+    scale = np.abs(ref[ok]).max()
+    assert np.abs(ys[engine.FLAG_TREE][ok] - ref[ok]).max() <= 1e-13 * scale
+    assert np.array_equal(np.isnan(ys[engine.FLAG_TREE]), ref_mask)
+    # long rows make the association visible
+    assert not np.array_equal(ys[engine.FLAG_TREE][ok], ref[ok])

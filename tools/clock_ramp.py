@@ -56,7 +56,7 @@ def main():
         torch.cuda.synchronize()
         time.sleep(idle_s)
         if busy:
-            for _ in range(40):          # ~ 6.5 ms of streaming copies
+            for _ in range(int(busy)):   # 256 MiB copies, ~0.085 ms each
                 engine.stream_copy(big_b, big_a)
         for i in range(args.warmup):
             launch(i)
@@ -72,7 +72,7 @@ def main():
         torch.cuda.synchronize()
         time.sleep(idle_s)
         if busy:
-            for _ in range(40):
+            for _ in range(int(busy)):
                 engine.stream_copy(big_b, big_a)
         for i in range(args.warmup):
             launch(i)
@@ -88,10 +88,12 @@ def main():
         per = [x.elapsed_time(y) for x, y in ev]
         return whole, per
 
-    for busy in (False, True):
-        print(f'--- GPU {"kept busy by copies before" if busy else "idle before"}'
-              f' the warm-up; warmup {args.warmup}, steps {args.steps}')
-        for idle in (0.0, 0.001, 0.01, 0.1, 1.0):
+    for busy in (0, 80, 240, 800, 2400):
+        print(f'--- {busy} x 256 MiB copies (~{busy * 0.085:.0f} ms busy) '
+              f'between the idle gap and the warm-up; warmup {args.warmup}, '
+              f'steps {args.steps}')
+        for idle in ((0.0, 0.001, 0.01, 0.1, 1.0) if busy == 0 else
+                     (0.1, 1.0)):
             for rep in range(2):
                 whole, per = region(idle, busy)
                 s = sorted(per)

@@ -68,10 +68,12 @@ def main():
     group_sets = {}
     for o in args.orders.split(';'):
         if o.startswith('group'):
-            st = int(o.split(':')[1]) if ':' in o else 32
+            # group:<supertile>[:<rows per group>]
+            parts = o.split(':')
+            st = int(parts[1]) if len(parts) > 1 else 32
             ratio = plan.build_groups(
                 None if o.startswith('group1d') else m.dst_dims,
-                super_tile=st)
+                super_tile=st, rows=int(parts[2]) if len(parts) > 2 else 8)
             print(f'{o}: union/nnz = {ratio}')
             orders[o] = plan.row_order
             group_sets[o] = plan.groups
