@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define REMAP_ABI_VERSION 12
+#define REMAP_ABI_VERSION 13
 
 enum {
     REMAP_OK = 0,
@@ -75,7 +75,7 @@ enum {
      * cannot serve this call (K <= 32, odd strides, a partial row range, a
      * missing schedule ...) choose automatically instead of failing */
     REMAP_FLAG_TUNE_HINT = 1u << 2,
-    /* few-fields calls (K <= 32, kernel family 3) may add a row's products
+    /* calls served by kernel family 3 (K <= 32, opt-in) may add a row's products
      * by lane-private partial sums and a butterfly across lanes instead of
      * one after the other in CSR order: a different association, within
      * 1e-13 relative of the default -- for callers that do not need the
@@ -191,13 +191,23 @@ typedef struct remap_apply_args {
     int64_t n_groups;
     int32_t group_rows;         /* G: 8 or 4                                */
     int32_t group_reserved;     /* must be 0                                */
+    /* Optional device-side switch (NULL = always run): the launch does its
+     * work only if the int32 at `gate` equals `gate_value` when the kernel
+     * starts, and is a no-op otherwise.  With remap_scan_nan() this moves
+     * the reference's `isnan(values).any()` decision (remap_numpy.py:201-204:
+     * masked branch iff the field holds a NaN) onto the device: scan into a
+     * flag, then enqueue the MASKED call gated on 1 and the FRACB call gated
+     * on 0 -- no host synchronisation in between.                           */
+    const int32_t *gate;    /* (device) optional                             */
+    int32_t gate_value;
     uint32_t flags;         /* REMAP_FLAG_*                                  */
     /* launch tuning, 0 = choose automatically:
      * tune[0] kernel family   1 = wave per row (lanes across K),
      *                         2 = lane per (row, k) (small K),
      *                         3 = a sub-group of lanes per row, lanes across
-     *                             the row's entries (K <= 32: the default
-     *                             there; tune[1] = lanes per row, 8 or 4),
+     *                             the row's entries (K <= 32, opt-in: it
+     *                             measured slower than 2; tune[1] = lanes
+     *                             per row, 8 or 4),
      *                         5 = LDS-staged patches (needs a patch plan),
      *                         10 = G rows per wave over the union of their
      *                              columns (needs the row-group schedule),
@@ -250,6 +260,14 @@ int remap_csr_from_coo(int64_t n_rows, int64_t n_cols, int64_t nnz,
                        int64_t *rowptr_out, int32_t *col_out,
                        double *val_out, int64_t *nnz_out, int64_t *bad_out,
                        void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * OR 1 into *flag (device int32, zeroed by the caller) if any of the n
+ * elements of x (device, REMAP_DTYPE_*, 16-byte aligned) is a NaN.
+ * Asynchronous on `stream`; the device half of remap_numpy.py:201-204.
+ */
+int remap_scan_nan(const void *x, int32_t x_dtype, int64_t n, int32_t *flag,
+                   void *stream);
 
 /*
  * Device-to-device streaming copy of `bytes` (16 B per lane, grid-stride):

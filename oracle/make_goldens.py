@@ -208,7 +208,11 @@ def run_array_cases(ref, name, m, src_names, dst_names, cases):
         field = c['field']
         nanmask = np.isnan(field)
         wrap = c.get('wrap', 'auto')
-        if wrap == 'ma' or (wrap == 'auto' and nanmask.any()):
+        if wrap == 'explicit':
+            # a caller's own MaskedArray: the mask is NOT isnan(field)
+            arg = np.ma.masked_array(field, c['mask'])
+            out[f'c{i}_in_mask'] = np.asarray(c['mask'], dtype=np.bool_)
+        elif wrap == 'ma' or (wrap == 'auto' and nanmask.any()):
             arg = np.ma.masked_array(field, nanmask)
         else:
             arg = field
@@ -228,6 +232,47 @@ def run_array_cases(ref, name, m, src_names, dst_names, cases):
     np.savez_compressed(path, **out)
     print(f'wrote {path}: {len(cases)} cases, nnz_in={m["S"].shape[0]} '
           f'nnz_csr={csr.nnz}')
+
+
+# --------------------------------------------------------------------------
+# G5: MaskedArrays whose mask is not isnan(data) (remap_numpy.py:262-266)
+# --------------------------------------------------------------------------
+
+def golden_g5(ref):
+    rng = np.random.default_rng(55)
+    m = make_map(rng, (300,), (12, 15), 1, 6)
+    f = rng.standard_normal((300, 6))
+    # (a) finite values under the mask; (b) a NaN that is NOT masked (goes
+    # through `in_mask * in_field` and poisons every cell it touches);
+    # (c) NaNs under the mask; (d) both at once, and a 3-D field
+    mask_a = rng.random(f.shape) < 0.25
+    f_b = f.copy()
+    f_b[17, 2] = np.nan
+    f_b[150, 0] = np.nan
+    mask_b = rng.random(f.shape) < 0.15
+    mask_b[17, 2] = False
+    mask_b[150, 0] = False
+    f_c = f.copy()
+    mask_c = rng.random(f.shape) < 0.3
+    f_c[mask_c] = np.nan
+    f_d = rng.standard_normal((2, 300, 5))
+    mask_d = rng.random(f_d.shape) < 0.2
+    f_d[0, 40, :] = np.nan
+    mask_d[0, 40, :] = [True, False, True, False, False]
+    cases = [
+        dict(field=f, mask=mask_a, remap_axes=[0], thr=0.1, wrap='explicit'),
+        dict(field=f_b, mask=mask_b, remap_axes=[0], thr=0.1,
+             wrap='explicit'),
+        dict(field=f_c, mask=mask_c, remap_axes=[0], thr=0.3,
+             wrap='explicit'),
+        dict(field=f_d, mask=mask_d, remap_axes=[1], thr=0.05,
+             wrap='explicit'),
+        # no threshold: the mask is ignored altogether (:258-261, :268)
+        dict(field=f_b, mask=mask_b, remap_axes=[0], thr=None,
+             wrap='explicit'),
+    ]
+    run_array_cases(ref, 'g5_explicit_mask', m, ['nCells'], ['lat', 'lon'],
+                    cases)
 
 
 # --------------------------------------------------------------------------
@@ -563,6 +608,7 @@ def main():
     golden_g2(ref)
     golden_g3(ref)
     golden_unstable(ref)
+    golden_g5(ref)
 
 
 if __name__ == '__main__':

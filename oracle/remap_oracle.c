@@ -168,11 +168,39 @@ void oracle_csr_matvecs(int64_t n_row, int64_t K, const int64_t *Ap,
  * Then (277-278) out = ok ? num / den : num (undivided), mask_out = !ok.
  * mask_out uses numpy.ma's convention: 1 = masked (invalid).
  */
+void oracle_remap_flat_mask(int64_t n_b, int64_t K, const int64_t *Ap,
+                            const int32_t *Aj, const double *Ax,
+                            const double *frac_b, const double *X,
+                            const uint8_t *in_masked, int masked, double thr,
+                            double *out, uint8_t *mask_out, int nthreads);
+
 void oracle_remap_flat(int64_t n_b, int64_t K, const int64_t *Ap,
                        const int32_t *Aj, const double *Ax,
                        const double *frac_b, const double *X, int masked,
                        double thr, double *out, uint8_t *mask_out,
                        int nthreads)
+{
+    oracle_remap_flat_mask(n_b, K, Ap, Aj, Ax, frac_b, X, NULL, masked, thr,
+                           out, mask_out, nthreads);
+}
+
+/*
+ * The same with the input mask given EXPLICITLY (in_masked[a * K + k] != 0 =
+ * masked, numpy.ma's convention) instead of read off the NaNs: the general
+ * form of remap_numpy.py:262-266, where
+ *     in_mask = array(logical_not(in_field.mask), float)
+ *     num = matrix.dot(in_mask * in_field)      den = matrix.dot(in_mask)
+ * `in_mask * in_field` holds +0.0 under the mask (numpy.ma keeps the FIRST
+ * operand's data there) and 1.0 * data elsewhere -- so a NaN that is NOT
+ * masked reaches the product and makes every destination cell it touches
+ * NaN (unmasked), while den counts it as valid.  in_masked == NULL: the mask
+ * is isnan(X), which is what _remap_data_array builds (:201-204).
+ */
+void oracle_remap_flat_mask(int64_t n_b, int64_t K, const int64_t *Ap,
+                            const int32_t *Aj, const double *Ax,
+                            const double *frac_b, const double *X,
+                            const uint8_t *in_masked, int masked, double thr,
+                            double *out, uint8_t *mask_out, int nthreads)
 {
     int64_t i;
     (void)nthreads;
@@ -198,8 +226,10 @@ void oracle_remap_flat(int64_t n_b, int64_t K, const int64_t *Ap,
                 for (jj = Ap[i]; jj < Ap[i + 1]; jj++) {
                     const double a = Ax[jj];
                     const double *x = X + K * (int64_t)Aj[jj];
+                    const uint8_t *im =
+                        in_masked ? in_masked + K * (int64_t)Aj[jj] : NULL;
                     for (k = 0; k < K; k++) {
-                        const int valid = !isnan(x[k]);
+                        const int valid = im ? !im[k] : !isnan(x[k]);
                         const double xv = valid ? x[k] : 0.0;
                         const double mv = valid ? 1.0 : 0.0;
                         y[k] = y[k] + a * xv;

@@ -290,9 +290,7 @@ int launch_rowgroup(const remap_apply_args *a, const KParams &p, int tiles,
                     int unr, bool fma, int64_t grid, hipStream_t stream)
 {
     typename GroupFn<XT>::type fn =
-        a->group_rows == 16
-            ? pick_rowgroup_shape<XT, 16>(unr, tiles, a->mode, fma)
-        : a->group_rows == 8
+        a->group_rows == 8
             ? pick_rowgroup_shape<XT, 8>(unr, tiles, a->mode, fma)
             : pick_rowgroup_shape<XT, 4>(unr, tiles, a->mode, fma);
     uint32_t lds_bytes = 0;
@@ -387,8 +385,7 @@ int check_args(const remap_apply_args *a, Call &c)
     c.patch_ok = patch_usable(a, c.K, c.f32, c.can_vec2);
     c.group_ok = a->group_meta && a->group_col && a->group_w &&
                  a->group_mask && a->group_rid && a->group_frac &&
-                 (a->group_rows == 16 || a->group_rows == 8 ||
-                  a->group_rows == 4) &&
+                 (a->group_rows == 8 || a->group_rows == 4) &&
                  a->group_reserved == 0 &&
                  a->n_groups ==
                      (c.n_rows + a->group_rows - 1) / a->group_rows;
@@ -406,6 +403,8 @@ KParams base_params(const remap_apply_args *a, const Call &c)
     p.frac_b = a->frac_b;
     p.mask_out = a->mask_out;
     p.row_order = a->row_order;
+    p.gate = a->gate;
+    p.gate_value = a->gate_value;
 #ifdef REMAP_DIAG
     p.diag = a->tune[6];
 #endif
@@ -429,7 +428,7 @@ KParams base_params(const remap_apply_args *a, const Call &c)
 bool hint_usable(const remap_apply_args *a, const Call &c)
 {
     if (c.K <= 32)
-        return false;  // the sub-group-per-row kernel owns small K
+        return false;  // the lane-per-(row, k) kernel owns small K
     switch (a->tune[0]) {
     case 10:
         return c.group_ok && c.can_vec2 && c.small_offsets;
@@ -450,8 +449,13 @@ bool hint_usable(const remap_apply_args *a, const Call &c)
 // presence decides.
 int automatic_family(const remap_apply_args *a, const Call &c)
 {
+    // few fields: lane per (row, k).  The sub-group-per-row kernel (family
+    // 3, coalesced (col, S) loads, CSR-order sums by shuffles) was built for
+    // this and measured slower on every case -- config 3's map: K = 1 17.7
+    // vs 9.7 us, K = 12 77 vs 27 us, K = 32 268 vs 57 us; config 1's
+    // bilinear map at K = 1: 10.1 vs 10.1 us -- so it stays opt-in
     if (c.K <= 32)
-        return 3;
+        return 2;
     if (c.patch_ok && c.K >= 64)
         return 5;
     return a->A.csr_pad >= 8 ? 6 : 1;
@@ -696,6 +700,68 @@ __global__ __launch_bounds__(kBlock) void stream_copy_kernel(
 }
 }  // namespace
 
+// ---------------------------------------------------------------------------
+// NaN scan: the device-side half of remap_numpy.py:201-204 (`isnan(values)
+// .any()` decides between the masked and the unmasked branch)
+// ---------------------------------------------------------------------------
+namespace {
+template <typename T>
+__global__ __launch_bounds__(kBlock) void scan_nan_kernel(
+    const T *__restrict__ x, size_t n, int32_t *__restrict__ flag)
+{
+    // 16 bytes per lane per step, blocks in dispatch order
+    constexpr int PER = 16 / sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(PER)));
+    const size_t nvec = n / PER;
+    bool found = false;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nvec;
+         i += (size_t)gridDim.x * kBlock) {
+        const vec_t v = __builtin_nontemporal_load(
+            reinterpret_cast<const vec_t *>(x) + i);
+#pragma unroll
+        for (int e = 0; e < PER; ++e)
+            found |= (v[e] != v[e]);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < n - nvec * PER) {
+        const T t = x[nvec * PER + threadIdx.x];
+        found |= (t != t);
+    }
+    if (__any(found) && (threadIdx.x & (kWave - 1)) == 0)
+        atomicOr(flag, 1);
+}
+}  // namespace
+
+int scan_nan(const void *x, int32_t dtype, int64_t n, int32_t *flag,
+             hipStream_t stream)
+{
+    if (n < 0 || !flag || (n > 0 && !x))
+        return fail(REMAP_ERR_ARG, "remap_scan_nan: bad argument");
+    if (dtype != REMAP_DTYPE_F64 && dtype != REMAP_DTYPE_F32)
+        return fail(REMAP_ERR_ARG, "remap_scan_nan: unknown dtype %d", dtype);
+    if (n == 0)
+        return REMAP_OK;
+    const size_t elem = dtype == REMAP_DTYPE_F64 ? 8 : 4;
+    if (!aligned(x, 16))
+        return fail(REMAP_ERR_ARG,
+                    "remap_scan_nan: needs a 16-byte aligned buffer");
+    const size_t nvec = (size_t)n * elem / 16;
+    size_t grid = (nvec + kBlock - 1) / kBlock;
+    if (grid < 1)
+        grid = 1;
+    if (grid > 256 * 64)
+        grid = 256 * 64;   // grid-stride beyond 64 blocks per CU
+    if (dtype == REMAP_DTYPE_F64)
+        hipLaunchKernelGGL(scan_nan_kernel<double>, dim3((uint32_t)grid),
+                           dim3(kBlock), 0, stream,
+                           static_cast<const double *>(x), (size_t)n, flag);
+    else
+        hipLaunchKernelGGL(scan_nan_kernel<float>, dim3((uint32_t)grid),
+                           dim3(kBlock), 0, stream,
+                           static_cast<const float *>(x), (size_t)n, flag);
+    REMAP_HIP_CHECK(hipGetLastError());
+    return REMAP_OK;
+}
+
 int stream_copy(void *dst, const void *src, size_t bytes, hipStream_t stream)
 {
     if (bytes == 0)
@@ -741,6 +807,13 @@ int remap_device_count(void)
 int remap_apply_f64(const remap_apply_args *args, void *stream)
 {
     return remap::apply(args, static_cast<hipStream_t>(stream));
+}
+
+int remap_scan_nan(const void *x, int32_t x_dtype, int64_t n, int32_t *flag,
+                   void *stream)
+{
+    return remap::scan_nan(x, x_dtype, n, flag,
+                           static_cast<hipStream_t>(stream));
 }
 
 int remap_stream_copy(void *dst, const void *src, size_t bytes, void *stream)

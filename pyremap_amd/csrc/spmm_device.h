@@ -23,6 +23,9 @@ struct KParams {
     int32_t xcd_map;
     uint32_t x_range;      // bytes addressable from a source row base
     uint32_t y_range;      // bytes addressable from a destination row base
+    const int32_t *__restrict__ gate;  // optional device-side switch: the
+    int32_t gate_value;                // launch is a no-op unless *gate ==
+                                       // gate_value (remap_apply_args.gate)
 #ifdef REMAP_DIAG
     int32_t diag;          // diagnostic build only (tune[6]): 1 = no Y
                            // stores, 2 = gather from the first 1024 rows
@@ -227,8 +230,17 @@ __device__ __forceinline__ void tile_offsets(
 
 // physical block -> logical block.  Blocks are dealt round-robin over the 8
 // XCDs, so bid % 8 labels the XCD; give each label a contiguous range.
+// A gated launch whose gate is closed does nothing: every wave reads the
+// gate word (one scalar load) and leaves.
+__device__ __forceinline__ bool gate_closed(const KParams &p)
+{
+    return p.gate != nullptr && *p.gate != p.gate_value;
+}
+
 __device__ __forceinline__ int64_t logical_block(const KParams &p)
 {
+    if (gate_closed(p))
+        return p.n_blocks;   // callers return on L >= n_blocks
     int64_t L = blockIdx.x;
     if (p.xcd_map) {
         const int64_t xcd = L & (kXcds - 1);

@@ -36,16 +36,9 @@ template <>
 struct I32Vec<8> {
     typedef int32_t type __attribute__((ext_vector_type(8), aligned(4)));
 };
-template <>
-struct I32Vec<16> {
-    typedef int32_t type __attribute__((ext_vector_type(16), aligned(4)));
-};
 template <int N>
 struct F64Vec;
-template <>
-struct F64Vec<16> {
-    typedef double type __attribute__((ext_vector_type(16), aligned(8)));
-};
+
 template <>
 struct F64Vec<4> {
     typedef double type __attribute__((ext_vector_type(4), aligned(8)));

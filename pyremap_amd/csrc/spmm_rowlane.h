@@ -8,6 +8,8 @@ template <typename XT, int MODE, bool FMA>
 __global__ __launch_bounds__(kBlock) void spmm_rowlane(const KParams p,
                                                        const uint32_t flags)
 {
+    if (gate_closed(p))
+        return;
     const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int64_t r = gid / p.K;
     const uint32_t kf = static_cast<uint32_t>(gid - r * p.K);

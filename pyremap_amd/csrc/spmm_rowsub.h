@@ -2,7 +2,9 @@
 // Part of remap_spmm.hip: included there inside namespace remap::(anonymous),
 // in the order given there; not a stand-alone header.
 // ---------------------------------------------------------------------------
-// rowsub: the few-fields path -- ONE 2-D field (K = 1: remap_numpy.py:240-248
+// rowsub: an alternative few-fields path (opt-in, tune[0] = 3: the simpler
+// lane-per-(row, k) kernel measured faster on every case tried, see
+// automatic_family) -- ONE 2-D field (K = 1: remap_numpy.py:240-248
 // appends a unit axis), monthly (Time, nCells) fields, a handful of levels.
 // There is no K to spread lanes over, so lanes go across a row's ENTRIES:
 // SUB (8 or 4) consecutive lanes own one destination row and fetch its
@@ -33,7 +35,7 @@ __global__ __launch_bounds__(kBlock) void spmm_rowsub(const KParams p,
     const int lane0 = lane & ~(SUB - 1);      // the sub-group's first lane
     const int64_t slot = p.row_begin + (int64_t)blockIdx.x * kRowsPerBlock +
                          threadIdx.x / SUB;
-    if (slot >= p.row_end)
+    if (slot >= p.row_end || gate_closed(p))
         return;   // whole sub-groups leave together
     const int64_t i = p.row_order ? (int64_t)p.row_order[slot] : slot;
     const int64_t s = p.rowptr[i];

@@ -33,7 +33,7 @@ FLAG_TREE = 8
 DTYPE_F64 = 0
 DTYPE_F32 = 1
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 #: readable pad entries kept behind col/val (remap_csr.csr_pad)
 CSR_PAD = 8
@@ -42,7 +42,7 @@ CSR_PAD = 8
 EXPORTS = (
     'remap_abi_version', 'remap_arch', 'remap_last_error',
     'remap_device_count', 'remap_apply_f64', 'remap_csr_from_coo_workspace',
-    'remap_csr_from_coo', 'remap_stream_copy',
+    'remap_csr_from_coo', 'remap_stream_copy', 'remap_scan_nan',
 )
 
 
@@ -97,6 +97,8 @@ class _ApplyArgs(ctypes.Structure):
         ('n_groups', ctypes.c_int64),
         ('group_rows', ctypes.c_int32),
         ('group_reserved', ctypes.c_int32),
+        ('gate', ctypes.c_void_p),
+        ('gate_value', ctypes.c_int32),
         ('flags', ctypes.c_uint32),
         ('tune', ctypes.c_int32 * 8),
     ]
@@ -150,6 +152,10 @@ def load_library():
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
         ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    lib.remap_scan_nan.restype = ctypes.c_int
+    lib.remap_scan_nan.argtypes = [ctypes.c_void_p, ctypes.c_int32,
+                                   ctypes.c_int64, ctypes.c_void_p,
+                                   ctypes.c_void_p]
     lib.remap_stream_copy.restype = ctypes.c_int
     lib.remap_stream_copy.argtypes = [ctypes.c_void_p, ctypes.c_void_p,
                                       ctypes.c_size_t, ctypes.c_void_p]
@@ -530,9 +536,9 @@ class RemapPlan:
         """
         torch = _torch()
         G = int(rows or self.GROUP)
-        if G not in (4, 8, 16):
-            raise ValueError('row groups hold 4, 8 or 16 rows')
-        gy = 4 if G == 16 else 2     # the group is a gy x gx tile
+        if G not in (4, 8):
+            raise ValueError('row groups hold 4 or 8 rows')
+        gy = 2                       # the group is a 2 x gx tile
         gx = G // gy
         self.groups = None
         if self.nnz == 0 or self.n_b == 0:
@@ -728,7 +734,7 @@ class RemapPlan:
 def apply_strided(plan, X, Y, *, n_batch, k_inner, x_row_stride,
                   x_batch_stride, y_row_stride, y_batch_stride, mode,
                   threshold=0.0, mask_out=None, flags=0, tune=None,
-                  row_begin=0, row_end=None):
+                  row_begin=0, row_end=None, gate=None, gate_value=0):
     """
     One asynchronous ``remap_apply_f64`` launch on torch's current stream.
     ``X``/``Y``/``mask_out`` are device tensors; strides are in elements.
@@ -802,6 +808,11 @@ def apply_strided(plan, X, Y, *, n_batch, k_inner, x_row_stride,
         args.group_frac = groups['frac'].data_ptr()
         args.n_groups = groups['n']
         args.group_rows = groups['rows']
+    if gate is not None:
+        if gate.dtype != torch.int32 or gate.device != plan.device:
+            raise TypeError('gate must be an int32 tensor on the plan device')
+        args.gate = gate.data_ptr()
+        args.gate_value = int(gate_value)
     args.flags = flags
     if not tune:
         # the plan's preference (auto_schedule); the library falls back to
@@ -827,8 +838,26 @@ def _prod(seq):
     return out
 
 
+def in_place_addressable(shape, remap_axes):
+    """
+    Can a field of this shape be addressed in place (strides instead of
+    permute copies)?  The source axes must be adjacent; the wave-per-row
+    kernels want a run of >= 8 contiguous fields behind them, the few-fields
+    kernel (K <= 32) takes any strides.
+    """
+    ndim = len(shape)
+    axes = [int(a) % ndim for a in remap_axes]
+    lead = min(axes)
+    if axes != list(range(lead, lead + len(axes))):
+        return False
+    n_batch = _prod(shape[:lead])
+    k_inner = _prod(shape[lead + len(axes):])
+    return k_inner >= 8 or n_batch == 1 or n_batch * k_inner <= 32
+
+
 def remap_tensor(plan, dst_grid_dims, field, remap_axes, mode, threshold=0.0,
-                 want_mask=False, flags=0, tune=None, out=None):
+                 want_mask=False, flags=0, tune=None, out=None, gate=None,
+                 gate_value=0, mask_out=None):
     """
     Device-level ``_remap_numpy_array``: ``field`` is a device tensor whose
     axes ``remap_axes`` hold the source grid; returns the float64 tensor with
@@ -859,12 +888,7 @@ def remap_tensor(plan, dst_grid_dims, field, remap_axes, mode, threshold=0.0,
     tail_shape = [int(field.shape[ax]) for ax in extra_axes if ax > lead]
     n_batch = _prod(lead_shape)
     k_inner = _prod(tail_shape)
-    # In-place addressing (strides instead of permute copies) whenever the
-    # source axes are adjacent: the wave-per-row kernels want a run of >= 8
-    # contiguous fields, the few-fields kernel (K <= 32: one 2-D field,
-    # monthly (Time, nCells) data) takes any strides
-    direct = contiguous_block and (
-        k_inner >= 8 or n_batch == 1 or n_batch * k_inner <= 32)
+    direct = in_place_addressable(field.shape, remap_axes)
     sharded = plan.n_b != plan.n_b_global
     # rows stay flat for a shard (its rows are no whole grid) and when the
     # caller names no destination grid
@@ -891,15 +915,20 @@ def remap_tensor(plan, dst_grid_dims, field, remap_axes, mode, threshold=0.0,
         X = field.contiguous()
         Y = out if out is not None else torch.empty(
             out_shape, dtype=torch.float64, device=field.device)
-        mask = torch.empty(out_shape, dtype=torch.uint8,
-                           device=field.device) if want_mask else None
+        mask = None
+        if want_mask:
+            mask = mask_out if mask_out is not None else torch.empty(
+                out_shape, dtype=torch.uint8, device=field.device)
         apply_strided(
             plan, X, Y, n_batch=n_batch, k_inner=k_inner,
             x_row_stride=k_inner, x_batch_stride=plan.n_a * k_inner,
             y_row_stride=k_inner, y_batch_stride=plan.n_b * k_inner,
             mode=mode, threshold=threshold, mask_out=mask, flags=flags,
-            tune=tune)
+            tune=tune, gate=gate, gate_value=gate_value)
         return (Y, mask) if want_mask else Y
+    if gate is not None or mask_out is not None:
+        raise ValueError('gated launches and caller-supplied masks need the '
+                         'source axes adjacent (in-place addressing)')
 
     # general axis order (or a very short contiguous run): one device
     # transpose to (n_a, K), the kernel, one transpose back
@@ -925,6 +954,49 @@ def remap_tensor(plan, dst_grid_dims, field, remap_axes, mode, threshold=0.0,
         out.copy_(Y)
         Y = out
     return (Y, back(mask)) if want_mask else Y
+
+
+def scan_nan(x, flag):
+    """
+    Asynchronously OR 1 into ``flag`` (int32 device tensor, zeroed by the
+    caller) if the float32/float64 device tensor ``x`` holds a NaN: the
+    device half of ``remap_numpy.py:201-204``.
+    """
+    torch = _torch()
+    lib = load_library()
+    if not x.is_contiguous():
+        raise ValueError('scan_nan needs a contiguous tensor')
+    dtype = {torch.float64: DTYPE_F64, torch.float32: DTYPE_F32}[x.dtype]
+    with torch.cuda.device(x.device):
+        _check(lib.remap_scan_nan(_ptr(x), dtype, x.numel(), _ptr(flag),
+                                  _stream_ptr(x.device)), 'remap_scan_nan')
+
+
+def remap_tensor_auto_mode(plan, dst_grid_dims, field, remap_axes, threshold,
+                           flags=0, out=None, flag=None):
+    """
+    ``_remap_data_array``'s branch (``remap_numpy.py:201-204``) without a
+    host round trip: the masked, renormalised result if ``field`` holds a
+    NaN, the ``frac_b``-normalised one if not.  One scan, two gated launches
+    (the one whose gate is closed does nothing), nothing synchronises.
+    """
+    torch = _torch()
+    if not in_place_addressable(field.shape, remap_axes):
+        # permute copies either side of the launch: decide with one readback
+        masked = bool(torch.isnan(field).any())
+        return remap_tensor(plan, dst_grid_dims, field, remap_axes,
+                            MODE_MASKED if masked else MODE_FRACB,
+                            threshold=threshold if masked else 0.0,
+                            flags=flags, out=out)
+    if flag is None:
+        flag = torch.zeros(1, dtype=torch.int32, device=field.device)
+    X = field.contiguous()
+    scan_nan(X, flag)
+    Y = remap_tensor(plan, dst_grid_dims, X, remap_axes, MODE_MASKED,
+                     threshold=threshold, flags=flags, out=out, gate=flag,
+                     gate_value=1)
+    return remap_tensor(plan, dst_grid_dims, X, remap_axes, MODE_FRACB,
+                        flags=flags, out=Y, gate=flag, gate_value=0)
 
 
 def stream_copy(dst, src):

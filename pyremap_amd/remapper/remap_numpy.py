@@ -22,7 +22,7 @@ import sys
 
 import numpy as np
 
-from pyremap_amd import engine, xr_lite
+from pyremap_amd import engine, host_path, xr_lite
 from pyremap_amd.io.mapfile import read_mapping
 
 try:  # real xarray is honoured when present; it is optional
@@ -90,8 +90,10 @@ def _remap_numpy(remapper, ds, renormalization_threshold):
         # variables holding only part of the source dims cannot be remapped
         partial = [name for name in ds.data_vars
                    if _check_drop(remapper, ds[name])]
-        result = ds.drop_vars(partial).map(_remap_data_array,
-                                           keep_attrs=True, args=args)
+        kept = ds.drop_vars(partial)
+        result = kept.map(
+            _LookAhead(remapper, kept, list(kept.data_vars),
+                       renormalization_threshold), keep_attrs=True)
     else:
         raise TypeError('ds not an xarray Dataset or DataArray.')
 
@@ -165,11 +167,20 @@ def _remap_data_array(da, remapper, renormalization_threshold):
     vanish, coordinates without a source dim are kept and the destination
     descriptor's coordinates are added.
     """
+    return _start_data_array(da, remapper, renormalization_threshold)()
+
+
+def _start_data_array(da, remapper, renormalization_threshold):
+    """
+    Enqueue the remap of one variable -- upload, NaN scan, launch, download,
+    none of which waits for the host -- and return the function that waits
+    for the data and assembles the result.
+    """
     src_dims = remapper.src_descriptor.dims
     remap_axes = [axis for axis, dim in enumerate(da.dims)
                   if dim in src_dims]
     if not remap_axes:
-        return da  # nothing to remap
+        return lambda: da  # nothing to remap
     if len(remap_axes) != len(src_dims):
         raise ValueError(
             'Data array with some (but not all) required source dims cannot '
@@ -189,39 +200,47 @@ def _remap_data_array(da, remapper, renormalization_threshold):
     # the NaN test of :201-204 and the product both run on the device; masked
     # entries come back as NaN, which is what xarray makes of the reference's
     # masked array
-    data = _remap_values(remapper, da.values, remap_axes,
-                         renormalization_threshold)
-    return _array_class(da).from_dict({
-        'coords': coords, 'attrs': da.attrs, 'dims': dims, 'data': data,
-        'name': da.name})
+    pending = host_path.remap_host_array(
+        remapper._matrix, remapper._ds_map.dst_grid_dims, da.values,
+        remap_axes,
+        mode='fracb' if renormalization_threshold is None else 'auto',
+        threshold=renormalization_threshold, flags=remapper.engine_flags)
+    make = _array_class(da).from_dict
+    attrs, name = da.attrs, da.name
+
+    def finish():
+        return make({'coords': coords, 'attrs': attrs, 'dims': dims,
+                     'data': pending.result(), 'name': name})
+    return finish
 
 
-def _upload(remapper, values):
-    torch = engine.require_gpu()
-    values = np.asarray(values)
-    if values.dtype.kind not in 'fiub':
-        raise TypeError(f'cannot remap an array of dtype {values.dtype}')
-    if values.dtype not in (np.float64, np.float32):
-        values = values.astype(np.float64)
-    if not values.flags['C_CONTIGUOUS'] or not values.flags['WRITEABLE']:
-        values = np.array(values, order='C')
-    return torch.from_numpy(values).to(remapper._matrix.device)
+class _LookAhead:
+    """
+    ``Dataset.map`` calls its function one variable at a time; this keeps the
+    next ``depth`` variables' transfers and launches enqueued while one is
+    awaited, so a variable's download overlaps its successors' uploads
+    (reference: the per-variable loop of ``remap_numpy.py:42-55``).
+    """
 
+    def __init__(self, remapper, ds, names, threshold, depth=2):
+        self.remapper, self.ds, self.names = remapper, ds, list(names)
+        self.threshold, self.depth = threshold, depth
+        self.started = {}
+        self.position = 0
 
-def _remap_values(remapper, values, remap_axes, renormalization_threshold):
-    """ndarray in, NaN-filled float64 ndarray out (used per variable)."""
-    torch = engine.require_gpu()
-    field = _upload(remapper, values)
-    masked = False
-    if renormalization_threshold is not None:
-        # reference: a MaskedArray is made iff the field holds a NaN (:203)
-        masked = bool(torch.isnan(field).any())
-    out = engine.remap_tensor(
-        remapper._matrix, remapper._ds_map.dst_grid_dims, field, remap_axes,
-        engine.MODE_MASKED if masked else engine.MODE_FRACB,
-        threshold=renormalization_threshold if masked else 0.0,
-        flags=remapper.engine_flags)
-    return out.cpu().numpy()
+    def _start_up_to(self, last):
+        while self.position <= min(last, len(self.names) - 1):
+            name = self.names[self.position]
+            self.started[name] = _start_data_array(
+                self.ds[name], self.remapper, self.threshold)
+            self.position += 1
+
+    def __call__(self, da, *unused):
+        name = da.name
+        if name not in self.names:
+            return _remap_data_array(da, self.remapper, self.threshold)
+        self._start_up_to(self.names.index(name) + self.depth)
+        return self.started.pop(name)()
 
 
 def _remap_numpy_array(remapper, in_field, remap_axes,
@@ -248,32 +267,32 @@ def _remap_numpy_array(remapper, in_field, remap_axes,
 
     if isinstance(in_field, torch.Tensor):
         field = in_field.to(plan.device)
-        masked = False
-        if renormalization_threshold is not None:
-            masked = bool(torch.isnan(field).any())
-        return engine.remap_tensor(
+        if field.dtype not in (torch.float64, torch.float32):
+            field = field.to(torch.float64)
+        if renormalization_threshold is None:
+            return engine.remap_tensor(plan, dst_grid_dims, field,
+                                       remap_axes, engine.MODE_FRACB,
+                                       flags=remapper.engine_flags)
+        # NaN scan and both candidate launches stay on the device
+        return engine.remap_tensor_auto_mode(
             plan, dst_grid_dims, field, remap_axes,
-            engine.MODE_MASKED if masked else engine.MODE_FRACB,
-            threshold=renormalization_threshold if masked else 0.0,
-            flags=remapper.engine_flags)
+            renormalization_threshold, flags=remapper.engine_flags)
 
     is_ma = isinstance(in_field, np.ma.MaskedArray)
     masked = is_ma and renormalization_threshold is not None
     data = np.ma.getdata(in_field) if is_ma else np.asarray(in_field)
+    host_mask = None
     if masked:
-        # the kernel derives the mask from NaN (what in_mask * in_field
-        # amounts to when the mask is isnan(field), :201-204 and :263)
+        # the kernel reads the mask off NaNs (what in_mask * in_field amounts
+        # to when the mask is isnan(field), :201-204 and :263): the mask goes
+        # up beside the data and is burnt in on the device
         host_mask = np.ma.getmaskarray(in_field)
-        if data.dtype.kind != 'f':
-            data = data.astype(np.float64)
-        if host_mask.any():
-            data = np.array(data, copy=True)
-            data[host_mask] = np.nan
-    field = _upload(remapper, data)
-    out, mask = engine.remap_tensor(
-        plan, dst_grid_dims, field, remap_axes,
-        engine.MODE_MASKED if masked else engine.MODE_FRACB,
-        threshold=renormalization_threshold if masked else 0.0,
-        want_mask=True, flags=remapper.engine_flags)
-    return np.ma.masked_array(out.cpu().numpy(),
-                              mask=mask.cpu().numpy().astype(bool))
+        if not host_mask.any():
+            host_mask = None
+    out, mask = host_path.remap_host_array(
+        plan, dst_grid_dims, data, remap_axes,
+        mode='masked' if masked else 'fracb',
+        threshold=renormalization_threshold if masked else None,
+        want_mask=True, flags=remapper.engine_flags,
+        host_mask=host_mask).result()
+    return np.ma.masked_array(out, mask=mask)

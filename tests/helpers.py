@@ -8,7 +8,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(REPO, 'tests', 'golden')
 
 
-def golden_files(pattern='g[012]_*.npz'):
+def golden_files(pattern='g[0125]_*.npz'):
     return sorted(glob.glob(os.path.join(GOLDEN, pattern)))
 
 
@@ -43,7 +43,9 @@ def golden_cases(path):
         field = g[f'c{i}_field']
         thr = float(g[f'c{i}_thr'])
         thr = None if np.isnan(thr) else thr
-        if bool(g[f'c{i}_was_masked_array']):
+        if f'c{i}_in_mask' in g:
+            arg = np.ma.masked_array(field, g[f'c{i}_in_mask'])
+        elif bool(g[f'c{i}_was_masked_array']):
             arg = np.ma.masked_array(field, np.isnan(field))
         else:
             arg = field

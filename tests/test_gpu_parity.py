@@ -743,7 +743,7 @@ def test_auto_schedule_picks_by_reuse(dev):
 # row-group family: 8 or 4 rows per wave over the union of their columns
 # ---------------------------------------------------------------------------
 
-@pytest.mark.parametrize('rows', [16, 8, 4])
+@pytest.mark.parametrize('rows', [8, 4])
 @pytest.mark.parametrize('grid', ['2d', '1d'])
 @pytest.mark.parametrize('K', [64, 128, 130, 320, 512])
 def test_rowgroup_kernel_bitwise(dev, grid, K, rows):
@@ -1281,7 +1281,7 @@ def test_tree_flag_is_close_not_identical(problem, dev):
     ys = {}
     for flags in (0, engine.FLAG_TREE):
         y = engine.remap_tensor(p['plan'], (p['n_b'],), xd, [0],
-                                engine.MODE_FRACB, flags=flags)
+                                engine.MODE_FRACB, flags=flags, tune=[3])
         ys[flags] = y.cpu().numpy()
     ok = ~ref_mask
     assert_bitwise(np.where(ok, ys[0], 0.0), np.where(ok, ref, 0.0))
@@ -1290,3 +1290,115 @@ def test_tree_flag_is_close_not_identical(problem, dev):
     assert np.array_equal(np.isnan(ys[engine.FLAG_TREE]), ref_mask)
     # long rows make the association visible
     assert not np.array_equal(ys[engine.FLAG_TREE][ok], ref[ok])
+
+
+# ---------------------------------------------------------------------------
+# device-side branch selection (remap_numpy.py:201-204) and the host path
+# ---------------------------------------------------------------------------
+
+def test_scan_nan_and_gated_launches(problem, dev):
+    """remap_scan_nan + remap_apply_args.gate: `isnan(values).any()` decides
+    the branch on the device; the launch whose gate is closed writes
+    nothing."""
+    from oracle import oracle
+    from pyremap_amd import engine
+    p = problem
+    for dtype in (torch.float64, torch.float32):
+        for n in (1, 3, 64, 1027, 70001):
+            x = torch.randn(n, dtype=dtype, device=dev)
+            flag = torch.zeros(1, dtype=torch.int32, device=dev)
+            engine.scan_nan(x, flag)
+            assert int(flag) == 0
+            x[n - 1] = float('nan')       # the tail element
+            engine.scan_nan(x, flag)
+            assert int(flag) == 1
+            x[n - 1] = 0.0
+            x[n // 2] = float('nan')
+            flag.zero_()
+            engine.scan_nan(x, flag)
+            assert int(flag) == 1
+    rng = np.random.default_rng(77)
+    for K in (3, 200):
+        clean = rng.standard_normal((p['n_a'], K))
+        holed = clean.copy()
+        holed[rng.random(p['n_a']) < 0.3, :] = np.nan
+        for x, masked in ((clean, False), (holed, True)):
+            xd = torch.from_numpy(x).to(dev)
+            y = engine.remap_tensor_auto_mode(p['plan'], (p['n_b'],), xd,
+                                              [0], 0.2)
+            ref, ref_mask = oracle.remap_flat(p['csr'], p['frac_b'], x,
+                                              masked, 0.2)
+            ref[ref_mask] = np.nan
+            assert_bitwise(y.cpu().numpy(), ref, f'auto mode K={K} {masked}')
+        # a closed gate leaves the output untouched
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        y = torch.full((p['n_b'], K), 5.0, dtype=torch.float64, device=dev)
+        engine.remap_tensor(p['plan'], (p['n_b'],), xd, [0],
+                            engine.MODE_FRACB, out=y, gate=flag,
+                            gate_value=1)
+        assert bool((y == 5.0).all())
+
+
+def test_host_arrays_pinned_pipelined_and_poisoned(dev):
+    """
+    numpy in -> numpy out through pyremap_amd.host_path: the single-shot and
+    the three-stream pipelined form (leading batch dims), NaN-decided branch,
+    masks, and a MaskedArray whose data holds an UNMASKED NaN (the reference
+    lets it through, remap_numpy.py:263) -- all against the oracle.
+    """
+    from oracle import oracle
+    from pyremap_amd import engine, host_path, synthetic
+    m = synthetic.conservative_map(3000, (40, 50), 1, 6, seed=3)
+    mm = m.numpy()
+    plan = engine.RemapPlan.from_triplets(mm['row'], mm['col'], mm['S'],
+                                          mm['frac_b'], m.n_a, m.n_b,
+                                          device=dev)
+    plan.auto_schedule(m.dst_dims)
+    csr = oracle.coo_to_csr(mm['row'] - 1, mm['col'] - 1, mm['S'], m.n_b,
+                            m.n_a)
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((6, m.n_a, 40))
+    holed = x.copy()
+    holed[:, rng.random(m.n_a) < 0.2, 10:] = np.nan
+    old = host_path.CHUNK_BYTES
+    host_path.CHUNK_BYTES = 2 * m.n_a * 40 * 8      # three chunks of two
+    try:
+        for field, mode, thr in ((x, 'fracb', None), (holed, 'masked', 0.3),
+                                 (holed, 'auto', 0.3), (x, 'auto', 0.3),
+                                 (x.astype(np.float32), 'fracb', None)):
+            masked = mode == 'masked' or (mode == 'auto' and
+                                          np.isnan(field).any())
+            arg = np.ma.masked_array(field, np.isnan(field)) if masked \
+                else field
+            ref = oracle.remap_numpy_array(csr, mm['frac_b'], m.dst_dims,
+                                           arg, [1], thr if masked else None)
+            want_mask = mode != 'auto'
+            got = host_path.remap_host_array(
+                plan, m.dst_dims, field, [1], mode=mode, threshold=thr,
+                want_mask=want_mask).result()
+            data = got[0] if want_mask else got
+            assert_bitwise(data, np.ma.filled(ref, np.nan),
+                           f'host path {mode} {field.dtype}')
+            if want_mask:
+                assert np.array_equal(got[1], np.ma.getmaskarray(ref))
+    finally:
+        host_path.CHUNK_BYTES = old
+    # MaskedArray with an unmasked NaN in its data
+    field = rng.standard_normal((m.n_a, 12))
+    mask = rng.random((m.n_a, 12)) < 0.2
+    field[5, 3] = np.nan
+    mask[5, 3] = False                      # poisoned: NaN but NOT masked
+    field[9, 4] = np.nan
+    mask[9, 4] = True                       # ordinary: NaN under the mask
+    arg = np.ma.masked_array(field, mask)
+    ref = oracle.remap_numpy_array(csr, mm['frac_b'], m.dst_dims, arg, [0],
+                                   0.05)
+    data, got_mask = host_path.remap_host_array(
+        plan, m.dst_dims, field, [0], mode='masked', threshold=0.05,
+        want_mask=True, host_mask=mask).result()
+    ref_data = np.ma.getdata(ref)
+    ref_mask = np.ma.getmaskarray(ref)
+    assert np.isnan(ref_data[~ref_mask]).any()     # the NaN got through
+    assert np.array_equal(got_mask, ref_mask)
+    assert_bitwise(np.where(ref_mask, 0.0, data),
+                   np.where(ref_mask, 0.0, ref_data), 'poisoned entry')

@@ -1,11 +1,16 @@
 #!/usr/bin/env python3
 """
 Turn a tools/profile.sh output directory (gpurun_out/prof_<tag>) into the
-committed evidence under profiles/: the rocprofv3 kernel-stats rows, the
-per-launch PMC averages of the remap kernel, and profiles/traffic_<workload>
-.json which bench.py reports as roofline.traffic.
+committed evidence under profiles/:
 
-    python tools/summarize_profile.py r01 config3 512 fracb
+  <tag>_summary.md          kernel-trace statistics of the driver's command,
+                            the metric kernel's launches INSIDE the timed
+                            region picked out of the per-dispatch rows, and
+                            the per-launch PMC averages of every workload
+  <tag>_kernel_stats.csv    rocprofv3's own --stats table (top rows)
+  traffic_<workload>.json   what bench.py reports as roofline.traffic
+
+    python tools/summarize_profile.py r02 config3 headline config4 config5
 """
 import collections
 import csv
@@ -15,115 +20,169 @@ import os
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+
+def short(name):
+    name = name.replace('(anonymous namespace)::', '').replace('void ', '')
+    return name.split('(')[0][:70]
 
 
 def main():
-    tag, workload, K, mode = sys.argv[1], sys.argv[2], int(sys.argv[3]), \
-        sys.argv[4]
+    tag, workloads = sys.argv[1], sys.argv[2:] or ['config3']
     src = os.path.join(REPO, 'gpurun_out', f'prof_{tag}')
     out = os.path.join(REPO, 'profiles')
     os.makedirs(out, exist_ok=True)
-    lines = [f'# rocprofv3 summary {tag} ({workload}, K = {K}, mode {mode})',
-             '',
-             'Collected by tools/profile.sh: the kernel-trace pass runs '
-             '`bench.py --no-cpu --no-extra` (default steps / warm-up, so its '
-             'average is comparable with `roofline.kernel_ms_mean` of the '
-             'bench line taken on the same box); each PMC group is its own '
-             '`rocprofv3 --pmc ...` pass over `bench.py --steps 20 --warmup '
-             '3 --no-cpu --no-extra`.', '']
+    L = [f'# rocprofv3 summary {tag}', '',
+         'Collected by tools/profile.sh.  Pass 1: `rocprofv3 --kernel-trace '
+         '--stats -- python3 bench.py --gpus 1 --steps 20 --warmup 5` (the '
+         "driver's command).  Pass 2..n: one `rocprofv3 --pmc <group>` pass "
+         'per counter group and workload over `bench.py --workload W '
+         '--no-extra --no-cpu`.', '']
 
-    # gpurun MERGES a run's files into gpurun_out/: files of earlier runs
-    # under the same tag may still be there.  tools/profile.sh ends with a
-    # listing of what THIS run wrote -- keep to it when it is available.
-    listing = os.path.join(REPO, 'gpurun_out', f'profile_{tag}.log')
-    current = None
-    if os.path.exists(listing):
-        current = {os.path.basename(line.strip())
-                   for line in open(listing) if line.strip().endswith('.csv')}
-
-    def only_current(paths):
-        if not current:
-            return paths
-        return [q for q in paths if os.path.basename(q) in current]
-
-    stats = only_current(glob.glob(
-        os.path.join(src, 'trace', '*', '*_kernel_stats.csv')))
-    kernel_avg_ns = None
-    kernel_name = None
+    # ---- pass 1: the driver's command ---------------------------------
+    live = None
+    try:
+        live = json.loads(open(os.path.join(
+            src, 'trace_bench.json')).read().strip().splitlines()[-1])
+    except (OSError, ValueError, IndexError):
+        pass
+    stats = glob.glob(os.path.join(src, 'trace', '*', '*_kernel_stats.csv'))
     if stats:
         rows = list(csv.DictReader(open(stats[0])))
-        keep = [r for r in rows if 'remap::' in r['Name']][:6]
         with open(os.path.join(out, f'{tag}_kernel_stats.csv'), 'w') as f:
             w = csv.DictWriter(f, fieldnames=rows[0].keys())
             w.writeheader()
-            for r in rows[:12]:
+            for r in rows[:14]:
                 w.writerow(r)
-        lines.append('## rocprofv3 --kernel-trace --stats (remap kernels)')
-        lines.append('')
-        lines.append('| kernel | calls | avg ns | min ns | max ns |')
-        lines.append('|---|---|---|---|---|')
-        for r in keep:
-            name = r['Name'].replace('(anonymous namespace)::', '')
-            name = name.replace('void ', '')[:60]
-            lines.append(f"| `{name}` | {r['Calls']} | "
-                         f"{float(r['AverageNs']):.0f} | {r['MinNs']} | "
-                         f"{r['MaxNs']} |")
-            if 'spmm' in r['Name'] and kernel_avg_ns is None:
-                kernel_avg_ns = float(r['AverageNs'])
-                kernel_name = name.split('<')[0].replace('remap::', '')
-        lines.append('')
+        L += ['## rocprofv3 --kernel-trace --stats (remap kernels, whole run)',
+              '', '| kernel | calls | avg ns | min ns | max ns |',
+              '|---|---|---|---|---|']
+        for r in [r for r in rows if 'remap::' in r['Name']][:8]:
+            L.append(f"| `{short(r['Name'])}` | {r['Calls']} | "
+                     f"{float(r['AverageNs']):.0f} | {r['MinNs']} | "
+                     f"{r['MaxNs']} |")
+        L.append('')
+    trace = glob.glob(os.path.join(src, 'trace', '*', '*_kernel_trace.csv'))
+    timed_avg = None
+    if trace and live:
+        steps, warmup = live['steps'], live['warmup']
+        rows = [r for r in csv.DictReader(open(trace[0]))
+                if 'spmm_' in r['Kernel_Name']]
+        rows.sort(key=lambda r: int(r['Start_Timestamp']))
+        # bench.py's last spmm launches are the metric workload's: W warm-up,
+        # K timed, min(K, 50) individually timed, 100 steady ones.  (The
+        # host-buffer extra that follows launches a few more: drop those by
+        # grid size -- it uses other kernels' shapes -- or by count.)
+        main_grid = None
+        by_grid = collections.Counter(r['Grid_Size_X'] for r in rows)
+        tail = 100 + min(steps, 50)
+        # the metric kernel is the most frequent grid among the last rows
+        main_grid = collections.Counter(
+            r['Grid_Size_X'] for r in rows[-(tail + steps + 40):]
+        ).most_common(1)[0][0]
+        mine = [r for r in rows if r['Grid_Size_X'] == main_grid and
+                short(r['Kernel_Name']) ==
+                short(rows[-1]['Kernel_Name'])] or \
+            [r for r in rows if r['Grid_Size_X'] == main_grid]
+        # walk back: steady 100, second pass, then the K timed launches
+        dur = [int(r['End_Timestamp']) - int(r['Start_Timestamp'])
+               for r in mine]
+        # launches after the metric workload (host-buffer extra) may share
+        # the grid: the timed region is located from the END of the block of
+        # 100 + min(K, 50) + K + W consecutive launches of the main plan
+        block = tail + steps + warmup
+        cand = dur[-block:] if len(dur) >= block else dur
+        timed = cand[warmup:warmup + steps]
+        timed_avg = sum(timed) / len(timed)
+        L += ['## The metric kernel inside the timed region (pass 1, '
+              'per-dispatch rows)', '',
+              f'Kernel `{short(mine[-1]["Kernel_Name"])}`, grid '
+              f'{main_grid} x {mine[-1]["Workgroup_Size_X"]}, '
+              f'{mine[-1]["VGPR_Count"]} VGPRs / {mine[-1]["SGPR_Count"]} '
+              f'SGPRs: the {steps} launches of the timed region average '
+              f'**{timed_avg:.0f} ns** (min {min(timed)}, max {max(timed)}); '
+              f'the bench line of the same run reports kernel_ms_mean = '
+              f'{live["roofline"]["kernel_ms_mean"] * 1e6:.0f} ns (one HIP '
+              f'event pair around the region, i.e. including the gaps '
+              f'between launches), frac {live["roofline"]["frac"]:.4f}.', '']
+        with open(os.path.join(out, f'{tag}_bench_under_rocprof.json'),
+                  'w') as f:
+            json.dump(live, f, indent=1)
 
-    pmc = collections.OrderedDict()
-    for path in only_current(sorted(glob.glob(os.path.join(
-            src, 'pmc_*', '*', '*_counter_collection.csv')))):
-        per = collections.defaultdict(list)
-        for r in csv.DictReader(open(path)):
-            if 'spmm_' in r['Kernel_Name']:
-                per[r['Counter_Name']].append(float(r['Counter_Value']))
-        for name, vals in per.items():
-            vals = vals[3:] if len(vals) > 6 else vals      # skip warm-up
-            pmc[name] = (sum(vals) / len(vals), min(vals), max(vals),
-                         len(vals))
-    lines.append('## rocprofv3 --pmc (one pass per group), per launch of '
-                 'the remap kernel')
-    lines.append('')
-    lines.append('| counter | mean | min | max | launches |')
-    lines.append('|---|---|---|---|---|')
-    for name, (mean, lo, hi, n) in pmc.items():
-        lines.append(f'| {name} | {mean:.6g} | {lo:.6g} | {hi:.6g} | {n} |')
-    lines.append('')
-
-    if 'FETCH_SIZE' in pmc and 'WRITE_SIZE' in pmc:
-        # FETCH_SIZE / WRITE_SIZE are in KiB.  MI355X_MICROARCH.md (HBM):
-        # on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a wide
-        # (16 B/lane) coalesced streaming read -> double it; WRITE_SIZE is
-        # exact for 16 B/lane streaming stores.
-        fetch = pmc['FETCH_SIZE'][0] * 1024 * 2
-        write = pmc['WRITE_SIZE'][0] * 1024
-        traffic = dict(
-            workload=workload, K=K, mode=mode,
-            fetch_bytes_per_launch=fetch, write_bytes_per_launch=write,
-            hbm_bytes_per_launch=fetch + write,
-            fetch_size_raw_kib=pmc['FETCH_SIZE'][0],
-            write_size_raw_kib=pmc['WRITE_SIZE'][0],
-            kernel_avg_ns_rocprof=kernel_avg_ns, kernel=kernel_name,
-            source=f'profiles/{tag}_summary.md: rocprofv3 --pmc FETCH_SIZE '
-                   f'and --pmc WRITE_SIZE (separate passes); FETCH_SIZE x '
-                   f'1024 x 2 (gfx950 half-count correction for 16 B/lane '
-                   f'reads, MI355X_MICROARCH.md) + WRITE_SIZE x 1024')
-        with open(os.path.join(out, f'traffic_{workload}.json'), 'w') as f:
-            json.dump(traffic, f, indent=1)
-        lines.append(f'Corrected fabric traffic per launch: reads '
+    # ---- PMC passes -----------------------------------------------------
+    for wl in workloads:
+        pmc = collections.OrderedDict()
+        cfg = None
+        for path in sorted(glob.glob(os.path.join(
+                src, f'pmc_{wl}_*', '*', '*_counter_collection.csv'))):
+            per = collections.defaultdict(list)
+            names = collections.Counter()
+            for r in csv.DictReader(open(path)):
+                if 'spmm_' in r['Kernel_Name']:
+                    per[r['Counter_Name']].append(float(r['Counter_Value']))
+                    names[short(r['Kernel_Name'])] += 1
+            for name, vals in per.items():
+                vals = vals[3:] if len(vals) > 6 else vals   # skip warm-up
+                pmc[name] = (sum(vals) / len(vals), min(vals), max(vals),
+                             len(vals), names.most_common(1)[0][0])
+        for path in glob.glob(os.path.join(src, f'pmc_{wl}_*.json')):
+            try:
+                cfg = json.loads(open(path).read().strip().splitlines()[-1])
+                break
+            except (OSError, ValueError, IndexError):
+                continue
+        if not pmc:
+            continue
+        L += [f'## rocprofv3 --pmc, {wl} (per launch of the remap kernel)',
+              '', '| counter | mean | min | max | launches |',
+              '|---|---|---|---|---|']
+        for name, (mean, lo, hi, n, _) in pmc.items():
+            L.append(f'| {name} | {mean:.6g} | {lo:.6g} | {hi:.6g} | {n} |')
+        L.append('')
+        if 'FETCH_SIZE' in pmc and 'WRITE_SIZE' in pmc:
+            # FETCH_SIZE / WRITE_SIZE are in KiB.  MI355X_MICROARCH.md (HBM):
+            # on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a wide
+            # (16 B/lane) coalesced streaming read -> double it; WRITE_SIZE
+            # is exact for 16 B/lane streaming stores.
+            fetch = pmc['FETCH_SIZE'][0] * 1024 * 2
+            write = pmc['WRITE_SIZE'][0] * 1024
+            K = cfg['config']['fields_K'] if cfg else None
+            mode = cfg['config']['mode'] if cfg else None
+            alg = cfg['roofline']['bytes_alg_per_launch'] if cfg else None
+            traffic = dict(
+                workload=wl, K=K, mode=mode,
+                fetch_bytes_per_launch=fetch, write_bytes_per_launch=write,
+                hbm_bytes_per_launch=fetch + write,
+                bytes_alg_per_launch=alg,
+                traffic_over_algorithmic=(fetch + write) / alg if alg else
+                None,
+                fetch_size_raw_kib=pmc['FETCH_SIZE'][0],
+                write_size_raw_kib=pmc['WRITE_SIZE'][0],
+                kernel=pmc['FETCH_SIZE'][4],
+                kernel_ms_mean_under_pmc=cfg['roofline']['kernel_ms_mean']
+                if cfg else None,
+                source=f'profiles/{tag}_summary.md: rocprofv3 --pmc '
+                       f'FETCH_SIZE and --pmc WRITE_SIZE (separate passes); '
+                       f'FETCH_SIZE x 1024 x 2 (gfx950 half-count correction '
+                       f'for 16 B/lane reads, MI355X_MICROARCH.md) + '
+                       f'WRITE_SIZE x 1024')
+            with open(os.path.join(out, f'traffic_{wl}.json'), 'w') as f:
+                json.dump(traffic, f, indent=1)
+            L.append(f'Corrected fabric traffic per launch: reads '
                      f'{fetch / 1e9:.3f} GB (FETCH_SIZE x 2), writes '
                      f'{write / 1e9:.3f} GB, total '
-                     f'{(fetch + write) / 1e9:.3f} GB.')
-        if 'TCC_HIT_sum' in pmc:
-            hit, miss = pmc['TCC_HIT_sum'][0], pmc['TCC_MISS_sum'][0]
-            lines.append(f'L2 hit rate (all requests): '
+                     f'{(fetch + write) / 1e9:.3f} GB' +
+                     (f' = {(fetch + write) / alg:.3f} x the algorithmic '
+                      f'{alg / 1e9:.3f} GB' if alg else '') + '.')
+            if 'TCC_HIT_sum' in pmc:
+                hit, miss = pmc['TCC_HIT_sum'][0], pmc['TCC_MISS_sum'][0]
+                L.append(f'L2 hit rate (all requests): '
                          f'{hit / (hit + miss):.3f}.')
+            L.append('')
     with open(os.path.join(out, f'{tag}_summary.md'), 'w') as f:
-        f.write('\n'.join(lines) + '\n')
-    print('\n'.join(lines))
+        f.write('\n'.join(L) + '\n')
+    print('\n'.join(L))
 
 
 if __name__ == '__main__':
