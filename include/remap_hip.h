@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define REMAP_ABI_VERSION 13
+#define REMAP_ABI_VERSION 14
 
 enum {
     REMAP_OK = 0,
@@ -259,6 +259,40 @@ int remap_csr_from_coo(int64_t n_rows, int64_t n_cols, int64_t nnz,
                        const double *S, int32_t index_base,
                        int64_t *rowptr_out, int32_t *col_out,
                        double *val_out, int64_t *nnz_out, int64_t *bad_out,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Build the row-group schedule of kernel family 10 (remap_apply_args.group_*)
+ * for the rows of A on the device -- what a binder needs to reach the
+ * kernels that carry the headline numbers without any host-side logic of its
+ * own.  Asynchronous on `stream`; nothing is allocated.
+ *
+ *   A            the CSR whose rows are scheduled (a row shard: its rows,
+ *                rowptr rebased to 0); canonical (remap_csr_from_coo's form)
+ *   frac_b       (device) A.n_rows
+ *   group_rows   G: 8, or 4
+ *   grid_dims    (HOST) NULL: groups are G consecutive rows; else {my, mx},
+ *                the C-order dims of the WHOLE destination grid: groups are
+ *                2 x G/2 tiles of it, walked row-major inside super_tile x
+ *                super_tile blocks (super_tile <= 0: over the whole grid)
+ *   row_offset   index of A's first row in the whole grid (0 unless a shard)
+ *   row_order_out (device, A.n_rows, may be NULL when grid_dims is NULL) the
+ *                processing order the schedule assumes: pass it as
+ *                remap_apply_args.row_order together with the schedule
+ *   group_meta   (device) 2 * (n_groups + 1)     n_groups = ceil(n_rows / G)
+ *   group_col, group_mask  (device) A.nnz + 8 each (union entries <= nnz)
+ *   group_w      (device) A.nnz + 64
+ *   group_rid, group_frac  (device) n_groups * G
+ *   n_union_out  (device) one int64: union entries actually used
+ */
+int remap_groups_workspace(int64_t n_rows, int64_t nnz, size_t *bytes_out);
+int remap_groups_build(const remap_csr *A, const double *frac_b,
+                       int32_t group_rows, const int64_t *grid_dims,
+                       int64_t row_offset, int32_t super_tile,
+                       int32_t *row_order_out, int64_t *group_meta,
+                       int32_t *group_col, int32_t *group_mask,
+                       double *group_w, int32_t *group_rid,
+                       double *group_frac, int64_t *n_union_out,
                        void *workspace, size_t workspace_bytes, void *stream);
 
 /*

@@ -1,0 +1,370 @@
+// remap_groups.hip -- builds the row-group schedule of kernel family 10 on
+// the device (one-off per Remapper / per row shard).
+//
+// The schedule (include/remap_hip.h, remap_apply_args.group_*) lets one wave
+// compute G neighbouring destination rows over the sorted union of their
+// columns.  Everything it needs is derived here from the CSR alone:
+//
+//   order_keys     a 2-D destination grid is walked in 2 x G/2 tiles
+//                  (row-major, optionally inside super_tile^2 blocks): key
+//                  of every row; 1-D destinations keep their natural order
+//   radix sort     rows by key -> row of every work slot (group_rid,
+//                  row_order); scatter -> slot of every row
+//   entry_keys     key = ((group * n_a + col) * G + member) per CSR entry
+//   radix sort     (key, S): the sorted weights ARE group_w -- the present
+//                  (union entry, member) pairs in (entry, member) order
+//   flag + scan    a new (group, col) starts a union entry -> its index
+//   fill_union     group_col, group_mask (atomicOr of the member bits)
+//   group_bounds   per group: lower_bound over the sorted keys -> first
+//                  union entry / first weight (group_meta)
+//   slot_info      group_rid padded to whole groups, group_frac
+//
+// rocPRIM supplies the two textbook primitives (radix sort, scan); nothing
+// synchronises and nothing is allocated: the caller provides a workspace.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <string.h>   // rocPRIM's texture iterator calls the host memset
+
+#include <rocprim/rocprim.hpp>
+
+#include "remap_common.h"
+
+namespace remap {
+namespace {
+
+constexpr size_t kAlignG = 256;
+
+size_t align_g(size_t n) { return (n + kAlignG - 1) / kAlignG * kAlignG; }
+
+struct GroupLayout {
+    size_t row_keys_in, row_keys_out, rows_in, slot_of_row, keys_in,
+        keys_out, head, uidx, temp, total;
+    size_t temp_bytes;
+};
+
+int group_layout(int64_t n_rows, int64_t nnz, GroupLayout *lay)
+{
+    const size_t nr = static_cast<size_t>(n_rows > 0 ? n_rows : 1);
+    const size_t ne = static_cast<size_t>(nnz > 0 ? nnz : 1);
+    size_t a = 0, b = 0, c = 0;
+    REMAP_HIP_CHECK((rocprim::radix_sort_pairs(
+        nullptr, a, static_cast<const uint64_t *>(nullptr),
+        static_cast<uint64_t *>(nullptr), static_cast<const int32_t *>(nullptr),
+        static_cast<int32_t *>(nullptr), nr, 0u, 64u)));
+    REMAP_HIP_CHECK((rocprim::radix_sort_pairs(
+        nullptr, b, static_cast<const uint64_t *>(nullptr),
+        static_cast<uint64_t *>(nullptr), static_cast<const double *>(nullptr),
+        static_cast<double *>(nullptr), ne, 0u, 64u)));
+    REMAP_HIP_CHECK((rocprim::exclusive_scan(
+        nullptr, c, static_cast<const uint32_t *>(nullptr),
+        static_cast<uint32_t *>(nullptr), 0u, ne, rocprim::plus<uint32_t>())));
+    lay->temp_bytes = a > b ? a : b;
+    if (c > lay->temp_bytes)
+        lay->temp_bytes = c;
+    size_t off = 0;
+    lay->row_keys_in = off;  off += align_g(nr * 8);
+    lay->row_keys_out = off; off += align_g(nr * 8);
+    lay->rows_in = off;      off += align_g(nr * 4);
+    lay->slot_of_row = off;  off += align_g(nr * 4);
+    lay->keys_in = off;      off += align_g(ne * 8);
+    lay->keys_out = off;     off += align_g(ne * 8);
+    lay->head = off;         off += align_g(ne * 4);
+    lay->uidx = off;         off += align_g(ne * 4);
+    lay->temp = off;         off += align_g(lay->temp_bytes);
+    lay->total = off;
+    return REMAP_OK;
+}
+
+// key of a row in the tile walk of the destination grid (my x mx cells,
+// row-major numbering): 2 x gx tiles, row-major inside st x st supertiles,
+// supertiles row-major over the grid
+__global__ __launch_bounds__(kBlock) void order_keys(
+    int64_t n_rows, int64_t row_offset, int64_t mx, int64_t st, int32_t G,
+    uint64_t *__restrict__ keys, int32_t *__restrict__ rows)
+{
+    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= n_rows)
+        return;
+    const int64_t gx = G / 2;
+    const int64_t i = row_offset + r;
+    const int64_t jy = i / mx;
+    const int64_t jx = i - jy * mx;
+    const int64_t nsx = (mx + st - 1) / st;
+    const int64_t key =
+        ((jy / st) * nsx + jx / st) * (st * st) +
+        (((jy % st) / 2) * (st / gx) + (jx % st) / gx) * G + (jy % 2) * gx +
+        jx % gx;
+    keys[r] = static_cast<uint64_t>(key);
+    rows[r] = static_cast<int32_t>(r);
+}
+
+__global__ __launch_bounds__(kBlock) void identity_order(
+    int64_t n_rows, int32_t *__restrict__ rid, int32_t *__restrict__ slot_of)
+{
+    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= n_rows)
+        return;
+    rid[r] = static_cast<int32_t>(r);
+    slot_of[r] = static_cast<int32_t>(r);
+}
+
+__global__ __launch_bounds__(kBlock) void invert_order(
+    int64_t n_rows, const int32_t *__restrict__ rid,
+    int32_t *__restrict__ slot_of, int32_t *__restrict__ row_order_out)
+{
+    const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (s >= n_rows)
+        return;
+    slot_of[rid[s]] = static_cast<int32_t>(s);
+    if (row_order_out)
+        row_order_out[s] = rid[s];
+}
+
+// one thread per row: keys of its entries
+__global__ __launch_bounds__(kBlock) void entry_keys(
+    int64_t n_rows, int64_t n_a, int32_t G,
+    const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const int32_t *__restrict__ slot_of, uint64_t *__restrict__ keys)
+{
+    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= n_rows)
+        return;
+    const uint64_t slot = static_cast<uint64_t>(slot_of[r]);
+    const uint64_t g = slot / G, member = slot % G;
+    for (int64_t e = rowptr[r]; e < rowptr[r + 1]; ++e)
+        keys[e] = (g * static_cast<uint64_t>(n_a) +
+                   static_cast<uint64_t>(col[e])) * G + member;
+}
+
+__global__ __launch_bounds__(kBlock) void flag_union_heads(
+    int64_t nnz, int32_t G, const uint64_t *__restrict__ keys,
+    uint32_t *__restrict__ head)
+{
+    const int64_t n = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (n >= nnz)
+        return;
+    head[n] = (n == 0 || keys[n] / G != keys[n - 1] / G) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(kBlock) void fill_union(
+    int64_t nnz, int64_t n_a, int32_t G, const uint64_t *__restrict__ keys,
+    const uint32_t *__restrict__ head, const uint32_t *__restrict__ uidx,
+    int32_t *__restrict__ gcol, int32_t *__restrict__ gmask,
+    int64_t *__restrict__ n_union_out)
+{
+    const int64_t n = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (n >= nnz)
+        return;
+    const uint64_t key = keys[n];
+    // head[n] = 1: entry n opens union entry uidx[n]; else it belongs to the
+    // one opened before it
+    const uint32_t u = head[n] ? uidx[n] : uidx[n] - 1u;
+    if (head[n])
+        gcol[u] = static_cast<int32_t>((key / G) % static_cast<uint64_t>(n_a));
+    atomicOr(gmask + u, 1 << static_cast<int>(key % G));
+    if (n == nnz - 1)
+        *n_union_out = static_cast<int64_t>(uidx[n]) + head[n];
+}
+
+__global__ __launch_bounds__(kBlock) void group_bounds(
+    int64_t n_groups, int64_t nnz, int64_t n_a, int32_t G,
+    const uint64_t *__restrict__ keys, const uint32_t *__restrict__ head,
+    const uint32_t *__restrict__ uidx, int64_t *__restrict__ meta)
+{
+    const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (g > n_groups)
+        return;
+    const uint64_t first = static_cast<uint64_t>(g) *
+                           static_cast<uint64_t>(n_a) * G;
+    int64_t lo = 0, hi = nnz;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (keys[mid] < first)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    // a group's first entry always opens a union entry (head = 1 there)
+    const int64_t n_union =
+        nnz > 0 ? (int64_t)uidx[nnz - 1] + (int64_t)head[nnz - 1] : 0;
+    meta[2 * g] = lo < nnz ? (int64_t)uidx[lo] : n_union;
+    meta[2 * g + 1] = lo;
+}
+
+__global__ __launch_bounds__(kBlock) void slot_info(
+    int64_t n_slots, int64_t n_rows, const double *__restrict__ frac_b,
+    int32_t *__restrict__ rid, double *__restrict__ gfrac)
+{
+    const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (s >= n_slots)
+        return;
+    // work slots past the last row (the partial last group) name a valid row
+    const int32_t r = s < n_rows ? rid[s] : static_cast<int32_t>(n_rows - 1);
+    if (s >= n_rows)
+        rid[s] = r;
+    gfrac[s] = frac_b[r];
+}
+
+uint32_t blocks_for(int64_t n)
+{
+    return static_cast<uint32_t>((n + kBlock - 1) / kBlock);
+}
+
+}  // namespace
+
+int groups_workspace(int64_t n_rows, int64_t nnz, size_t *bytes_out)
+{
+    if (!bytes_out || n_rows < 0 || nnz < 0)
+        return fail(REMAP_ERR_ARG, "remap_groups_workspace: bad args");
+    GroupLayout lay;
+    const int rc = group_layout(n_rows, nnz, &lay);
+    if (rc != REMAP_OK)
+        return rc;
+    *bytes_out = lay.total;
+    return REMAP_OK;
+}
+
+int groups_build(const remap_csr *A, const double *frac_b, int32_t G,
+                 const int64_t *grid_dims, int64_t row_offset,
+                 int32_t super_tile, int32_t *row_order_out, int64_t *meta,
+                 int32_t *gcol, int32_t *gmask, double *gw, int32_t *rid,
+                 double *gfrac, int64_t *n_union_out, void *workspace,
+                 size_t workspace_bytes, hipStream_t stream)
+{
+    if (!A || !frac_b || !meta || !gcol || !gmask || !gw || !rid || !gfrac ||
+        !n_union_out)
+        return fail(REMAP_ERR_ARG, "remap_groups_build: NULL argument");
+    if (G != 4 && G != 8)
+        return fail(REMAP_ERR_ARG,
+                    "remap_groups_build: groups hold 4 or 8 rows, not %d", G);
+    const int64_t n_rows = A->n_rows, nnz = A->nnz, n_a = A->n_cols;
+    if (n_rows <= 0 || nnz <= 0 || n_a <= 0)
+        return fail(REMAP_ERR_ARG,
+                    "remap_groups_build: an empty matrix has no schedule");
+    if (!A->rowptr || !A->col || !A->val)
+        return fail(REMAP_ERR_ARG, "remap_groups_build: NULL CSR array");
+    const int64_t n_groups = (n_rows + G - 1) / G;
+    // key = ((group * n_a + col) * G + member) must fit 64 bits
+    if (static_cast<long double>(n_groups) * n_a * G >= 9.0e18L ||
+        nnz >= (int64_t(1) << 32) - 1)
+        return fail(REMAP_ERR_UNSUPPORTED,
+                    "remap_groups_build: mapping too large for 64-bit keys");
+    int64_t st = super_tile > 0 ? super_tile : (int64_t(1) << 30);
+    if (grid_dims) {
+        if (grid_dims[0] <= 0 || grid_dims[1] <= 0 || row_offset < 0 ||
+            row_offset + n_rows > grid_dims[0] * grid_dims[1])
+            return fail(REMAP_ERR_ARG,
+                        "remap_groups_build: rows [%lld, %lld) outside the "
+                        "%lld x %lld grid", (long long)row_offset,
+                        (long long)(row_offset + n_rows),
+                        (long long)grid_dims[0], (long long)grid_dims[1]);
+        if (st % (G / 2) != 0 || st % 2 != 0)
+            return fail(REMAP_ERR_ARG,
+                        "remap_groups_build: super_tile %lld is not a "
+                        "multiple of the group tile", (long long)st);
+    }
+    GroupLayout lay;
+    int rc = group_layout(n_rows, nnz, &lay);
+    if (rc != REMAP_OK)
+        return rc;
+    if (!workspace || workspace_bytes < lay.total)
+        return fail(REMAP_ERR_WORKSPACE,
+                    "remap_groups_build: workspace of %zu bytes, need %zu",
+                    workspace_bytes, lay.total);
+    char *ws = static_cast<char *>(workspace);
+    uint64_t *rk_in = reinterpret_cast<uint64_t *>(ws + lay.row_keys_in);
+    uint64_t *rk_out = reinterpret_cast<uint64_t *>(ws + lay.row_keys_out);
+    int32_t *rows_in = reinterpret_cast<int32_t *>(ws + lay.rows_in);
+    int32_t *slot_of = reinterpret_cast<int32_t *>(ws + lay.slot_of_row);
+    uint64_t *k_in = reinterpret_cast<uint64_t *>(ws + lay.keys_in);
+    uint64_t *k_out = reinterpret_cast<uint64_t *>(ws + lay.keys_out);
+    uint32_t *head = reinterpret_cast<uint32_t *>(ws + lay.head);
+    uint32_t *uidx = reinterpret_cast<uint32_t *>(ws + lay.uidx);
+    void *temp = ws + lay.temp;
+
+    // 1. work-slot order
+    if (grid_dims) {
+        hipLaunchKernelGGL(order_keys, dim3(blocks_for(n_rows)), dim3(kBlock),
+                           0, stream, n_rows, row_offset, grid_dims[1], st, G,
+                           rk_in, rows_in);
+        REMAP_HIP_CHECK(hipGetLastError());
+        size_t tb = lay.temp_bytes;
+        REMAP_HIP_CHECK((rocprim::radix_sort_pairs(
+            temp, tb, static_cast<const uint64_t *>(rk_in), rk_out,
+            static_cast<const int32_t *>(rows_in), rid,
+            static_cast<size_t>(n_rows), 0u, 64u, stream)));
+        hipLaunchKernelGGL(invert_order, dim3(blocks_for(n_rows)),
+                           dim3(kBlock), 0, stream, n_rows, rid, slot_of,
+                           row_order_out);
+        REMAP_HIP_CHECK(hipGetLastError());
+    } else {
+        hipLaunchKernelGGL(identity_order, dim3(blocks_for(n_rows)),
+                           dim3(kBlock), 0, stream, n_rows, rid, slot_of);
+        REMAP_HIP_CHECK(hipGetLastError());
+    }
+    // 2. entries sorted by (group, col, member); the weights come out in
+    //    group_w's order
+    hipLaunchKernelGGL(entry_keys, dim3(blocks_for(n_rows)), dim3(kBlock), 0,
+                       stream, n_rows, n_a, G, A->rowptr, A->col, slot_of,
+                       k_in);
+    REMAP_HIP_CHECK(hipGetLastError());
+    size_t tb = lay.temp_bytes;
+    REMAP_HIP_CHECK((rocprim::radix_sort_pairs(
+        temp, tb, static_cast<const uint64_t *>(k_in), k_out, A->val, gw,
+        static_cast<size_t>(nnz), 0u, 64u, stream)));
+    REMAP_HIP_CHECK(hipMemsetAsync(gw + nnz, 0, 64 * sizeof(double), stream));
+    // 3. union entries
+    hipLaunchKernelGGL(flag_union_heads, dim3(blocks_for(nnz)), dim3(kBlock),
+                       0, stream, nnz, G, k_out, head);
+    REMAP_HIP_CHECK(hipGetLastError());
+    tb = lay.temp_bytes;
+    REMAP_HIP_CHECK((rocprim::exclusive_scan(
+        temp, tb, static_cast<const uint32_t *>(head), uidx, 0u,
+        static_cast<size_t>(nnz), rocprim::plus<uint32_t>(), stream)));
+    REMAP_HIP_CHECK(hipMemsetAsync(gcol, 0, (nnz + 8) * sizeof(int32_t),
+                                   stream));
+    REMAP_HIP_CHECK(hipMemsetAsync(gmask, 0, (nnz + 8) * sizeof(int32_t),
+                                   stream));
+    hipLaunchKernelGGL(fill_union, dim3(blocks_for(nnz)), dim3(kBlock), 0,
+                       stream, nnz, n_a, G, k_out, head, uidx, gcol, gmask,
+                       n_union_out);
+    REMAP_HIP_CHECK(hipGetLastError());
+    // 4. per-group bounds, per-slot row ids and frac_b
+    hipLaunchKernelGGL(group_bounds, dim3(blocks_for(n_groups + 1)),
+                       dim3(kBlock), 0, stream, n_groups, nnz, n_a, G, k_out,
+                       head, uidx, meta);
+    REMAP_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(slot_info, dim3(blocks_for(n_groups * G)), dim3(kBlock),
+                       0, stream, n_groups * G, n_rows, frac_b, rid, gfrac);
+    REMAP_HIP_CHECK(hipGetLastError());
+    return REMAP_OK;
+}
+
+}  // namespace remap
+
+extern "C" {
+
+int remap_groups_workspace(int64_t n_rows, int64_t nnz, size_t *bytes_out)
+{
+    return remap::groups_workspace(n_rows, nnz, bytes_out);
+}
+
+int remap_groups_build(const remap_csr *A, const double *frac_b,
+                       int32_t group_rows, const int64_t *grid_dims,
+                       int64_t row_offset, int32_t super_tile,
+                       int32_t *row_order_out, int64_t *group_meta,
+                       int32_t *group_col, int32_t *group_mask,
+                       double *group_w, int32_t *group_rid,
+                       double *group_frac, int64_t *n_union_out,
+                       void *workspace, size_t workspace_bytes, void *stream)
+{
+    return remap::groups_build(A, frac_b, group_rows, grid_dims, row_offset,
+                               super_tile, row_order_out, group_meta,
+                               group_col, group_mask, group_w, group_rid,
+                               group_frac, n_union_out, workspace,
+                               workspace_bytes,
+                               static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

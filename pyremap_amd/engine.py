@@ -33,7 +33,7 @@ FLAG_TREE = 8
 DTYPE_F64 = 0
 DTYPE_F32 = 1
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 #: readable pad entries kept behind col/val (remap_csr.csr_pad)
 CSR_PAD = 8
@@ -43,6 +43,7 @@ EXPORTS = (
     'remap_abi_version', 'remap_arch', 'remap_last_error',
     'remap_device_count', 'remap_apply_f64', 'remap_csr_from_coo_workspace',
     'remap_csr_from_coo', 'remap_stream_copy', 'remap_scan_nan',
+    'remap_groups_workspace', 'remap_groups_build',
 )
 
 
@@ -152,6 +153,14 @@ def load_library():
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
         ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    lib.remap_groups_workspace.restype = ctypes.c_int
+    lib.remap_groups_workspace.argtypes = [
+        ctypes.c_int64, ctypes.c_int64, ctypes.POINTER(ctypes.c_size_t)]
+    lib.remap_groups_build.restype = ctypes.c_int
+    lib.remap_groups_build.argtypes = [
+        ctypes.POINTER(_CSR), ctypes.c_void_p, ctypes.c_int32,
+        ctypes.POINTER(ctypes.c_int64), ctypes.c_int64, ctypes.c_int32] + \
+        [ctypes.c_void_p] * 9 + [ctypes.c_size_t, ctypes.c_void_p]
     lib.remap_scan_nan.restype = ctypes.c_int
     lib.remap_scan_nan.argtypes = [ctypes.c_void_p, ctypes.c_int32,
                                    ctypes.c_int64, ctypes.c_void_p,
@@ -527,83 +536,71 @@ class RemapPlan:
 
     def build_groups(self, grid_dims=None, super_tile=32, rows=None):
         """
-        Build the row-group schedule (``remap_apply_args.group_*``): ``rows``
-        (8 or 4) consecutive work slots -- a 2 x 4 or 2 x 2 tile of a 2-D
-        destination grid -- share one sorted list of the distinct source rows
-        they reference; the weights are stored for the present (union entry,
-        member) pairs only, in that order.  Returns union entries / entries
-        (small = many shared source rows).
+        Build the row-group schedule (``remap_apply_args.group_*``) with the
+        library's device builder (``remap_groups_build``): ``rows`` (8 or 4)
+        consecutive work slots -- a 2 x 4 or 2 x 2 tile of a 2-D destination
+        grid, walked row-major inside ``super_tile`` x ``super_tile`` blocks
+        -- share one sorted list of the distinct source rows they reference;
+        the weights are stored for the present (union entry, member) pairs
+        only, in that order.  Returns union entries / entries (small = many
+        shared source rows).
         """
         torch = _torch()
+        lib = load_library()
         G = int(rows or self.GROUP)
         if G not in (4, 8):
             raise ValueError('row groups hold 4 or 8 rows')
-        gy = 2                       # the group is a 2 x gx tile
-        gx = G // gy
         self.groups = None
         if self.nnz == 0 or self.n_b == 0:
             return None
-        if grid_dims is not None and len(grid_dims) == 2:
-            # 2 x gx groups, walked row-major INSIDE super_tile x super_tile
-            # blocks of the grid (keeps a group's neighbours -- and the
-            # stencil band they share -- in the XCD's L2)
+        dev = self.device
+        two_d = grid_dims is not None and len(grid_dims) == 2
+        dims = None
+        if two_d:
             my, mx = (int(d) for d in grid_dims)
             if my * mx != self.n_b_global:
                 raise ValueError(f'grid {grid_dims} does not hold '
                                  f'{self.n_b_global} cells')
-            st = int(super_tile)
-            rows_i = torch.arange(self.row_offset, self.row_offset + self.n_b,
-                                  device=self.device, dtype=torch.int64)
-            jy = rows_i // mx
-            jx = rows_i - jy * mx
-            nsx = (mx + st - 1) // st
-            key = ((jy // st) * nsx + jx // st) * (st * st) + \
-                (((jy % st) // gy) * (st // gx) + (jx % st) // gx) * G + \
-                (jy % gy) * gx + jx % gx
-            self.row_order = torch.argsort(key, stable=True).to(torch.int32)
-            order = self.row_order
-            slot_of_row = torch.empty(self.n_b, dtype=torch.int64,
-                                      device=self.device)
-            slot_of_row[order.to(torch.int64)] = torch.arange(
-                self.n_b, device=self.device)
-        else:
-            self.row_order = None
-            order = None
-            slot_of_row = torch.arange(self.n_b, device=self.device)
-        lens = self.rowptr[1:] - self.rowptr[:-1]
-        entry_slot = torch.repeat_interleave(slot_of_row, lens)
-        group_of_entry = entry_slot // G
-        member = entry_slot % G
+            dims = (ctypes.c_int64 * 2)(my, mx)
+        st = int(super_tile)
+        if st >= 1 << 30:
+            st = 0           # no supertiles: row-major over the whole grid
         n_groups = (self.n_b + G - 1) // G
-        key = group_of_entry * self.n_a + self.col.to(torch.int64)
-        uniq, inverse = torch.unique(key, sorted=True, return_inverse=True)
-        nu = int(uniq.shape[0])
-        meta = torch.zeros((n_groups + 1, 2), dtype=torch.int64,
-                           device=self.device)
-        meta[1:, 0] = torch.cumsum(torch.bincount(uniq // self.n_a,
-                                                  minlength=n_groups), 0)
-        meta[1:, 1] = torch.cumsum(torch.bincount(group_of_entry,
-                                                  minlength=n_groups), 0)
-        # weights of the present pairs in (union entry, member) order; a
-        # canonical CSR (unique (row, col) pairs: from_triplets / from_csr
-        # guarantee it) gives every pair one weight and one mask bit
-        perm = torch.argsort(inverse * G + member)
-        w = torch.zeros(self.nnz + 64, dtype=torch.float64,
-                        device=self.device)
-        w[:self.nnz] = self.val[perm]
-        mask = torch.zeros(nu + 8, dtype=torch.int32, device=self.device)
-        mask.index_add_(0, inverse, (1 << member).to(torch.int32))
-        col = torch.zeros(nu + 8, dtype=torch.int32, device=self.device)
-        col[:nu] = (uniq % self.n_a).to(torch.int32)
-        # row id and frac_b of every work slot, padded to whole groups
-        rid = torch.full((n_groups * G,), max(self.n_b - 1, 0),
-                         dtype=torch.int32, device=self.device)
-        rid[:self.n_b] = order if order is not None else torch.arange(
-            self.n_b, device=self.device, dtype=torch.int32)
-        frac = self.frac_b[rid.to(torch.int64)].contiguous()
-        self.groups = dict(meta=meta.contiguous(), col=col, w=w, mask=mask,
-                           rid=rid, frac=frac, n=n_groups, rows=G,
-                           order=order, union=nu)
+        meta = torch.empty((n_groups + 1, 2), dtype=torch.int64, device=dev)
+        col = torch.empty(self.nnz + 8, dtype=torch.int32, device=dev)
+        mask = torch.empty(self.nnz + 8, dtype=torch.int32, device=dev)
+        w = torch.empty(self.nnz + 64, dtype=torch.float64, device=dev)
+        rid = torch.empty(n_groups * G, dtype=torch.int32, device=dev)
+        frac = torch.empty(n_groups * G, dtype=torch.float64, device=dev)
+        order = torch.empty(self.n_b, dtype=torch.int32, device=dev) \
+            if two_d else None
+        n_union = torch.zeros(1, dtype=torch.int64, device=dev)
+        csr = _CSR()
+        csr.n_rows, csr.n_cols, csr.nnz = self.n_b, self.n_a, self.nnz
+        csr.rowptr = self.rowptr.data_ptr()
+        csr.col = self.col.data_ptr()
+        csr.val = self.val.data_ptr()
+        csr.max_row_nnz, csr.csr_pad = self.max_row_nnz, self.csr_pad
+        with torch.cuda.device(dev):
+            nbytes = ctypes.c_size_t(0)
+            _check(lib.remap_groups_workspace(self.n_b, self.nnz,
+                                              ctypes.byref(nbytes)),
+                   'remap_groups_workspace')
+            ws = torch.empty(max(int(nbytes.value), 1), dtype=torch.uint8,
+                             device=dev)
+            _check(lib.remap_groups_build(
+                ctypes.byref(csr), _ptr(self.frac_b), G, dims,
+                self.row_offset, st, _ptr(order), _ptr(meta), _ptr(col),
+                _ptr(mask), _ptr(w), _ptr(rid), _ptr(frac), _ptr(n_union),
+                _ptr(ws), ws.numel(), _stream_ptr(dev)),
+                'remap_groups_build')
+            nu = int(n_union)
+        self.row_order = order
+        # trim the union arrays to what is used (+ the readable pad)
+        self.groups = dict(meta=meta, col=col[:nu + 8].clone(),
+                           w=w, mask=mask[:nu + 8].clone(), rid=rid,
+                           frac=frac, n=n_groups, rows=G, order=order,
+                           union=nu)
         return nu / self.nnz
 
     #: tiles tried by auto_schedule, largest first

@@ -19,6 +19,9 @@ What this module is about is everything AROUND the 0.4 ms kernel:
 * nothing blocks until the caller asks for the data: a Dataset's variables
   are all enqueued before the first result is awaited.
 """
+import queue
+import threading
+
 import numpy as np
 
 from pyremap_amd import engine
@@ -202,12 +205,33 @@ def remap_host_array(plan, dst_grid_dims, values, remap_axes, *, mode,
         start.record(main)
         up.wait_event(start)
         finished = None
-        for b0 in range(0, n_batch, step):
-            b1 = min(b0 + step, n_batch)
-            with torch.cuda.stream(up):
-                xdb[b0:b1].copy_(xb[b0:b1], non_blocking=True)
-                arrived = torch.cuda.Event()
-                arrived.record(up)
+        chunks = [(b0, min(b0 + step, n_batch))
+                  for b0 in range(0, n_batch, step)]
+        # Uploads from PAGEABLE memory block the calling thread until the
+        # bytes are on the device, downloads into pinned memory do not: a
+        # helper thread feeds the `up` stream so that this thread can queue
+        # launches and downloads meanwhile (measured, 0.96 GB up + 1.06 GB
+        # down: 22 ms overlapped, 34 ms one after the other)
+        arrivals = queue.Queue()
+
+        def uploader():
+            try:
+                with torch.cuda.device(device), torch.cuda.stream(up):
+                    for b0, b1 in chunks:
+                        xdb[b0:b1].copy_(xb[b0:b1], non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record(up)
+                        arrivals.put(ev)
+            except BaseException as exc:   # noqa: BLE001 - handed over
+                arrivals.put(exc)
+
+        feeder = threading.Thread(target=uploader, daemon=True)
+        feeder.start()
+        for b0, b1 in chunks:
+            arrived = arrivals.get()
+            if isinstance(arrived, BaseException):
+                feeder.join()
+                raise arrived
             main.wait_event(arrived)
             engine.remap_tensor(
                 plan, dst_grid_dims, xdb[b0:b1], axes_b, emode,
@@ -223,6 +247,7 @@ def remap_host_array(plan, dst_grid_dims, values, remap_axes, *, mode,
                     mhb[b0:b1].copy_(mdb[b0:b1], non_blocking=True)
                 finished = torch.cuda.Event()
                 finished.record(down)
+        feeder.join()
         x_d.record_stream(up)
         y_d.record_stream(down)
         if m_d is not None:

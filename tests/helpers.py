@@ -58,3 +58,59 @@ def golden_map(path):
     return {k: g[k] for k in ('n_a', 'n_b', 'src_grid_dims', 'dst_grid_dims',
                               'row', 'col', 'S', 'frac_b', 'csr_indptr',
                               'csr_indices', 'csr_data')}
+
+
+def reference_group_schedule(plan, grid_dims=None, super_tile=32, rows=8):
+    """
+    The row-group schedule of kernel family 10 written out with plain torch
+    operations on the host's view of the CSR -- an independent restatement of
+    what ``remap_groups_build`` (csrc/remap_groups.hip) produces on the
+    device: ``(meta, col, mask, w, rid, frac, order, n_union)``.
+    """
+    import torch
+    G = int(rows)
+    gx = G // 2
+    dev = plan.device
+    if grid_dims is not None and len(grid_dims) == 2:
+        my, mx = (int(d) for d in grid_dims)
+        st = int(super_tile) if super_tile and super_tile < 1 << 30 \
+            else 1 << 30
+        r = torch.arange(plan.row_offset, plan.row_offset + plan.n_b,
+                         device=dev, dtype=torch.int64)
+        jy = r // mx
+        jx = r - jy * mx
+        nsx = (mx + st - 1) // st
+        key = ((jy // st) * nsx + jx // st) * (st * st) + \
+            (((jy % st) // 2) * (st // gx) + (jx % st) // gx) * G + \
+            (jy % 2) * gx + jx % gx
+        order = torch.argsort(key, stable=True).to(torch.int32)
+        slot_of_row = torch.empty(plan.n_b, dtype=torch.int64, device=dev)
+        slot_of_row[order.to(torch.int64)] = torch.arange(plan.n_b,
+                                                          device=dev)
+    else:
+        order = None
+        slot_of_row = torch.arange(plan.n_b, device=dev)
+    lens = plan.rowptr[1:] - plan.rowptr[:-1]
+    entry_slot = torch.repeat_interleave(slot_of_row, lens)
+    group_of_entry = entry_slot // G
+    member = entry_slot % G
+    n_groups = (plan.n_b + G - 1) // G
+    key = group_of_entry * plan.n_a + plan.col.to(torch.int64)
+    uniq, inverse = torch.unique(key, sorted=True, return_inverse=True)
+    nu = int(uniq.shape[0])
+    meta = torch.zeros((n_groups + 1, 2), dtype=torch.int64, device=dev)
+    meta[1:, 0] = torch.cumsum(torch.bincount(uniq // plan.n_a,
+                                              minlength=n_groups), 0)
+    meta[1:, 1] = torch.cumsum(torch.bincount(group_of_entry,
+                                              minlength=n_groups), 0)
+    perm = torch.argsort(inverse * G + member)
+    w = plan.val[perm]
+    mask = torch.zeros(nu, dtype=torch.int32, device=dev)
+    mask.index_add_(0, inverse, (1 << member).to(torch.int32))
+    col = (uniq % plan.n_a).to(torch.int32)
+    rid = torch.full((n_groups * G,), max(plan.n_b - 1, 0),
+                     dtype=torch.int32, device=dev)
+    rid[:plan.n_b] = order if order is not None else torch.arange(
+        plan.n_b, device=dev, dtype=torch.int32)
+    frac = plan.frac_b[rid.to(torch.int64)]
+    return meta, col, mask, w, rid, frac, order, nu

@@ -1402,3 +1402,45 @@ def test_host_arrays_pinned_pipelined_and_poisoned(dev):
     assert np.array_equal(got_mask, ref_mask)
     assert_bitwise(np.where(ref_mask, 0.0, data),
                    np.where(ref_mask, 0.0, ref_data), 'poisoned entry')
+
+
+@pytest.mark.parametrize('rows', [8, 4])
+@pytest.mark.parametrize('case', ['2d', '2d_supertile', '1d', 'shard'])
+def test_group_schedule_builder_matches_restatement(dev, case, rows):
+    """
+    remap_groups_build (the C ABI's device builder of the row-group schedule)
+    against a plain-torch restatement: every array identical -- group bounds,
+    union columns, member masks, the compact weights, work-slot row ids,
+    frac_b, processing order.
+    """
+    from helpers import reference_group_schedule
+    from pyremap_amd import engine, synthetic
+    m = synthetic.conservative_map(2500, (37, 50), 2, 12, seed=31,
+                                   signed=True)
+    mm = m.numpy()
+    plan = engine.RemapPlan.from_triplets(mm['row'], mm['col'], mm['S'],
+                                          mm['frac_b'], m.n_a, m.n_b,
+                                          device=dev)
+    dims, st = m.dst_dims, 1 << 30
+    if case == '2d_supertile':
+        st = 8
+    elif case == '1d':
+        dims = None
+    elif case == 'shard':
+        plan = plan.row_slice(333, 1501)       # rows 333..1500 of the grid
+    ratio = plan.build_groups(dims, super_tile=st, rows=rows)
+    g = plan.groups
+    meta, col, mask, w, rid, frac, order, nu = reference_group_schedule(
+        plan, dims, super_tile=st, rows=rows)
+    assert g['union'] == nu and abs(ratio - nu / plan.nnz) < 1e-15
+    assert torch.equal(g['meta'], meta)
+    assert torch.equal(g['col'][:nu], col)
+    assert torch.equal(g['mask'][:nu], mask)
+    assert torch.equal(g['w'][:plan.nnz], w)          # bit for bit
+    assert bool((g['w'][plan.nnz:] == 0).all())
+    assert torch.equal(g['rid'], rid)
+    assert torch.equal(g['frac'], frac)
+    if order is None:
+        assert plan.row_order is None
+    else:
+        assert torch.equal(plan.row_order, order)
