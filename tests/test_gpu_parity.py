@@ -1444,3 +1444,54 @@ def test_group_schedule_builder_matches_restatement(dev, case, rows):
         assert plan.row_order is None
     else:
         assert torch.equal(plan.row_order, order)
+
+
+def test_integration_stub_runs_on_the_c_abi_alone(dev):
+    """
+    The ctypes stub printed in INTEGRATION.md -- what a pyremap maintainer
+    would paste -- is executed as it stands (only the library path is filled
+    in): CSR from triplets, the row-group schedule from remap_groups_build,
+    the apply; none of pyremap_amd's host code is involved.  Bit for bit the
+    oracle, frac_b and masked branch, and the schedule's kernel really ran.
+    """
+    from oracle import oracle
+    from pyremap_amd import engine, synthetic
+    text = open(os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), 'INTEGRATION.md')).read()
+    code = text[text.index('```python') + len('```python'):]
+    code = code[:code.index('```')]
+    code = code.replace("'libremap_hip.so'", repr(engine.library_path()))
+    ns = {}
+    exec(compile(code, 'INTEGRATION.md', 'exec'), ns)
+    m = synthetic.conservative_map(3000, (30, 44), 1, 7, seed=12)
+    mm = m.numpy()
+    csr = ns['build_csr'](mm['row'], mm['col'], mm['S'], m.n_b, m.n_a)
+    frac_b = torch.as_tensor(mm['frac_b'], device=dev)
+    sched = ns['build_schedule'](csr, frac_b, list(m.dst_dims))
+    ref_csr = oracle.coo_to_csr(mm['row'] - 1, mm['col'] - 1, mm['S'],
+                                m.n_b, m.n_a)
+    rng = np.random.default_rng(6)
+    K = 192
+    x = rng.standard_normal((m.n_a, K))
+    xm = x.copy()
+    xm[rng.random(m.n_a) < 0.25, :] = np.nan
+    for field, masked in ((x, False), (xm, True)):
+        X = torch.from_numpy(field).to(dev)
+        Y = torch.full((m.n_b, K), 9.0, dtype=torch.float64, device=dev)
+        M = torch.zeros((m.n_b, K), dtype=torch.uint8, device=dev)
+        ns['apply'](csr, sched, frac_b, X, Y, K, masked, 0.2, mask_out=M)
+        ref, ref_mask = oracle.remap_flat(ref_csr, mm['frac_b'], field,
+                                          masked, 0.2)
+        ref[ref_mask] = np.nan
+        assert_bitwise(Y.cpu().numpy(), ref, f'stub masked={masked}')
+        assert np.array_equal(M.cpu().numpy().astype(bool), ref_mask)
+    # a schedule that is not what it claims to be would be caught here: the
+    # group kernel without the schedule's processing order gives other rows
+    plain = torch.empty((m.n_b, K), dtype=torch.float64, device=dev)
+    ns['apply'](csr, None, frac_b, torch.from_numpy(x).to(dev), plain, K,
+                False, 0.0)
+    Y2 = torch.empty((m.n_b, K), dtype=torch.float64, device=dev)
+    ns['apply'](csr, sched, frac_b, torch.from_numpy(x).to(dev), Y2, K,
+                False, 0.0)
+    assert torch.equal(torch.nan_to_num(plain, nan=1e300),
+                       torch.nan_to_num(Y2, nan=1e300))

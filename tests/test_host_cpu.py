@@ -593,3 +593,17 @@ def test_xr_lite_container_api():
     assert doubled['raw'].values.tolist() == [0.0, 2.0]
     ds['t'].attrs['units'] = 'K'                # attrs are shared, not copied
     assert ds['t'].attrs['units'] == 'K'
+
+
+def test_integration_stub_matches_the_binding():
+    """The ctypes stub shown in INTEGRATION.md declares the same struct
+    fields, in the same order, as the binding the package itself uses (which
+    test_struct_layout_matches_header ties to include/remap_hip.h)."""
+    import re
+    from pyremap_amd import engine
+    text = open(os.path.join(REPO, 'INTEGRATION.md')).read()
+    block = text[text.index('class _Args(ctypes.Structure)'):]
+    block = block[:block.index('def _check')]
+    names = re.findall(r"\('(\w+)',", block)
+    assert names == [f[0] for f in engine._ApplyArgs._fields_]
+    assert f'remap_abi_version() == {engine.ABI_VERSION}' in text

@@ -40,7 +40,7 @@ def main():
           for _ in range(2)]
 
     def launch(i):
-        engine.remap_tensor(plan, m.dst_dims if n == 1 else None, xs[i % 2], [0], engine.MODE_FRACB,
+        engine.remap_tensor(plan, None, xs[i % 2], [0], engine.MODE_FRACB,
                             out=ys[i % 2])
 
     for i in range(20):
