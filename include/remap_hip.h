@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define REMAP_ABI_VERSION 14
+#define REMAP_ABI_VERSION 15
 
 enum {
     REMAP_OK = 0,
@@ -294,6 +294,33 @@ int remap_groups_build(const remap_csr *A, const double *frac_b,
                        double *group_w, int32_t *group_rid,
                        double *group_frac, int64_t *n_union_out,
                        void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Build the LDS patch plan of kernel family 5 (remap_apply_args.patch_*) for
+ * the rows of A on the device.  Work slots are walked in tile_y x tile_x
+ * tiles of a 2-D destination grid (grid_dims = HOST {my, mx}; NULL: natural
+ * order, patches of tile_y * tile_x consecutive rows); tile_y * tile_x
+ * consecutive slots form a patch (= remap_apply_args.patch_rows).
+ *
+ *   row_order_out (device, A.n_rows; required with grid_dims)
+ *   patch_ptr     (device) n_patches + 1      n_patches = ceil(n_rows / rows)
+ *   patch_ucol    (device) A.nnz (distinct (patch, col) pairs <= nnz)
+ *   patch_rowptr  (device) A.n_rows + 1
+ *   patch_lidx, patch_val  (device) A.nnz
+ *   stats_out     (device) int64[3]: distinct pairs, longest per-patch list
+ *                 (patch_umax), most entries in one patch (patch_emax) --
+ *                 what the caller needs to size the LDS image (see
+ *                 patch_row_bytes) and to decide whether the tile fits
+ * Asynchronous on `stream`; nothing is allocated.
+ */
+int remap_patches_workspace(int64_t n_rows, int64_t nnz, size_t *bytes_out);
+int remap_patches_build(const remap_csr *A, const int64_t *grid_dims,
+                        int64_t row_offset, int32_t tile_y, int32_t tile_x,
+                        int32_t *row_order_out, int32_t *patch_ptr,
+                        int32_t *patch_ucol, int32_t *patch_rowptr,
+                        int32_t *patch_lidx, double *patch_val,
+                        int64_t *stats_out, void *workspace,
+                        size_t workspace_bytes, void *stream);
 
 /*
  * OR 1 into *flag (device int32, zeroed by the caller) if any of the n

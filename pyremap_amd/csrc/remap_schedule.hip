@@ -1,5 +1,6 @@
-// remap_groups.hip -- builds the row-group schedule of kernel family 10 on
-// the device (one-off per Remapper / per row shard).
+// remap_schedule.hip -- builds the per-mapping schedules on the device
+// (one-off per Remapper / per row shard): the row-group schedule of kernel
+// family 10 (first half) and the LDS patch plan of family 5 (second half).
 //
 // The schedule (include/remap_hip.h, remap_apply_args.group_*) lets one wave
 // compute G neighbouring destination rows over the sorted union of their
@@ -365,6 +366,346 @@ int remap_groups_build(const remap_csr *A, const double *frac_b,
                                group_frac, n_union_out, workspace,
                                workspace_bytes,
                                static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"
+
+// ===========================================================================
+// The LDS patch plan of kernel family 5 (remap_apply_args.patch_*), built on
+// the device the same way:
+//
+//   tile_keys      rows of a 2-D destination grid are walked in ty x tx tiles
+//                  (1-D: natural order); ty * tx consecutive work slots = one
+//                  patch
+//   radix sort     rows by key -> row of every slot; scatter -> slot of a row
+//   slot_lengths + scan   entries per slot -> patch_rowptr (patch-major CSR)
+//   patch_entry_keys      per CSR entry: key = patch * n_a + col, payload =
+//                  its position q in slot order; patch_val[q] = S
+//   radix sort     (key, q); head flags + scan -> index of the distinct
+//                  (patch, col) pair
+//   patch_bounds   per patch: lower_bound -> patch_ptr; per distinct pair:
+//                  patch_ucol
+//   patch_local    patch_lidx[q] = index of the entry's column in ITS patch's
+//                  list; umax / emax by atomicMax
+// ===========================================================================
+namespace remap {
+namespace {
+
+struct PatchLayout {
+    size_t row_keys_in, row_keys_out, rows_in, rid, slot_of_row, lens, keys_in,
+        keys_out, q_in, q_out, head, uidx, temp, total;
+    size_t temp_bytes;
+};
+
+int patch_layout(int64_t n_rows, int64_t nnz, PatchLayout *lay)
+{
+    const size_t nr = static_cast<size_t>(n_rows > 0 ? n_rows : 1);
+    const size_t ne = static_cast<size_t>(nnz > 0 ? nnz : 1);
+    size_t a = 0, b = 0, c = 0, d = 0;
+    REMAP_HIP_CHECK((rocprim::radix_sort_pairs(
+        nullptr, a, static_cast<const uint64_t *>(nullptr),
+        static_cast<uint64_t *>(nullptr), static_cast<const int32_t *>(nullptr),
+        static_cast<int32_t *>(nullptr), nr, 0u, 64u)));
+    REMAP_HIP_CHECK((rocprim::radix_sort_pairs(
+        nullptr, b, static_cast<const uint64_t *>(nullptr),
+        static_cast<uint64_t *>(nullptr),
+        static_cast<const uint32_t *>(nullptr),
+        static_cast<uint32_t *>(nullptr), ne, 0u, 64u)));
+    REMAP_HIP_CHECK((rocprim::exclusive_scan(
+        nullptr, c, static_cast<const uint32_t *>(nullptr),
+        static_cast<uint32_t *>(nullptr), 0u, ne, rocprim::plus<uint32_t>())));
+    REMAP_HIP_CHECK((rocprim::exclusive_scan(
+        nullptr, d, static_cast<const int32_t *>(nullptr),
+        static_cast<int32_t *>(nullptr), 0, nr + 1, rocprim::plus<int32_t>())));
+    lay->temp_bytes = a;
+    if (b > lay->temp_bytes) lay->temp_bytes = b;
+    if (c > lay->temp_bytes) lay->temp_bytes = c;
+    if (d > lay->temp_bytes) lay->temp_bytes = d;
+    size_t off = 0;
+    lay->row_keys_in = off;  off += align_g(nr * 8);
+    lay->row_keys_out = off; off += align_g(nr * 8);
+    lay->rows_in = off;      off += align_g(nr * 4);
+    lay->rid = off;          off += align_g(nr * 4);
+    lay->slot_of_row = off;  off += align_g(nr * 4);
+    lay->lens = off;         off += align_g((nr + 1) * 4);
+    lay->keys_in = off;      off += align_g(ne * 8);
+    lay->keys_out = off;     off += align_g(ne * 8);
+    lay->q_in = off;         off += align_g(ne * 4);
+    lay->q_out = off;        off += align_g(ne * 4);
+    lay->head = off;         off += align_g(ne * 4);
+    lay->uidx = off;         off += align_g(ne * 4);
+    lay->temp = off;         off += align_g(lay->temp_bytes);
+    lay->total = off;
+    return REMAP_OK;
+}
+
+__global__ __launch_bounds__(kBlock) void tile_keys(
+    int64_t n_rows, int64_t row_offset, int64_t mx, int64_t ty, int64_t tx,
+    uint64_t *__restrict__ keys, int32_t *__restrict__ rows)
+{
+    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= n_rows)
+        return;
+    const int64_t i = row_offset + r;
+    const int64_t jy = i / mx;
+    const int64_t jx = i - jy * mx;
+    const int64_t ntx = (mx + tx - 1) / tx;
+    keys[r] = static_cast<uint64_t>(
+        ((jy / ty) * ntx + jx / tx) * (ty * tx) + (jy % ty) * tx + jx % tx);
+    rows[r] = static_cast<int32_t>(r);
+}
+
+__global__ __launch_bounds__(kBlock) void slot_lengths(
+    int64_t n_rows, const int32_t *__restrict__ rid,
+    const int64_t *__restrict__ rowptr, int32_t *__restrict__ lens)
+{
+    const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (s > n_rows)
+        return;
+    lens[s] = s < n_rows
+                  ? static_cast<int32_t>(rowptr[rid[s] + 1] - rowptr[rid[s]])
+                  : 0;
+}
+
+__global__ __launch_bounds__(kBlock) void patch_entry_keys(
+    int64_t n_rows, int64_t n_a, int64_t patch_rows,
+    const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const double *__restrict__ val, const int32_t *__restrict__ slot_of,
+    const int32_t *__restrict__ prow, uint64_t *__restrict__ keys,
+    uint32_t *__restrict__ q_of, double *__restrict__ pval)
+{
+    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= n_rows)
+        return;
+    const int64_t slot = slot_of[r];
+    const uint64_t patch = static_cast<uint64_t>(slot / patch_rows);
+    const int64_t q0 = prow[slot];
+    const int64_t e0 = rowptr[r];
+    for (int64_t e = e0; e < rowptr[r + 1]; ++e) {
+        const int64_t q = q0 + (e - e0);
+        keys[e] = patch * static_cast<uint64_t>(n_a) +
+                  static_cast<uint64_t>(col[e]);
+        q_of[e] = static_cast<uint32_t>(q);
+        pval[q] = val[e];
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void flag_pair_heads(
+    int64_t nnz, const uint64_t *__restrict__ keys,
+    uint32_t *__restrict__ head)
+{
+    const int64_t n = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (n >= nnz)
+        return;
+    head[n] = (n == 0 || keys[n] != keys[n - 1]) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(kBlock) void patch_bounds(
+    int64_t n_patches, int64_t nnz, int64_t n_a, int64_t n_rows,
+    int64_t patch_rows, const uint64_t *__restrict__ keys,
+    const uint32_t *__restrict__ head, const uint32_t *__restrict__ uidx,
+    const int32_t *__restrict__ prow, int32_t *__restrict__ pptr,
+    int64_t *__restrict__ stats)
+{
+    const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (p > n_patches)
+        return;
+    auto first_of = [&](int64_t patch) {
+        const uint64_t first =
+            static_cast<uint64_t>(patch) * static_cast<uint64_t>(n_a);
+        int64_t lo = 0, hi = nnz;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (keys[mid] < first)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        const int64_t n_union =
+            nnz > 0 ? (int64_t)uidx[nnz - 1] + (int64_t)head[nnz - 1] : 0;
+        return lo < nnz ? (int64_t)uidx[lo] : n_union;
+    };
+    const int64_t mine = first_of(p);
+    pptr[p] = static_cast<int32_t>(mine);
+    if (p == n_patches) {
+        stats[0] = mine;   // distinct (patch, col) pairs
+        return;
+    }
+    const int64_t next = first_of(p + 1);
+    atomicMax(reinterpret_cast<unsigned long long *>(stats + 1),
+              static_cast<unsigned long long>(next - mine));
+    int64_t s1 = (p + 1) * patch_rows;
+    if (s1 > n_rows)
+        s1 = n_rows;
+    atomicMax(reinterpret_cast<unsigned long long *>(stats + 2),
+              static_cast<unsigned long long>(prow[s1] - prow[p * patch_rows]));
+}
+
+__global__ __launch_bounds__(kBlock) void patch_local(
+    int64_t nnz, int64_t n_a, const uint64_t *__restrict__ keys,
+    const uint32_t *__restrict__ q_sorted, const uint32_t *__restrict__ head,
+    const uint32_t *__restrict__ uidx, const int32_t *__restrict__ pptr,
+    int32_t *__restrict__ ucol, int32_t *__restrict__ lidx)
+{
+    const int64_t n = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (n >= nnz)
+        return;
+    const uint64_t key = keys[n];
+    const uint32_t u = head[n] ? uidx[n] : uidx[n] - 1u;
+    const uint64_t patch = key / static_cast<uint64_t>(n_a);
+    if (head[n])
+        ucol[u] = static_cast<int32_t>(key % static_cast<uint64_t>(n_a));
+    lidx[q_sorted[n]] = static_cast<int32_t>(u) - pptr[patch];
+}
+
+}  // namespace
+
+int patches_workspace(int64_t n_rows, int64_t nnz, size_t *bytes_out)
+{
+    if (!bytes_out || n_rows < 0 || nnz < 0)
+        return fail(REMAP_ERR_ARG, "remap_patches_workspace: bad args");
+    PatchLayout lay;
+    const int rc = patch_layout(n_rows, nnz, &lay);
+    if (rc != REMAP_OK)
+        return rc;
+    *bytes_out = lay.total;
+    return REMAP_OK;
+}
+
+int patches_build(const remap_csr *A, const int64_t *grid_dims,
+                  int64_t row_offset, int32_t tile_y, int32_t tile_x,
+                  int32_t *row_order_out, int32_t *pptr, int32_t *ucol,
+                  int32_t *prow, int32_t *lidx, double *pval, int64_t *stats,
+                  void *workspace, size_t workspace_bytes, hipStream_t stream)
+{
+    if (!A || !pptr || !ucol || !prow || !lidx || !pval || !stats)
+        return fail(REMAP_ERR_ARG, "remap_patches_build: NULL argument");
+    const int64_t n_rows = A->n_rows, nnz = A->nnz, n_a = A->n_cols;
+    if (n_rows <= 0 || nnz <= 0 || n_a <= 0)
+        return fail(REMAP_ERR_ARG,
+                    "remap_patches_build: an empty matrix has no plan");
+    if (!A->rowptr || !A->col || !A->val)
+        return fail(REMAP_ERR_ARG, "remap_patches_build: NULL CSR array");
+    if (tile_y < 1 || tile_x < 1)
+        return fail(REMAP_ERR_ARG, "remap_patches_build: tile %d x %d",
+                    tile_y, tile_x);
+    if (grid_dims && !row_order_out)
+        return fail(REMAP_ERR_ARG,
+                    "remap_patches_build: a 2-D walk needs row_order_out");
+    const int64_t patch_rows = (int64_t)tile_y * tile_x;
+    const int64_t n_patches = (n_rows + patch_rows - 1) / patch_rows;
+    if (nnz >= (int64_t(1) << 31) ||
+        static_cast<long double>(n_patches) * n_a >= 9.0e18L)
+        return fail(REMAP_ERR_UNSUPPORTED,
+                    "remap_patches_build: mapping too large for 32-bit "
+                    "patch offsets");
+    if (grid_dims &&
+        (grid_dims[0] <= 0 || grid_dims[1] <= 0 || row_offset < 0 ||
+         row_offset + n_rows > grid_dims[0] * grid_dims[1]))
+        return fail(REMAP_ERR_ARG,
+                    "remap_patches_build: rows outside the grid");
+    PatchLayout lay;
+    int rc = patch_layout(n_rows, nnz, &lay);
+    if (rc != REMAP_OK)
+        return rc;
+    if (!workspace || workspace_bytes < lay.total)
+        return fail(REMAP_ERR_WORKSPACE,
+                    "remap_patches_build: workspace of %zu bytes, need %zu",
+                    workspace_bytes, lay.total);
+    char *ws = static_cast<char *>(workspace);
+    uint64_t *rk_in = reinterpret_cast<uint64_t *>(ws + lay.row_keys_in);
+    uint64_t *rk_out = reinterpret_cast<uint64_t *>(ws + lay.row_keys_out);
+    int32_t *rows_in = reinterpret_cast<int32_t *>(ws + lay.rows_in);
+    int32_t *rid = reinterpret_cast<int32_t *>(ws + lay.rid);
+    int32_t *slot_of = reinterpret_cast<int32_t *>(ws + lay.slot_of_row);
+    int32_t *lens = reinterpret_cast<int32_t *>(ws + lay.lens);
+    uint64_t *k_in = reinterpret_cast<uint64_t *>(ws + lay.keys_in);
+    uint64_t *k_out = reinterpret_cast<uint64_t *>(ws + lay.keys_out);
+    uint32_t *q_in = reinterpret_cast<uint32_t *>(ws + lay.q_in);
+    uint32_t *q_out = reinterpret_cast<uint32_t *>(ws + lay.q_out);
+    uint32_t *head = reinterpret_cast<uint32_t *>(ws + lay.head);
+    uint32_t *uidx = reinterpret_cast<uint32_t *>(ws + lay.uidx);
+    void *temp = ws + lay.temp;
+
+    REMAP_HIP_CHECK(hipMemsetAsync(stats, 0, 3 * sizeof(int64_t), stream));
+    if (grid_dims) {
+        hipLaunchKernelGGL(tile_keys, dim3(blocks_for(n_rows)), dim3(kBlock),
+                           0, stream, n_rows, row_offset, grid_dims[1],
+                           (int64_t)tile_y, (int64_t)tile_x, rk_in, rows_in);
+        REMAP_HIP_CHECK(hipGetLastError());
+        size_t tb = lay.temp_bytes;
+        REMAP_HIP_CHECK((rocprim::radix_sort_pairs(
+            temp, tb, static_cast<const uint64_t *>(rk_in), rk_out,
+            static_cast<const int32_t *>(rows_in), rid,
+            static_cast<size_t>(n_rows), 0u, 64u, stream)));
+        hipLaunchKernelGGL(invert_order, dim3(blocks_for(n_rows)),
+                           dim3(kBlock), 0, stream, n_rows, rid, slot_of,
+                           row_order_out);
+        REMAP_HIP_CHECK(hipGetLastError());
+    } else {
+        hipLaunchKernelGGL(identity_order, dim3(blocks_for(n_rows)),
+                           dim3(kBlock), 0, stream, n_rows, rid, slot_of);
+        REMAP_HIP_CHECK(hipGetLastError());
+    }
+    // entries per slot -> patch_rowptr
+    hipLaunchKernelGGL(slot_lengths, dim3(blocks_for(n_rows + 1)),
+                       dim3(kBlock), 0, stream, n_rows, rid, A->rowptr, lens);
+    REMAP_HIP_CHECK(hipGetLastError());
+    size_t tb = lay.temp_bytes;
+    REMAP_HIP_CHECK((rocprim::exclusive_scan(
+        temp, tb, static_cast<const int32_t *>(lens), prow, 0,
+        static_cast<size_t>(n_rows + 1), rocprim::plus<int32_t>(), stream)));
+    // distinct (patch, col) pairs
+    hipLaunchKernelGGL(patch_entry_keys, dim3(blocks_for(n_rows)),
+                       dim3(kBlock), 0, stream, n_rows, n_a, patch_rows,
+                       A->rowptr, A->col, A->val, slot_of, prow, k_in, q_in,
+                       pval);
+    REMAP_HIP_CHECK(hipGetLastError());
+    tb = lay.temp_bytes;
+    REMAP_HIP_CHECK((rocprim::radix_sort_pairs(
+        temp, tb, static_cast<const uint64_t *>(k_in), k_out,
+        static_cast<const uint32_t *>(q_in), q_out, static_cast<size_t>(nnz),
+        0u, 64u, stream)));
+    hipLaunchKernelGGL(flag_pair_heads, dim3(blocks_for(nnz)), dim3(kBlock),
+                       0, stream, nnz, k_out, head);
+    REMAP_HIP_CHECK(hipGetLastError());
+    tb = lay.temp_bytes;
+    REMAP_HIP_CHECK((rocprim::exclusive_scan(
+        temp, tb, static_cast<const uint32_t *>(head), uidx, 0u,
+        static_cast<size_t>(nnz), rocprim::plus<uint32_t>(), stream)));
+    hipLaunchKernelGGL(patch_bounds, dim3(blocks_for(n_patches + 1)),
+                       dim3(kBlock), 0, stream, n_patches, nnz, n_a, n_rows,
+                       patch_rows, k_out, head, uidx, prow, pptr, stats);
+    REMAP_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(patch_local, dim3(blocks_for(nnz)), dim3(kBlock), 0,
+                       stream, nnz, n_a, k_out, q_out, head, uidx, pptr, ucol,
+                       lidx);
+    REMAP_HIP_CHECK(hipGetLastError());
+    return REMAP_OK;
+}
+
+}  // namespace remap
+
+extern "C" {
+
+int remap_patches_workspace(int64_t n_rows, int64_t nnz, size_t *bytes_out)
+{
+    return remap::patches_workspace(n_rows, nnz, bytes_out);
+}
+
+int remap_patches_build(const remap_csr *A, const int64_t *grid_dims,
+                        int64_t row_offset, int32_t tile_y, int32_t tile_x,
+                        int32_t *row_order_out, int32_t *patch_ptr,
+                        int32_t *patch_ucol, int32_t *patch_rowptr,
+                        int32_t *patch_lidx, double *patch_val,
+                        int64_t *stats_out, void *workspace,
+                        size_t workspace_bytes, void *stream)
+{
+    return remap::patches_build(A, grid_dims, row_offset, tile_y, tile_x,
+                                row_order_out, patch_ptr, patch_ucol,
+                                patch_rowptr, patch_lidx, patch_val,
+                                stats_out, workspace, workspace_bytes,
+                                static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

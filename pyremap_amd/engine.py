@@ -33,7 +33,7 @@ FLAG_TREE = 8
 DTYPE_F64 = 0
 DTYPE_F32 = 1
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 #: readable pad entries kept behind col/val (remap_csr.csr_pad)
 CSR_PAD = 8
@@ -44,6 +44,7 @@ EXPORTS = (
     'remap_device_count', 'remap_apply_f64', 'remap_csr_from_coo_workspace',
     'remap_csr_from_coo', 'remap_stream_copy', 'remap_scan_nan',
     'remap_groups_workspace', 'remap_groups_build',
+    'remap_patches_workspace', 'remap_patches_build',
 )
 
 
@@ -161,6 +162,14 @@ def load_library():
         ctypes.POINTER(_CSR), ctypes.c_void_p, ctypes.c_int32,
         ctypes.POINTER(ctypes.c_int64), ctypes.c_int64, ctypes.c_int32] + \
         [ctypes.c_void_p] * 9 + [ctypes.c_size_t, ctypes.c_void_p]
+    lib.remap_patches_workspace.restype = ctypes.c_int
+    lib.remap_patches_workspace.argtypes = [
+        ctypes.c_int64, ctypes.c_int64, ctypes.POINTER(ctypes.c_size_t)]
+    lib.remap_patches_build.restype = ctypes.c_int
+    lib.remap_patches_build.argtypes = [
+        ctypes.POINTER(_CSR), ctypes.POINTER(ctypes.c_int64), ctypes.c_int64,
+        ctypes.c_int32, ctypes.c_int32] + [ctypes.c_void_p] * 8 + \
+        [ctypes.c_size_t, ctypes.c_void_p]
     lib.remap_scan_nan.restype = ctypes.c_int
     lib.remap_scan_nan.argtypes = [ctypes.c_void_p, ctypes.c_int32,
                                    ctypes.c_int64, ctypes.c_void_p,
@@ -447,90 +456,89 @@ class RemapPlan:
             raise ValueError(f'unknown schedule {kind!r}')
         self.row_order = torch.argsort(key, stable=True).to(torch.int32)
 
+    def _csr_struct(self):
+        csr = _CSR()
+        csr.n_rows, csr.n_cols, csr.nnz = self.n_b, self.n_a, self.nnz
+        csr.rowptr = self.rowptr.data_ptr()
+        csr.col = self.col.data_ptr()
+        csr.val = self.val.data_ptr()
+        csr.max_row_nnz, csr.csr_pad = self.max_row_nnz, self.csr_pad
+        return csr
+
     def build_patches(self, grid_dims=None, tile=(4, 8), lds_budget=80 * 1024,
                       row_bytes=1024):
         """
-        Build the LDS-staging schedule (``remap_apply_args.patch_*``):
-        destination rows are walked in ``tile`` order over a 2-D grid (natural
-        order for 1-D destinations), ``tile[0] * tile[1]`` consecutive work
-        slots form a patch, and for every patch the distinct source rows are
-        listed once.  The tile is halved until the longest list fits the LDS
-        budget (``row_bytes`` per staged source-row chunk).  Returns the
-        fraction distinct / entries (small = much reuse), or ``None`` if no
-        patch size fits.
+        Build the LDS-staging schedule (``remap_apply_args.patch_*``) with
+        the library's device builder (``remap_patches_build``): destination
+        rows are walked in ``tile`` order over a 2-D grid (natural order for
+        1-D destinations), ``tile[0] * tile[1]`` consecutive work slots form
+        a patch, and for every patch the distinct source rows are listed
+        once.  The tile is halved until the longest list fits the LDS budget
+        (``row_bytes`` per staged source-row chunk).  Returns the fraction
+        distinct / entries (small = much reuse), or ``None`` if no patch size
+        fits.
         """
         torch = _torch()
+        lib = load_library()
         if self.nnz == 0 or self.n_b == 0:
             self.patches = None
             return None
+        dev = self.device
         ty, tx = (int(t) for t in tile)
-        lens = self.rowptr[1:] - self.rowptr[:-1]
-        entry_row = torch.repeat_interleave(
-            torch.arange(self.n_b, device=self.device), lens)
-        col64 = self.col.to(torch.int64)
-        while True:
-            if grid_dims is not None and len(grid_dims) == 2:
-                self.set_grid_schedule(grid_dims, 'tile', (ty, tx))
-                order = self.row_order
-                slot_of_row = torch.empty(self.n_b, dtype=torch.int64,
-                                          device=self.device)
-                slot_of_row[order.to(torch.int64)] = torch.arange(
-                    self.n_b, device=self.device)
-            else:
-                self.row_order = None
-                order = None
-                slot_of_row = torch.arange(self.n_b, device=self.device)
-            rows = ty * tx
-            n_patches = (self.n_b + rows - 1) // rows
-            patch_of_entry = slot_of_row[entry_row] // rows
-            key = patch_of_entry * self.n_a + col64
-            uniq, inverse = torch.unique(key, sorted=True,
-                                         return_inverse=True)
-            upatch = uniq // self.n_a
-            counts = torch.bincount(upatch, minlength=n_patches)
-            umax = int(counts.max())
-            # entries staged next to the rows: 12 B each (+16 B per row)
-            epp = torch.zeros(n_patches, dtype=torch.int64,
-                              device=self.device)
-            epp.index_add_(0, slot_of_row // rows, lens)
-            footprint = (umax + 1) * row_bytes + int(epp.max()) * 12 + \
-                rows * 16 + 32
-            if footprint <= lds_budget:
-                break
-            if rows == 1:
-                self.patches = None
-                return None
-            if tx >= ty and tx > 1:
-                tx //= 2
-            else:
-                ty //= 2
-        ptr = torch.zeros(n_patches + 1, dtype=torch.int64,
-                          device=self.device)
-        ptr[1:] = torch.cumsum(counts, 0)
-        lidx = (inverse - ptr[patch_of_entry]).to(torch.int32)
-        # the weights again in slot order (patch-major CSR)
-        rows_by_slot = order.to(torch.int64) if order is not None else \
-            torch.arange(self.n_b, device=self.device)
-        lens_by_slot = lens[rows_by_slot]
-        prow = torch.zeros(self.n_b + 1, dtype=torch.int64,
-                           device=self.device)
-        prow[1:] = torch.cumsum(lens_by_slot, 0)
-        shift = self.rowptr[:-1][rows_by_slot] - prow[:-1]
-        src = torch.repeat_interleave(shift, lens_by_slot) + \
-            torch.arange(self.nnz, device=self.device)
-        per_patch = prow[torch.arange(0, n_patches * rows + 1, rows,
-                                      device=self.device).clamp(
-                                          max=self.n_b)]
-        emax = int((per_patch[1:] - per_patch[:-1]).max())
+        two_d = grid_dims is not None and len(grid_dims) == 2
+        dims = None
+        if two_d:
+            my, mx = (int(d) for d in grid_dims)
+            if my * mx != self.n_b_global:
+                raise ValueError(f'grid {grid_dims} does not hold '
+                                 f'{self.n_b_global} cells')
+            dims = (ctypes.c_int64 * 2)(my, mx)
+        csr = self._csr_struct()
+        with torch.cuda.device(dev):
+            nbytes = ctypes.c_size_t(0)
+            _check(lib.remap_patches_workspace(self.n_b, self.nnz,
+                                               ctypes.byref(nbytes)),
+                   'remap_patches_workspace')
+            ws = torch.empty(max(int(nbytes.value), 1), dtype=torch.uint8,
+                             device=dev)
+            ucol = torch.empty(self.nnz, dtype=torch.int32, device=dev)
+            prow = torch.empty(self.n_b + 1, dtype=torch.int32, device=dev)
+            lidx = torch.empty(self.nnz, dtype=torch.int32, device=dev)
+            pval = torch.empty(self.nnz, dtype=torch.float64, device=dev)
+            order = torch.empty(self.n_b, dtype=torch.int32, device=dev) \
+                if two_d else None
+            stats = torch.zeros(3, dtype=torch.int64, device=dev)
+            while True:
+                rows = ty * tx
+                n_patches = (self.n_b + rows - 1) // rows
+                ptr = torch.empty(n_patches + 1, dtype=torch.int32,
+                                  device=dev)
+                _check(lib.remap_patches_build(
+                    ctypes.byref(csr), dims, self.row_offset, ty, tx,
+                    _ptr(order), _ptr(ptr), _ptr(ucol), _ptr(prow),
+                    _ptr(lidx), _ptr(pval), _ptr(stats), _ptr(ws),
+                    ws.numel(), _stream_ptr(dev)), 'remap_patches_build')
+                distinct, umax, emax = (int(v) for v in stats.cpu())
+                # entries staged next to the rows: 12 B each (+16 B per row)
+                footprint = (umax + 1) * row_bytes + emax * 12 + \
+                    rows * 16 + 32
+                if footprint <= lds_budget:
+                    break
+                if rows == 1:
+                    self.patches = None
+                    self.row_order = None
+                    return None
+                if tx >= ty and tx > 1:
+                    tx //= 2
+                else:
+                    ty //= 2
+        self.row_order = order
         self.patches = dict(
-            ptr=ptr.to(torch.int32).contiguous(),
-            ucol=(uniq % self.n_a).to(torch.int32).contiguous(),
-            rowptr=prow.to(torch.int32).contiguous(),
-            lidx=lidx[src].contiguous(), val=self.val[src].contiguous(),
-            rows=rows, umax=umax, emax=emax, n=n_patches, order=order,
-            tile=(ty, tx), distinct=int(uniq.shape[0]),
+            ptr=ptr, ucol=ucol[:max(distinct, 1)].clone(), rowptr=prow,
+            lidx=lidx, val=pval, rows=rows, umax=umax, emax=emax,
+            n=n_patches, order=order, tile=(ty, tx), distinct=distinct,
             row_bytes=int(row_bytes))
-        return uniq.shape[0] / self.nnz
+        return distinct / self.nnz
 
     GROUP = 8   # default rows per group (remap_apply_args.group_rows)
 
@@ -575,12 +583,7 @@ class RemapPlan:
         order = torch.empty(self.n_b, dtype=torch.int32, device=dev) \
             if two_d else None
         n_union = torch.zeros(1, dtype=torch.int64, device=dev)
-        csr = _CSR()
-        csr.n_rows, csr.n_cols, csr.nnz = self.n_b, self.n_a, self.nnz
-        csr.rowptr = self.rowptr.data_ptr()
-        csr.col = self.col.data_ptr()
-        csr.val = self.val.data_ptr()
-        csr.max_row_nnz, csr.csr_pad = self.max_row_nnz, self.csr_pad
+        csr = self._csr_struct()
         with torch.cuda.device(dev):
             nbytes = ctypes.c_size_t(0)
             _check(lib.remap_groups_workspace(self.n_b, self.nnz,

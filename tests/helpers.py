@@ -64,7 +64,7 @@ def reference_group_schedule(plan, grid_dims=None, super_tile=32, rows=8):
     """
     The row-group schedule of kernel family 10 written out with plain torch
     operations on the host's view of the CSR -- an independent restatement of
-    what ``remap_groups_build`` (csrc/remap_groups.hip) produces on the
+    what ``remap_groups_build`` (csrc/remap_schedule.hip) produces on the
     device: ``(meta, col, mask, w, rid, frac, order, n_union)``.
     """
     import torch
@@ -114,3 +114,58 @@ def reference_group_schedule(plan, grid_dims=None, super_tile=32, rows=8):
         plan.n_b, device=dev, dtype=torch.int32)
     frac = plan.frac_b[rid.to(torch.int64)]
     return meta, col, mask, w, rid, frac, order, nu
+
+
+def reference_patch_plan(plan, grid_dims, tile, rows_hint=None):
+    """
+    The LDS patch plan of kernel family 5 for a FIXED tile, written out with
+    plain torch operations -- an independent restatement of what
+    ``remap_patches_build`` (csrc/remap_schedule.hip) produces on the device:
+    ``(ptr, ucol, rowptr, lidx, val, order, distinct, umax, emax)``.
+    """
+    import torch
+    dev = plan.device
+    ty, tx = (int(t) for t in tile)
+    lens = plan.rowptr[1:] - plan.rowptr[:-1]
+    entry_row = torch.repeat_interleave(
+        torch.arange(plan.n_b, device=dev), lens)
+    col64 = plan.col.to(torch.int64)
+    if grid_dims is not None and len(grid_dims) == 2:
+        my, mx = (int(d) for d in grid_dims)
+        r = torch.arange(plan.row_offset, plan.row_offset + plan.n_b,
+                         device=dev, dtype=torch.int64)
+        jy = r // mx
+        jx = r - jy * mx
+        ntx = (mx + tx - 1) // tx
+        key = ((jy // ty) * ntx + jx // tx) * (ty * tx) + \
+            (jy % ty) * tx + jx % tx
+        order = torch.argsort(key, stable=True).to(torch.int32)
+        slot_of_row = torch.empty(plan.n_b, dtype=torch.int64, device=dev)
+        slot_of_row[order.to(torch.int64)] = torch.arange(plan.n_b,
+                                                          device=dev)
+    else:
+        order = None
+        slot_of_row = torch.arange(plan.n_b, device=dev)
+    rows = ty * tx
+    n_patches = (plan.n_b + rows - 1) // rows
+    patch_of_entry = slot_of_row[entry_row] // rows
+    key = patch_of_entry * plan.n_a + col64
+    uniq, inverse = torch.unique(key, sorted=True, return_inverse=True)
+    counts = torch.bincount(uniq // plan.n_a, minlength=n_patches)
+    ptr = torch.zeros(n_patches + 1, dtype=torch.int64, device=dev)
+    ptr[1:] = torch.cumsum(counts, 0)
+    lidx = (inverse - ptr[patch_of_entry]).to(torch.int32)
+    rows_by_slot = order.to(torch.int64) if order is not None else \
+        torch.arange(plan.n_b, device=dev)
+    lens_by_slot = lens[rows_by_slot]
+    prow = torch.zeros(plan.n_b + 1, dtype=torch.int64, device=dev)
+    prow[1:] = torch.cumsum(lens_by_slot, 0)
+    shift = plan.rowptr[:-1][rows_by_slot] - prow[:-1]
+    src = torch.repeat_interleave(shift, lens_by_slot) + \
+        torch.arange(plan.nnz, device=dev)
+    per_patch = prow[torch.arange(0, n_patches * rows + 1, rows,
+                                  device=dev).clamp(max=plan.n_b)]
+    return (ptr.to(torch.int32), (uniq % plan.n_a).to(torch.int32),
+            prow.to(torch.int32), lidx[src], plan.val[src], order,
+            int(uniq.shape[0]), int(counts.max()),
+            int((per_patch[1:] - per_patch[:-1]).max()))

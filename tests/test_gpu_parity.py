@@ -1495,3 +1495,46 @@ def test_integration_stub_runs_on_the_c_abi_alone(dev):
                 False, 0.0)
     assert torch.equal(torch.nan_to_num(plain, nan=1e300),
                        torch.nan_to_num(Y2, nan=1e300))
+
+
+@pytest.mark.parametrize('case', ['2d', '1d', 'shard', 'bilinear'])
+def test_patch_plan_builder_matches_restatement(dev, case):
+    """remap_patches_build (device builder of the LDS patch plan) against a
+    plain-torch restatement: every array and statistic identical."""
+    from helpers import reference_patch_plan
+    from pyremap_amd import engine, synthetic
+    if case == 'bilinear':
+        m = synthetic.bilinear_map((17, 23), (61, 90), seed=2)
+    else:
+        m = synthetic.conservative_map(2500, (37, 50), 1, 7, seed=32)
+    mm = m.numpy()
+    plan = engine.RemapPlan.from_triplets(mm['row'], mm['col'], mm['S'],
+                                          mm['frac_b'], m.n_a, m.n_b,
+                                          device=dev)
+    dims, tile = m.dst_dims, (4, 8)
+    if case == '1d':
+        dims, tile = None, (1, 32)
+    elif case == 'shard':
+        plan = plan.row_slice(211, 1403)
+    ratio = plan.build_patches(dims, tile=tile, lds_budget=150 * 1024)
+    p = plan.patches
+    assert p['tile'] == tile          # fits as asked: same tile both sides
+    ptr, ucol, prow, lidx, val, order, distinct, umax, emax = \
+        reference_patch_plan(plan, dims, tile)
+    assert (p['distinct'], p['umax'], p['emax']) == (distinct, umax, emax)
+    assert abs(ratio - distinct / plan.nnz) < 1e-15
+    assert torch.equal(p['ptr'], ptr)
+    assert torch.equal(p['ucol'], ucol)
+    assert torch.equal(p['rowptr'], prow)
+    assert torch.equal(p['lidx'], lidx)
+    assert torch.equal(p['val'], val)
+    if order is None:
+        assert plan.row_order is None
+    else:
+        assert torch.equal(plan.row_order, order)
+    # a budget that forces smaller tiles still yields a consistent plan
+    plan.build_patches(dims, tile=tile, lds_budget=24 * 1024)
+    q = plan.patches
+    if q is not None:
+        ref = reference_patch_plan(plan, dims, q['tile'])
+        assert torch.equal(q['lidx'], ref[3]) and q['umax'] == ref[7]
