@@ -601,7 +601,9 @@ def measure_extras(ready, args, dist, extra):
             extra[tag] = {k: r[k] for k in EXTRA_KEYS}
             extra[tag]['steps'] = steps
             extra[tag]['frac_of_peak'] = r['achieved_GBps'] / HBM_PEAK_GBPS
-            traffic, _ = load_traffic(w.name, w.K, w.mode)
+            # (the committed counter traffic is that of the (n_a, K) layout)
+            traffic, _ = load_traffic(w.name, w.K, w.mode) \
+                if w.layout == 'nk' else (None, None)
             extra[tag]['traffic'] = traffic
         except Exception as exc:  # noqa: BLE001
             extra[tag] = {'error': f'{type(exc).__name__}: {exc}'}
