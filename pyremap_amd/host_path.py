@@ -19,8 +19,10 @@ What this module is about is everything AROUND the 0.4 ms kernel:
 * nothing blocks until the caller asks for the data: a Dataset's variables
   are all enqueued before the first result is awaited.
 """
+import os
 import queue
 import threading
+import weakref
 
 import numpy as np
 
@@ -30,7 +32,38 @@ from pyremap_amd import engine
 #: enough that the first download starts early)
 CHUNK_BYTES = 64 << 20
 
+#: Results are handed out in PINNED host memory (page-locked: a resource the
+#: OS does not swap).  At most this many bytes of results may be alive at a
+#: time in pinned memory; beyond it a result lands in ordinary pageable
+#: memory (slower: first-touch page faults) rather than pinning without
+#: bound.  Environment: PYREMAP_AMD_PINNED_LIMIT (bytes).
+PINNED_LIMIT = int(os.environ.get('PYREMAP_AMD_PINNED_LIMIT', 16 << 30))
+
 _streams = {}
+_pinned_alive = [0]
+_pinned_lock = threading.Lock()
+
+
+def _host_buffer(shape, dtype):
+    """A result buffer: pinned while the budget lasts, pageable beyond."""
+    torch = engine._torch()
+    nbytes = _prod(shape) * torch.empty((), dtype=dtype).element_size()
+    with _pinned_lock:
+        pin = _pinned_alive[0] + nbytes <= PINNED_LIMIT
+        if pin:
+            _pinned_alive[0] += nbytes
+    return torch.empty(shape, dtype=dtype, pin_memory=pin), \
+        (nbytes if pin else 0)
+
+
+def _release_pinned(nbytes):
+    with _pinned_lock:
+        _pinned_alive[0] -= nbytes
+
+
+def pinned_bytes_alive():
+    """Bytes of results currently alive in pinned host memory."""
+    return _pinned_alive[0]
 
 
 def _side_streams(device):
@@ -69,20 +102,32 @@ class Pending:
     torch's pool when they are garbage collected.
     """
 
-    def __init__(self, event, out, mask, fix=None):
+    def __init__(self, event, out, mask, pinned=(0, 0)):
         self._event = event
         self._out = out
         self._mask = mask
-        self._fix = fix
+        self._pinned = list(pinned)    # pinned bytes of (out, mask)
+        self._done = None
+        # a Pending dropped without result() gives its budget back
+        self._guard = weakref.finalize(self, _release_pinned, sum(pinned))
 
     def result(self):
+        if self._done is not None:
+            return self._done
         if self._event is not None:
             self._event.synchronize()
             self._event = None
+        # the budget now follows the ARRAYS (views keep their base alive)
+        self._guard.detach()
         data = self._out.numpy()
+        weakref.finalize(data, _release_pinned, self._pinned[0])
         if self._mask is None:
+            self._done = data
             return data
-        return data, self._mask.numpy().view(np.bool_)
+        mask = self._mask.numpy()
+        weakref.finalize(mask, _release_pinned, self._pinned[1])
+        self._done = (data, mask.view(np.bool_))
+        return self._done
 
 
 def remap_host_array(plan, dst_grid_dims, values, remap_axes, *, mode,
@@ -122,9 +167,9 @@ def remap_host_array(plan, dst_grid_dims, values, remap_axes, *, mode,
         list(values.shape[lead + len(remap_axes):])
 
     with torch.cuda.device(device):
-        out_h = torch.empty(out_shape, dtype=torch.float64, pin_memory=True)
-        mask_h = torch.empty(out_shape, dtype=torch.uint8, pin_memory=True) \
-            if want_mask else None
+        out_h, pin_o = _host_buffer(out_shape, torch.float64)
+        mask_h, pin_m = _host_buffer(out_shape, torch.uint8) \
+            if want_mask else (None, 0)
         x_d = torch.empty(values.shape, dtype=host.dtype, device=device)
 
         if not in_place or host_mask is not None or mode == 'auto' or \
@@ -182,7 +227,7 @@ def remap_host_array(plan, dst_grid_dims, values, remap_axes, *, mode,
             y_d.record_stream(down)
             if m_out is not None:
                 m_out.record_stream(down)
-            return Pending(finished, out_h, mask_h)
+            return Pending(finished, out_h, mask_h, (pin_o, pin_m))
 
         # ---- pipelined: batches of leading dims, three streams ------------
         emode = engine.MODE_MASKED if mode == 'masked' else engine.MODE_FRACB
@@ -253,4 +298,4 @@ def remap_host_array(plan, dst_grid_dims, values, remap_axes, *, mode,
         if m_d is not None:
             m_d.record_stream(down)
         del lead_shape
-        return Pending(finished, out_h, mask_h)
+        return Pending(finished, out_h, mask_h, (pin_o, pin_m))

@@ -1383,6 +1383,39 @@ def test_host_arrays_pinned_pipelined_and_poisoned(dev):
                 assert np.array_equal(got[1], np.ma.getmaskarray(ref))
     finally:
         host_path.CHUNK_BYTES = old
+    # pinned results are budgeted: what is alive is accounted for, given back
+    # when the arrays die, and beyond the budget results are pageable
+    import gc
+    del got, data
+    gc.collect()
+    base = host_path.pinned_bytes_alive()
+    got = host_path.remap_host_array(plan, m.dst_dims, x, [1],
+                                     mode='fracb').result()
+    assert host_path.pinned_bytes_alive() == base + got.nbytes
+    view = got[1:3]
+    del got
+    gc.collect()
+    assert host_path.pinned_bytes_alive() == base + view.base.nbytes
+    del view
+    gc.collect()
+    assert host_path.pinned_bytes_alive() == base
+    dropped = host_path.remap_host_array(plan, m.dst_dims, x, [1],
+                                         mode='fracb')
+    del dropped                      # never awaited: budget returned too
+    gc.collect()
+    torch.cuda.synchronize()
+    assert host_path.pinned_bytes_alive() == base
+    old_limit = host_path.PINNED_LIMIT
+    host_path.PINNED_LIMIT = 0
+    try:
+        ref = oracle.remap_numpy_array(csr, mm['frac_b'], m.dst_dims, x, [1],
+                                       None)
+        got = host_path.remap_host_array(plan, m.dst_dims, x, [1],
+                                         mode='fracb').result()
+        assert host_path.pinned_bytes_alive() == base
+        assert_bitwise(got, np.ma.filled(ref, np.nan), 'pageable result')
+    finally:
+        host_path.PINNED_LIMIT = old_limit
     # MaskedArray with an unmasked NaN in its data
     field = rng.standard_normal((m.n_a, 12))
     mask = rng.random((m.n_a, 12)) < 0.2
