@@ -187,7 +187,8 @@ def time_steps(launch, steps, warmup, dist):
     return wall, mean_ms, per_launch
 
 
-def make_fields(n_a, K, layout, sets, seed, device, nan_frac=0.0):
+def make_fields(n_a, K, layout, sets, seed, device, nan_frac=0.0,
+                dtype='f64'):
     import torch
     g = torch.Generator(device=device)
     g.manual_seed(seed)
@@ -201,6 +202,8 @@ def make_fields(n_a, K, layout, sets, seed, device, nan_frac=0.0):
             shape, cell_axis = (8, n_a, K // 8), 1
         x = torch.randn(shape, generator=g, device=device,
                         dtype=torch.float64)
+        if dtype == 'f32':
+            x = x.to(torch.float32)
         if nan_frac:
             # whole source cells missing in every field (land / ice shelf)
             dead = torch.rand(n_a, generator=g, device=device) < nan_frac
@@ -214,7 +217,7 @@ class Workload:
 
 
 def prepare(name, args, rank, world, dist, K=None, mode=None, layout=None,
-            sets=None):
+            sets=None, dtype='f64'):
     """Build plan + fields + output buffers for one workload."""
     import torch
 
@@ -255,8 +258,10 @@ def prepare(name, args, rank, world, dist, K=None, mode=None, layout=None,
         w.schedule = {'family': 'explicit tune', 'tune': args.tune}
     torch.cuda.synchronize()
     w.plan_s = time.perf_counter() - t0
+    w.dtype = dtype
     w.fields = make_fields(m.n_a, w.K_local, w.layout, w.sets, 1234, device,
-                           nan_frac=0.25 if w.mode == 'masked' else 0.0)
+                           nan_frac=0.25 if w.mode == 'masked' else 0.0,
+                           dtype=dtype)
     w.exchange = None
     if w.sharded:
         w.exchange = time_exchange(w, dist)
@@ -374,7 +379,8 @@ def measure(w, args, dist, steps=None, warmup=None):
     m, plan = w.m, w.plan
     # algorithmic bytes of ONE launch on this rank; only
     # source rows some entry references count towards X
-    bytes_alg = plan.algorithmic_bytes(w.K_local, 8, w.emode)
+    bytes_alg = plan.algorithmic_bytes(w.K_local,
+                                       4 if w.dtype == 'f32' else 8, w.emode)
     return dict(
         name=w.name, title=w.title, n_a=m.n_a, n_b=m.n_b,
         n_s_file=m.n_s, nnz_csr=w.full.nnz, K=w.K, mode=w.mode,
@@ -553,6 +559,7 @@ def extras_todo(args, world):
             ('K1_one_2d_field', dict(name='config3', K=1), 50),
             ('K12_monthly_time_nCells', dict(name='config3', K=12,
                                              layout='tn'), 50),
+            ('f32_fields', dict(name='config3', dtype='f32'), 50),
             ('layout_T8_nCells_L64', dict(name='config3', layout='tnl'), 50),
             ('masked_renormalised', dict(name='config3', mode='masked'), 50),
         ]
@@ -603,7 +610,7 @@ def measure_extras(ready, args, dist, extra):
             extra[tag]['frac_of_peak'] = r['achieved_GBps'] / HBM_PEAK_GBPS
             # (the committed counter traffic is that of the (n_a, K) layout)
             traffic, _ = load_traffic(w.name, w.K, w.mode) \
-                if w.layout == 'nk' else (None, None)
+                if w.layout == 'nk' and w.dtype == 'f64' else (None, None)
             extra[tag]['traffic'] = traffic
         except Exception as exc:  # noqa: BLE001
             extra[tag] = {'error': f'{type(exc).__name__}: {exc}'}
