@@ -264,6 +264,8 @@ class RemapPlan:
         self.max_row_nnz = int((rowptr[1:] - rowptr[:-1]).max()) \
             if self.n_b > 0 else 0
         self._touched = None
+        self._row_last_col = None
+        self._extent_cache = {}
         #: launch tuning used when a call passes none (set by auto_schedule)
         self.default_tune = None
         #: optional LDS-staging schedule (see build_patches)
@@ -698,6 +700,37 @@ class RemapPlan:
         return {'family': 'rowscalar', 'reason': 'little source-row reuse'}
 
     # -- accounting ---------------------------------------------------------
+    def block_source_extent(self, rows_per_block):
+        """
+        For consecutive blocks of ``rows_per_block`` destination rows: one
+        past the LAST source row any of the block's entries references, as a
+        running maximum over the blocks (a list, one value per block).  A
+        block can be computed once that many source rows are resident.
+        Cached: the per-row maxima once per plan, the block values per size.
+        """
+        torch = _torch()
+        rows_per_block = int(rows_per_block)
+        if rows_per_block in self._extent_cache:
+            return self._extent_cache[rows_per_block]
+        if self._row_last_col is None:
+            last = torch.zeros(self.n_b, dtype=torch.int64,
+                               device=self.device)
+            if self.nnz:
+                # columns ascend within a row: the last entry is the largest
+                lens = self.rowptr[1:] - self.rowptr[:-1]
+                has = lens > 0
+                last[has] = self.col[(self.rowptr[1:][has] - 1)].to(
+                    torch.int64) + 1
+            self._row_last_col = last
+        n_blocks = (self.n_b + rows_per_block - 1) // rows_per_block
+        padded = torch.zeros(n_blocks * rows_per_block, dtype=torch.int64,
+                             device=self.device)
+        padded[:self.n_b] = self._row_last_col
+        hi = padded.reshape(n_blocks, rows_per_block).amax(dim=1)
+        out = torch.cummax(hi, 0).values.cpu().tolist()
+        self._extent_cache[rows_per_block] = out
+        return out
+
     def touched_sources(self):
         """Number of DISTINCT source cells this plan's rows reference."""
         if self._touched is None:

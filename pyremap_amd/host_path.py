@@ -172,6 +172,14 @@ def remap_host_array(plan, dst_grid_dims, values, remap_axes, *, mode,
             if want_mask else (None, 0)
         x_d = torch.empty(values.shape, dtype=host.dtype, device=device)
 
+        banded = in_place and host_mask is None and mode != 'auto' and \
+            n_batch == 1 and lead == 0 and \
+            values.nbytes >= 4 * CHUNK_BYTES and plan.n_b == plan.n_b_global
+        if banded:
+            done = _banded_pipeline(plan, values, host, x_d, out_h, mask_h,
+                                    mode, thr, flags, up, down, main)
+            if done is not None:
+                return Pending(done, out_h, mask_h, (pin_o, pin_m))
         if not in_place or host_mask is not None or mode == 'auto' or \
                 n_batch < 2:
             # ---- one upload, one launch, one download -----------------
@@ -299,3 +307,86 @@ def remap_host_array(plan, dst_grid_dims, values, remap_axes, *, mode,
             m_d.record_stream(down)
         del lead_shape
         return Pending(finished, out_h, mask_h, (pin_o, pin_m))
+
+
+def _banded_pipeline(plan, values, host, x_d, out_h, mask_h, mode, thr,
+                     flags, up, down, main):
+    """
+    A field whose source axes lead -- ``(n_a, K)``, rows contiguous on both
+    sides -- with the mode known: X goes up in row chunks, and a block of
+    destination rows is launched as soon as the last source row IT references
+    has arrived (on a mapping whose destination order follows the source
+    mesh that is a band moving through X), its rows going down while later
+    chunks still come up.  Both PCIe directions stay busy; every copy is
+    contiguous.  Mappings without that locality simply wait for the whole
+    upload first (no loss against the plain form).  Returns the event that
+    marks the last download, or ``None`` to decline.
+    """
+    torch = engine._torch()
+    device = plan.device
+    n_a, n_b = plan.n_a, plan.n_b
+    K = values.size // n_a
+    if K < 33:
+        return None        # the wave-per-row kernels serve partial row ranges
+    xh = host.reshape(n_a, K)
+    xd = x_d.reshape(n_a, K)
+    yh = out_h.reshape(n_b, K)
+    mh = mask_h.reshape(n_b, K) if mask_h is not None else None
+    y_d = torch.empty((n_b, K), dtype=torch.float64, device=device)
+    m_d = torch.empty((n_b, K), dtype=torch.uint8, device=device) \
+        if mh is not None else None
+    rows_up = max(1, CHUNK_BYTES // (K * xh.element_size()))
+    rows_dn = max(1, CHUNK_BYTES // (K * 8))
+    ups = [(a, min(a + rows_up, n_a)) for a in range(0, n_a, rows_up)]
+    dns = [(r, min(r + rows_dn, n_b)) for r in range(0, n_b, rows_dn)]
+    # last source row each destination block needs (one small readback)
+    need = plan.block_source_extent(rows_dn)
+    emode = engine.MODE_MASKED if mode == 'masked' else engine.MODE_FRACB
+    start = torch.cuda.Event()
+    start.record(main)
+    up.wait_event(start)
+    arrivals = queue.Queue()
+
+    def uploader():
+        try:
+            with torch.cuda.device(device), torch.cuda.stream(up):
+                for a, b in ups:
+                    xd[a:b].copy_(xh[a:b], non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(up)
+                    arrivals.put((b, ev))
+        except BaseException as exc:   # noqa: BLE001 - handed over
+            arrivals.put(exc)
+
+    feeder = threading.Thread(target=uploader, daemon=True)
+    feeder.start()
+    have = 0
+    finished = None
+    for (r0, r1), hi in zip(dns, need):
+        while have < hi:
+            got = arrivals.get()
+            if isinstance(got, BaseException):
+                feeder.join()
+                raise got
+            have, ev = got
+            main.wait_event(ev)
+        engine.apply_strided(
+            plan, xd, y_d, n_batch=1, k_inner=K, x_row_stride=K,
+            x_batch_stride=0, y_row_stride=K, y_batch_stride=0, mode=emode,
+            threshold=thr if emode == engine.MODE_MASKED else 0.0,
+            mask_out=m_d, flags=flags, row_begin=r0, row_end=r1)
+        computed = torch.cuda.Event()
+        computed.record(main)
+        with torch.cuda.stream(down):
+            down.wait_event(computed)
+            yh[r0:r1].copy_(y_d[r0:r1], non_blocking=True)
+            if mh is not None:
+                mh[r0:r1].copy_(m_d[r0:r1], non_blocking=True)
+            finished = torch.cuda.Event()
+            finished.record(down)
+    feeder.join()
+    x_d.record_stream(up)
+    y_d.record_stream(down)
+    if m_d is not None:
+        m_d.record_stream(down)
+    return finished

@@ -1383,6 +1383,38 @@ def test_host_arrays_pinned_pipelined_and_poisoned(dev):
                 assert np.array_equal(got[1], np.ma.getmaskarray(ref))
     finally:
         host_path.CHUNK_BYTES = old
+    # (n_a, K) fields: destination row blocks launched as their band of
+    # source rows arrives, downloads under the remaining uploads
+    flat = rng.standard_normal((m.n_a, 70))
+    flat_holed = flat.copy()
+    flat_holed[rng.random(m.n_a) < 0.2, 5:] = np.nan
+    host_path.CHUNK_BYTES = 96 * 1024
+    calls = []
+    real_banded = host_path._banded_pipeline
+
+    def spy(*a, **k):
+        out = real_banded(*a, **k)
+        calls.append(out is not None)
+        return out
+    host_path._banded_pipeline = spy
+    try:
+        for field, mode, thr in ((flat, 'fracb', None),
+                                 (flat_holed, 'masked', 0.2),
+                                 (flat.astype(np.float32), 'fracb', None)):
+            arg = np.ma.masked_array(field, np.isnan(field)) \
+                if mode == 'masked' else field
+            ref = oracle.remap_numpy_array(csr, mm['frac_b'], m.dst_dims,
+                                           arg, [0], thr)
+            data, got_mask = host_path.remap_host_array(
+                plan, m.dst_dims, field, [0], mode=mode, threshold=thr,
+                want_mask=True).result()
+            assert_bitwise(data, np.ma.filled(ref, np.nan),
+                           f'banded {mode} {field.dtype}')
+            assert np.array_equal(got_mask, np.ma.getmaskarray(ref))
+        assert calls == [True, True, True]
+    finally:
+        host_path.CHUNK_BYTES = old
+        host_path._banded_pipeline = real_banded
     # pinned results are budgeted: what is alive is accounted for, given back
     # when the arrays die, and beyond the budget results are pageable
     import gc
