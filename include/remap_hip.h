@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define REMAP_ABI_VERSION 15
+#define REMAP_ABI_VERSION 16
 
 enum {
     REMAP_OK = 0,
@@ -321,6 +321,65 @@ int remap_patches_build(const remap_csr *A, const int64_t *grid_dims,
                         int32_t *patch_lidx, double *patch_val,
                         int64_t *stats_out, void *workspace,
                         size_t workspace_bytes, void *stream);
+
+/*
+ * WHICH schedule a mapping gets -- decided (from the measurements recorded in
+ * DESIGN.md section 6) and built in one call.  The schedule's arrays live in
+ * ONE device arena the caller provides and keeps alive as long as the
+ * schedule is used; the struct returns the ready-to-copy fields of
+ * remap_apply_args.  Synchronous on `stream` (statistics are read back to
+ * choose).  Query both sizes first with remap_schedule_sizes().
+ *
+ *   family  0: nothing to attach (no destination grid, empty matrix, or no
+ *              source-row sharing to exploit)
+ *           5: LDS patches   -> row_order, patch_*   (bilinear, coarse->fine)
+ *          10: row groups    -> row_order, group_*   (conservative maps)
+ *           6: plain kernels in a tiled processing order -> row_order only
+ *   tune[mode]: what to pass as remap_apply_args.tune for REMAP_MODE_<mode>,
+ *              together with REMAP_FLAG_TUNE_HINT (a call the family cannot
+ *              serve then falls back by itself)
+ *   grid_dims  (HOST) the C-order dims of the WHOLE destination grid, n_dims
+ *              = 1 or 2 (0: no grid, nothing is scheduled); row_offset = the
+ *              index of A's first row in it (0 unless A is a row shard)
+ */
+typedef struct remap_schedule {
+    int32_t family;
+    int32_t entry_rich;          /* >= 10 entries per non-empty row          */
+    const int32_t *row_order;    /* (device, arena) or NULL                  */
+    const int32_t *patch_ptr;
+    const int32_t *patch_ucol;
+    const int32_t *patch_rowptr;
+    const int32_t *patch_lidx;
+    const double *patch_val;
+    int32_t patch_rows;
+    int32_t patch_umax;
+    int32_t patch_emax;
+    int32_t patch_row_bytes;
+    int64_t n_patches;
+    const int64_t *group_meta;
+    const int32_t *group_col;
+    const double *group_w;
+    const int32_t *group_mask;
+    const int32_t *group_rid;
+    const double *group_frac;
+    int64_t n_groups;
+    int32_t group_rows;
+    int32_t super_tile;          /* 0: groups row-major over the whole grid  */
+    int32_t tile_y;              /* patch tile / processing-order tile       */
+    int32_t tile_x;
+    double ratio;                /* distinct/entries (5), union/entries (10) */
+    int64_t n_distinct;          /* distinct pairs (5), union entries (10)   */
+    int32_t tune[3][8];
+    size_t arena_used;           /* bytes of the arena the schedule occupies */
+} remap_schedule;
+
+int remap_schedule_sizes(int64_t n_rows, int64_t nnz, size_t *arena_bytes,
+                         size_t *workspace_bytes);
+int remap_schedule_auto(const remap_csr *A, const double *frac_b,
+                        const int64_t *grid_dims, int32_t n_dims,
+                        int64_t row_offset, void *arena, size_t arena_bytes,
+                        void *workspace, size_t workspace_bytes,
+                        remap_schedule *schedule_out, void *stream);
 
 /*
  * OR 1 into *flag (device int32, zeroed by the caller) if any of the n

@@ -709,3 +709,320 @@ int remap_patches_build(const remap_csr *A, const int64_t *grid_dims,
 }
 
 }  // extern "C"
+
+// ===========================================================================
+// remap_schedule_auto: WHICH schedule a mapping gets, decided and built in
+// one call.  The rules are measurements:
+//
+//   1. LDS patches pay when neighbouring destination rows share most of
+//      their source rows and rows are short (bilinear, coarse -> fine:
+//      BASELINE config 4, 2.2x): the largest tile of kAutoTiles whose LDS
+//      image fits 100 KB (1 KiB per staged row first, then 512 B), kept if
+//      distinct / entries <= 0.30.  Never for entry-rich rows (>= 10 entries
+//      per non-empty row: the compute phase is LDS-issue-bound there).
+//   2. Else row groups when rows share columns at all (union / entries <=
+//      0.95): 2 x 4 groups inside 32 x 32 supertiles for entry-rich rows,
+//      2 K-tiles x 2 groups per wave (1 K-tile in masked mode); otherwise
+//      2 x 2 groups in row-major order, one group per wave.
+//   3. Else the plain wave-per-row kernel -- in 32 x 32 tile order for
+//      entry-rich rows on a 2-D grid (keeps the stencil band in L2).
+//
+// The schedule's arrays are laid out in ONE caller-provided device arena;
+// the returned struct carries the ready-to-copy remap_apply_args fields.
+// ===========================================================================
+namespace remap {
+namespace {
+
+constexpr int kAutoTiles[8][2] = {{24, 24}, {32, 16}, {24, 16}, {16, 16},
+                                  {8, 16},  {8, 8},   {6, 8},   {4, 8}};
+constexpr int kAutoTiles1D[2][2] = {{1, 256}, {1, 64}};
+constexpr int64_t kAutoLdsBudget = 100 * 1024;
+constexpr double kAutoPatchRatio = 0.30;
+constexpr double kAutoGroupRatio = 0.95;
+
+struct Arena {
+    char *base;
+    size_t size, used;
+    template <typename T>
+    T *take(size_t n)
+    {
+        const size_t bytes = align_g(n * sizeof(T));
+        if (used + bytes > size)
+            return nullptr;
+        T *p = reinterpret_cast<T *>(base + used);
+        used += bytes;
+        return p;
+    }
+};
+
+size_t arena_need(int64_t n_rows, int64_t nnz)
+{
+    const size_t nr = static_cast<size_t>(n_rows), ne = static_cast<size_t>(nnz);
+    const size_t order = align_g(nr * 4);
+    const size_t patch = align_g((nr + 1) * 4) + align_g(ne * 4) +
+                         align_g((nr + 1) * 4) + align_g(ne * 4) +
+                         align_g(ne * 8);
+    const size_t n_groups = nr / 4 + 2;
+    const size_t group = align_g(2 * (n_groups + 1) * 8) +
+                         2 * align_g((ne + 8) * 4) + align_g((ne + 64) * 8) +
+                         align_g(n_groups * 8 * 4) + align_g(n_groups * 8 * 8);
+    return order + (patch > group ? patch : group) + align_g(64);
+}
+
+__global__ __launch_bounds__(kBlock) void count_nonempty(
+    int64_t n_rows, const int64_t *__restrict__ rowptr,
+    unsigned long long *__restrict__ count)
+{
+    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool has = r < n_rows && rowptr[r + 1] > rowptr[r];
+    const unsigned long long b = __builtin_amdgcn_ballot_w64(has);
+    if ((threadIdx.x & (kWave - 1)) == 0 && b)
+        atomicAdd(count, (unsigned long long)__builtin_popcountll(b));
+}
+
+int read_back(void *host, const void *dev, size_t bytes, hipStream_t stream)
+{
+    REMAP_HIP_CHECK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost,
+                                   stream));
+    REMAP_HIP_CHECK(hipStreamSynchronize(stream));
+    return REMAP_OK;
+}
+
+void set_tune(remap_schedule *s, int mode, int family, int vec, int tiles,
+              int per_wave, int map = 0)
+{
+    s->tune[mode][0] = family;
+    s->tune[mode][1] = vec;
+    s->tune[mode][2] = tiles;
+    s->tune[mode][3] = per_wave;
+    s->tune[mode][4] = map;
+}
+
+}  // namespace
+
+int schedule_sizes(int64_t n_rows, int64_t nnz, size_t *arena_bytes,
+                   size_t *workspace_bytes)
+{
+    if (!arena_bytes || !workspace_bytes || n_rows < 0 || nnz < 0)
+        return fail(REMAP_ERR_ARG, "remap_schedule_sizes: bad args");
+    GroupLayout gl;
+    PatchLayout pl;
+    int rc = group_layout(n_rows, nnz, &gl);
+    if (rc != REMAP_OK)
+        return rc;
+    rc = patch_layout(n_rows, nnz, &pl);
+    if (rc != REMAP_OK)
+        return rc;
+    *workspace_bytes = gl.total > pl.total ? gl.total : pl.total;
+    *arena_bytes = arena_need(n_rows > 0 ? n_rows : 1, nnz > 0 ? nnz : 1);
+    return REMAP_OK;
+}
+
+int schedule_auto(const remap_csr *A, const double *frac_b,
+                  const int64_t *grid_dims, int32_t n_dims,
+                  int64_t row_offset, void *arena_ptr, size_t arena_bytes,
+                  void *workspace, size_t workspace_bytes,
+                  remap_schedule *out, hipStream_t stream)
+{
+    if (!A || !out)
+        return fail(REMAP_ERR_ARG, "remap_schedule_auto: NULL argument");
+    memset(out, 0, sizeof(*out));
+    const int64_t n_rows = A->n_rows, nnz = A->nnz;
+    if (n_dims < 0 || n_dims > 2 || (n_dims > 0 && !grid_dims))
+        return fail(REMAP_ERR_ARG, "remap_schedule_auto: bad grid_dims");
+    if (n_dims == 0 || nnz <= 0 || n_rows <= 0)
+        return REMAP_OK;   // no destination grid / nothing to schedule
+    if (!frac_b || !arena_ptr || !workspace)
+        return fail(REMAP_ERR_ARG, "remap_schedule_auto: NULL buffer");
+    if (arena_bytes < arena_need(n_rows, nnz))
+        return fail(REMAP_ERR_WORKSPACE,
+                    "remap_schedule_auto: arena of %zu bytes, need %zu",
+                    arena_bytes, arena_need(n_rows, nnz));
+    const bool two_d = n_dims == 2;
+    const int64_t *dims2 = two_d ? grid_dims : nullptr;
+    Arena arena{static_cast<char *>(arena_ptr), arena_bytes, 0};
+    int64_t *stats = arena.take<int64_t>(8);
+    int32_t *order = arena.take<int32_t>(n_rows);
+    const size_t mark = arena.used;
+
+    // entry-rich?
+    REMAP_HIP_CHECK(hipMemsetAsync(stats, 0, 8 * sizeof(int64_t), stream));
+    hipLaunchKernelGGL(count_nonempty, dim3(blocks_for(n_rows)), dim3(kBlock),
+                       0, stream, n_rows, A->rowptr,
+                       reinterpret_cast<unsigned long long *>(stats + 4));
+    REMAP_HIP_CHECK(hipGetLastError());
+    int64_t nonempty = 0;
+    int rc = read_back(&nonempty, stats + 4, sizeof(int64_t), stream);
+    if (rc != REMAP_OK)
+        return rc;
+    const bool entry_rich =
+        nonempty > 0 && static_cast<double>(nnz) / nonempty >= 10.0;
+    out->entry_rich = entry_rich ? 1 : 0;
+
+    // 1. LDS patches
+    if (!entry_rich) {
+        const int (*tiles)[2] = two_d ? kAutoTiles : kAutoTiles1D;
+        const int n_tiles = two_d ? 8 : 2;
+        for (int row_bytes = 1024; row_bytes >= 512; row_bytes /= 2) {
+            bool fits = false;
+            for (int t = 0; t < n_tiles && !fits; ++t) {
+                const int ty = tiles[t][0], tx = tiles[t][1];
+                const int64_t rows = (int64_t)ty * tx;
+                const int64_t n_patches = (n_rows + rows - 1) / rows;
+                arena.used = mark;
+                int32_t *pptr = arena.take<int32_t>(n_patches + 1);
+                int32_t *ucol = arena.take<int32_t>(nnz);
+                int32_t *prow = arena.take<int32_t>(n_rows + 1);
+                int32_t *lidx = arena.take<int32_t>(nnz);
+                double *pval = arena.take<double>(nnz);
+                if (!pval)
+                    return fail(REMAP_ERR_WORKSPACE,
+                                "remap_schedule_auto: arena too small");
+                rc = patches_build(A, dims2, row_offset, ty, tx,
+                                   two_d ? order : nullptr, pptr, ucol, prow,
+                                   lidx, pval, stats, workspace,
+                                   workspace_bytes, stream);
+                if (rc != REMAP_OK)
+                    return rc;
+                int64_t st3[3];
+                rc = read_back(st3, stats, sizeof(st3), stream);
+                if (rc != REMAP_OK)
+                    return rc;
+                const int64_t footprint = (st3[1] + 1) * row_bytes +
+                                          st3[2] * 12 + rows * 16 + 32;
+                if (footprint > kAutoLdsBudget)
+                    continue;   // does not fit: the next, smaller tile
+                fits = true;
+                const double ratio = static_cast<double>(st3[0]) / nnz;
+                if (ratio <= kAutoPatchRatio) {
+                    out->family = 5;
+                    out->row_order = two_d ? order : nullptr;
+                    out->patch_ptr = pptr;
+                    out->patch_ucol = ucol;
+                    out->patch_rowptr = prow;
+                    out->patch_lidx = lidx;
+                    out->patch_val = pval;
+                    out->patch_rows = static_cast<int32_t>(rows);
+                    out->patch_umax = static_cast<int32_t>(st3[1]);
+                    out->patch_emax = static_cast<int32_t>(st3[2]);
+                    out->patch_row_bytes = row_bytes;
+                    out->n_patches = n_patches;
+                    out->tile_y = ty;
+                    out->tile_x = tx;
+                    out->ratio = ratio;
+                    out->n_distinct = st3[0];
+                    out->arena_used = arena.used;
+                    for (int mode = 0; mode < 3; ++mode)
+                        set_tune(out, mode, 5, 0, 0, 0);
+                    return REMAP_OK;
+                }
+                // fits, too little reuse: smaller tiles share even less
+            }
+            if (fits)
+                break;
+        }
+    }
+
+    // 2. row groups
+    {
+        const int G = entry_rich ? 8 : 4;
+        const int st = entry_rich ? 32 : 0;
+        const int64_t n_groups = (n_rows + G - 1) / G;
+        arena.used = mark;
+        int64_t *meta = arena.take<int64_t>(2 * (n_groups + 1));
+        int32_t *gcol = arena.take<int32_t>(nnz + 8);
+        int32_t *gmask = arena.take<int32_t>(nnz + 8);
+        double *gw = arena.take<double>(nnz + 64);
+        int32_t *rid = arena.take<int32_t>(n_groups * G);
+        double *gfrac = arena.take<double>(n_groups * G);
+        if (!gfrac)
+            return fail(REMAP_ERR_WORKSPACE,
+                        "remap_schedule_auto: arena too small");
+        rc = groups_build(A, frac_b, G, dims2, row_offset, st,
+                          two_d ? order : nullptr, meta, gcol, gmask, gw, rid,
+                          gfrac, stats, workspace, workspace_bytes, stream);
+        if (rc != REMAP_OK)
+            return rc;
+        int64_t n_union = 0;
+        rc = read_back(&n_union, stats, sizeof(int64_t), stream);
+        if (rc != REMAP_OK)
+            return rc;
+        const double ratio = static_cast<double>(n_union) / nnz;
+        if (ratio <= kAutoGroupRatio) {
+            out->family = 10;
+            out->row_order = two_d ? order : nullptr;
+            out->group_meta = meta;
+            out->group_col = gcol;
+            out->group_w = gw;
+            out->group_mask = gmask;
+            out->group_rid = rid;
+            out->group_frac = gfrac;
+            out->n_groups = n_groups;
+            out->group_rows = G;
+            out->super_tile = st;
+            out->ratio = ratio;
+            out->n_distinct = n_union;
+            out->arena_used = arena.used;
+            for (int mode = 0; mode < 3; ++mode) {
+                if (entry_rich)
+                    set_tune(out, mode, 10, 0,
+                             mode == REMAP_MODE_MASKED ? 1 : 2, 2);
+                else
+                    set_tune(out, mode, 10, 0, 0, 1);
+            }
+            return REMAP_OK;
+        }
+    }
+
+    // 3. plain kernels; entry-rich rows on a 2-D grid in 32 x 32 tile order
+    arena.used = mark;
+    if (two_d && entry_rich) {
+        // only the order is wanted: a patch build with 32 x 32 tiles yields
+        // it (its other outputs land in the arena and are abandoned)
+        int32_t *pptr = arena.take<int32_t>(n_rows / 1024 + 2);
+        int32_t *ucol = arena.take<int32_t>(nnz);
+        int32_t *prow = arena.take<int32_t>(n_rows + 1);
+        int32_t *lidx = arena.take<int32_t>(nnz);
+        double *pval = arena.take<double>(nnz);
+        if (!pval)
+            return fail(REMAP_ERR_WORKSPACE,
+                        "remap_schedule_auto: arena too small");
+        rc = patches_build(A, dims2, row_offset, 32, 32, order, pptr, ucol,
+                           prow, lidx, pval, stats, workspace,
+                           workspace_bytes, stream);
+        if (rc != REMAP_OK)
+            return rc;
+        REMAP_HIP_CHECK(hipStreamSynchronize(stream));
+        out->family = 6;
+        out->row_order = order;
+        out->tile_y = out->tile_x = 32;
+        out->arena_used = mark;
+        for (int mode = 0; mode < 3; ++mode)
+            set_tune(out, mode, 6, 0, 2, 4, 2);
+    }
+    return REMAP_OK;
+}
+
+}  // namespace remap
+
+extern "C" {
+
+int remap_schedule_sizes(int64_t n_rows, int64_t nnz, size_t *arena_bytes,
+                         size_t *workspace_bytes)
+{
+    return remap::schedule_sizes(n_rows, nnz, arena_bytes, workspace_bytes);
+}
+
+int remap_schedule_auto(const remap_csr *A, const double *frac_b,
+                        const int64_t *grid_dims, int32_t n_dims,
+                        int64_t row_offset, void *arena, size_t arena_bytes,
+                        void *workspace, size_t workspace_bytes,
+                        remap_schedule *schedule_out, void *stream)
+{
+    return remap::schedule_auto(A, frac_b, grid_dims, n_dims, row_offset,
+                                arena, arena_bytes, workspace,
+                                workspace_bytes, schedule_out,
+                                static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -33,7 +33,7 @@ FLAG_TREE = 8
 DTYPE_F64 = 0
 DTYPE_F32 = 1
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 #: readable pad entries kept behind col/val (remap_csr.csr_pad)
 CSR_PAD = 8
@@ -45,6 +45,7 @@ EXPORTS = (
     'remap_csr_from_coo', 'remap_stream_copy', 'remap_scan_nan',
     'remap_groups_workspace', 'remap_groups_build',
     'remap_patches_workspace', 'remap_patches_build',
+    'remap_schedule_sizes', 'remap_schedule_auto',
 )
 
 
@@ -103,6 +104,39 @@ class _ApplyArgs(ctypes.Structure):
         ('gate_value', ctypes.c_int32),
         ('flags', ctypes.c_uint32),
         ('tune', ctypes.c_int32 * 8),
+    ]
+
+
+class _Schedule(ctypes.Structure):
+    _fields_ = [
+        ('family', ctypes.c_int32),
+        ('entry_rich', ctypes.c_int32),
+        ('row_order', ctypes.c_void_p),
+        ('patch_ptr', ctypes.c_void_p),
+        ('patch_ucol', ctypes.c_void_p),
+        ('patch_rowptr', ctypes.c_void_p),
+        ('patch_lidx', ctypes.c_void_p),
+        ('patch_val', ctypes.c_void_p),
+        ('patch_rows', ctypes.c_int32),
+        ('patch_umax', ctypes.c_int32),
+        ('patch_emax', ctypes.c_int32),
+        ('patch_row_bytes', ctypes.c_int32),
+        ('n_patches', ctypes.c_int64),
+        ('group_meta', ctypes.c_void_p),
+        ('group_col', ctypes.c_void_p),
+        ('group_w', ctypes.c_void_p),
+        ('group_mask', ctypes.c_void_p),
+        ('group_rid', ctypes.c_void_p),
+        ('group_frac', ctypes.c_void_p),
+        ('n_groups', ctypes.c_int64),
+        ('group_rows', ctypes.c_int32),
+        ('super_tile', ctypes.c_int32),
+        ('tile_y', ctypes.c_int32),
+        ('tile_x', ctypes.c_int32),
+        ('ratio', ctypes.c_double),
+        ('n_distinct', ctypes.c_int64),
+        ('tune', (ctypes.c_int32 * 8) * 3),
+        ('arena_used', ctypes.c_size_t),
     ]
 
 
@@ -170,6 +204,16 @@ def load_library():
         ctypes.POINTER(_CSR), ctypes.POINTER(ctypes.c_int64), ctypes.c_int64,
         ctypes.c_int32, ctypes.c_int32] + [ctypes.c_void_p] * 8 + \
         [ctypes.c_size_t, ctypes.c_void_p]
+    lib.remap_schedule_sizes.restype = ctypes.c_int
+    lib.remap_schedule_sizes.argtypes = [
+        ctypes.c_int64, ctypes.c_int64, ctypes.POINTER(ctypes.c_size_t),
+        ctypes.POINTER(ctypes.c_size_t)]
+    lib.remap_schedule_auto.restype = ctypes.c_int
+    lib.remap_schedule_auto.argtypes = [
+        ctypes.POINTER(_CSR), ctypes.c_void_p,
+        ctypes.POINTER(ctypes.c_int64), ctypes.c_int32, ctypes.c_int64,
+        ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
+        ctypes.POINTER(_Schedule), ctypes.c_void_p]
     lib.remap_scan_nan.restype = ctypes.c_int
     lib.remap_scan_nan.argtypes = [ctypes.c_void_p, ctypes.c_int32,
                                    ctypes.c_int64, ctypes.c_void_p,
@@ -264,6 +308,7 @@ class RemapPlan:
         self.max_row_nnz = int((rowptr[1:] - rowptr[:-1]).max()) \
             if self.n_b > 0 else 0
         self._touched = None
+        self._arena = None
         self._row_last_col = None
         self._extent_cache = {}
         #: launch tuning used when a call passes none (set by auto_schedule)
@@ -608,95 +653,123 @@ class RemapPlan:
                            union=nu)
         return nu / self.nnz
 
-    #: tiles tried by auto_schedule, largest first
-    AUTO_TILES = ((24, 24), (32, 16), (24, 16), (16, 16), (8, 16), (8, 8),
-                  (6, 8), (4, 8))
-
-    def auto_schedule(self, grid_dims, max_ratio=0.30,
-                      lds_budget=100 * 1024):
+    def auto_schedule(self, grid_dims):
         """
-        Choose the schedule for this mapping.  The LDS-staged patch family
-        pays when neighbouring destination rows share most of their source
-        rows (bilinear or conservative maps onto a much finer grid: measured
-        2.2x on BASELINE config 4) and merely ties the register-gather kernel
-        otherwise (config 3).  So: build the patch plan with the largest tile
-        whose LDS footprint stays under ``lds_budget`` -- fewer, larger
-        gather phases beat a second resident workgroup: 24 x 24 at one
-        workgroup per CU measured 5.36 ms on config 4, 16 x 24 at two 5.64 ms
-        -- and keep it only if distinct source rows / entries <=
-        ``max_ratio``.  Returns the description of what was chosen.
+        Choose AND build the schedule for this mapping with the library's
+        ``remap_schedule_auto`` (the rules -- LDS patches for heavily shared,
+        short rows; row groups where rows share columns at all; the plain
+        kernel otherwise -- live there, next to the measurements they come
+        from: ``csrc/remap_schedule.hip``).  The
+        schedule's arrays are views into one device arena owned by the plan.
+        Returns the description of what was chosen.
         """
+        torch = _torch()
+        lib = load_library()
         self.patches = None
         self.groups = None
         self.row_order = None
         self.default_tune = None
+        self._arena = None
         if grid_dims is None or self.nnz == 0 or self.n_b == 0:
             return {'family': 'rowscalar', 'reason': 'no destination grid'}
         dims = tuple(int(d) for d in grid_dims)
-        nonempty = int((self.rowptr[1:] > self.rowptr[:-1]).sum())
-        entry_rich = nonempty > 0 and self.nnz / nonempty >= 10.0
-        tiles = self.AUTO_TILES if len(dims) == 2 else ((1, 256), (1, 64))
-        if entry_rich:
-            tiles = ()   # patch compute phase is LDS-issue-bound there:
-            #              measured slower than the tiled register kernel
-        # 1 KiB per staged row first (16-byte lanes in the compute phase);
-        # 512 B lets twice the patch area fit when rows are entry-rich
-        for row_bytes in (1024, 512):
-            fits = False
-            for tile in tiles:
-                ratio = self.build_patches(
-                    dims if len(dims) == 2 else None, tile=tile,
-                    lds_budget=lds_budget, row_bytes=row_bytes)
-                if ratio is None or self.patches['tile'] != tile:
-                    continue  # does not fit as asked: try the next size
-                fits = True
-                if ratio <= max_ratio:
-                    return {'family': 'patch', 'tile': tile, 'ratio': ratio,
-                            'umax': self.patches['umax'],
-                            'row_bytes': row_bytes}
-                break         # fits, too little reuse: smaller is worse
-            if fits:
-                break
-        self.patches = None
-        self.row_order = None
-        # Row groups: G neighbouring rows per wave over the union of their
-        # columns (family 10).  Measured (DESIGN.md section 6):
-        #  * entry-rich rows (>= 10 entries: wide stencils, config 5): 2 x 4
-        #    groups nested in 32 x 32 supertiles so the stencil band stays in
-        #    the XCD's L2, 2 K-tiles x 2 groups per wave (1 K-tile masked);
-        #  * other mappings: 2 x 2 groups in row-major order, one group per
-        #    wave -- config 3: 0.362-0.369 ms in every mode against 0.392
-        #    for the wave-per-row kernel; 2 x 4 groups tie in frac_b mode
-        #    and lose 5 % in the masked mode (their second accumulator set
-        #    costs two waves per SIMD).
-        # Only when rows share columns at all (union / entries <= 0.95).
-        two_d = len(dims) == 2
-        ratio = self.build_groups(dims if two_d else None,
-                                  super_tile=32 if entry_rich else 1 << 30,
-                                  rows=8 if entry_rich else 4)
-        if ratio is not None and ratio <= 0.95:
-            if entry_rich:
-                self.default_tune = {MODE_RAW: [10, 0, 2, 2],
-                                     MODE_FRACB: [10, 0, 2, 2],
-                                     MODE_MASKED: [10, 0, 1, 2]}
-            else:
-                self.default_tune = {MODE_RAW: [10, 0, 0, 1],
-                                     MODE_FRACB: [10, 0, 0, 1],
-                                     MODE_MASKED: [10, 0, 0, 1]}
-            return {'family': 'rowgroup', 'union_ratio': ratio,
-                    'rows_per_group': self.groups['rows'],
-                    'order': '2x4 groups in 32x32 supertiles' if entry_rich
-                    else '2x2 groups, row-major' if two_d else
+        if len(dims) not in (1, 2):
+            return {'family': 'rowscalar',
+                    'reason': f'{len(dims)}-D destination grid'}
+        if _prod(dims) != self.n_b_global:
+            raise ValueError(f'grid {dims} does not hold '
+                             f'{self.n_b_global} cells')
+        dev = self.device
+        sched = _Schedule()
+        csr = self._csr_struct()
+        cdims = (ctypes.c_int64 * len(dims))(*dims)
+        with torch.cuda.device(dev):
+            a_bytes, w_bytes = ctypes.c_size_t(0), ctypes.c_size_t(0)
+            _check(lib.remap_schedule_sizes(
+                self.n_b, self.nnz, ctypes.byref(a_bytes),
+                ctypes.byref(w_bytes)), 'remap_schedule_sizes')
+            arena = torch.empty(int(a_bytes.value), dtype=torch.uint8,
+                                device=dev)
+            ws = torch.empty(max(int(w_bytes.value), 1), dtype=torch.uint8,
+                             device=dev)
+            _check(lib.remap_schedule_auto(
+                ctypes.byref(csr), _ptr(self.frac_b), cdims, len(dims),
+                self.row_offset, _ptr(arena), arena.numel(), _ptr(ws),
+                ws.numel(), ctypes.byref(sched), _stream_ptr(dev)),
+                'remap_schedule_auto')
+            del ws
+            if sched.family in (5, 10) and \
+                    sched.arena_used < arena.numel() // 2:
+                # keep only what the schedule occupies (the arena was sized
+                # for the larger of the two candidate layouts)
+                used = (int(sched.arena_used) + 255) // 256 * 256
+                small = arena[:used].clone()
+                shift = small.data_ptr() - arena.data_ptr()
+                for name, _ in _Schedule._fields_:
+                    v = getattr(sched, name)
+                    if name != 'arena_used' and isinstance(v, int) and \
+                            arena.data_ptr() <= v < arena.data_ptr() + used:
+                        setattr(sched, name, v + shift)
+                arena = small
+        base = arena.data_ptr()
+
+        def view(ptr, count, dtype):
+            if not ptr:
+                return None
+            nbytes = count * torch.empty((), dtype=dtype).element_size()
+            return arena[ptr - base:ptr - base + nbytes].view(dtype)
+
+        self._arena = arena
+        order = view(sched.row_order, self.n_b, torch.int32)
+        tune = {mode: [int(v) for v in sched.tune[mode]][:5]
+                for mode in (MODE_RAW, MODE_FRACB, MODE_MASKED)}
+        if sched.family == 5:
+            self.row_order = order
+            n_p = int(sched.n_patches)
+            self.patches = dict(
+                ptr=view(sched.patch_ptr, n_p + 1, torch.int32),
+                ucol=view(sched.patch_ucol, max(int(sched.n_distinct), 1),
+                          torch.int32),
+                rowptr=view(sched.patch_rowptr, self.n_b + 1, torch.int32),
+                lidx=view(sched.patch_lidx, self.nnz, torch.int32),
+                val=view(sched.patch_val, self.nnz, torch.float64),
+                rows=int(sched.patch_rows), umax=int(sched.patch_umax),
+                emax=int(sched.patch_emax), n=n_p, order=order,
+                tile=(int(sched.tile_y), int(sched.tile_x)),
+                distinct=int(sched.n_distinct),
+                row_bytes=int(sched.patch_row_bytes))
+            return {'family': 'patch', 'tile': self.patches['tile'],
+                    'ratio': float(sched.ratio),
+                    'umax': self.patches['umax'],
+                    'row_bytes': self.patches['row_bytes']}
+        if sched.family == 10:
+            self.row_order = order
+            n_g, G = int(sched.n_groups), int(sched.group_rows)
+            nu = int(sched.n_distinct)
+            self.groups = dict(
+                meta=view(sched.group_meta, 2 * (n_g + 1),
+                          torch.int64).reshape(n_g + 1, 2),
+                col=view(sched.group_col, nu + 8, torch.int32),
+                w=view(sched.group_w, self.nnz + 64, torch.float64),
+                mask=view(sched.group_mask, nu + 8, torch.int32),
+                rid=view(sched.group_rid, n_g * G, torch.int32),
+                frac=view(sched.group_frac, n_g * G, torch.float64),
+                n=n_g, rows=G, order=order, union=nu)
+            self.default_tune = tune
+            rich = bool(sched.entry_rich)
+            return {'family': 'rowgroup', 'union_ratio': float(sched.ratio),
+                    'rows_per_group': G,
+                    'order': '2x4 groups in 32x32 supertiles' if rich
+                    else '2x2 groups, row-major' if len(dims) == 2 else
                     '4 consecutive rows', 'tune': self.default_tune}
-        self.groups = None
-        self.row_order = None
-        if two_d and entry_rich:
-            # no sharing to exploit in registers: still keep the band in L2
-            self.set_grid_schedule(dims, 'tile', (32, 32))
-            self.default_tune = [6, 0, 2, 4, 2]   # vec stays automatic
+        if sched.family == 6:
+            self.row_order = order.clone()
+            self._arena = None
+            self.default_tune = tune[MODE_FRACB]
             return {'family': 'rowscalar', 'order': 'tile 32x32',
                     'tune': self.default_tune,
                     'reason': 'entry-rich rows: keep the stencil band in L2'}
+        self._arena = None
         return {'family': 'rowscalar', 'reason': 'little source-row reuse'}
 
     # -- accounting ---------------------------------------------------------

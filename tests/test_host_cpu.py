@@ -52,6 +52,8 @@ def test_struct_layout_matches_header():
     assert fields('remap_csr') == [f[0] for f in engine._CSR._fields_]
     assert fields('remap_apply_args') == \
         [f[0] for f in engine._ApplyArgs._fields_]
+    assert fields('remap_schedule') == \
+        [f[0] for f in engine._Schedule._fields_]
 
 
 def test_no_gpu_means_loud_failure():
@@ -606,4 +608,8 @@ def test_integration_stub_matches_the_binding():
     block = block[:block.index('def _check')]
     names = re.findall(r"\('(\w+)',", block)
     assert names == [f[0] for f in engine._ApplyArgs._fields_]
+    block = text[text.index('class _Schedule(ctypes.Structure)'):]
+    block = block[:block.index('def build_schedule')]
+    names = re.findall(r"\('(\w+)',", block)
+    assert names == [f[0] for f in engine._Schedule._fields_]
     assert f'remap_abi_version() == {engine.ABI_VERSION}' in text
