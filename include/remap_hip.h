@@ -14,6 +14,17 @@
  *                                   280-295   unflatten/unpermute: absorbed
  *                                             into the batch/row strides of
  *                                             remap_apply_args (no copies)
+ *   pyremap/remapper/remap_numpy.py:201-204   `isnan(values).any()` picks the
+ *                                             masked or the unmasked branch
+ *                                             -> remap_scan_nan() + two calls
+ *                                             gated on its flag
+ *                                             (remap_apply_args.gate)
+ *   (no counterpart in the reference)         which kernel schedule a mapping
+ *                                             gets, and building it on the
+ *                                             device -> remap_schedule_auto()
+ *                                             (remap_groups_build() and
+ *                                             remap_patches_build() are its
+ *                                             two builders, also exported)
  *
  * Conventions: extern "C"; plain pointers and sizes only; every pointer
  * marked (device) is an address in the current HIP device's memory (e.g.
