@@ -488,8 +488,13 @@ int run_rowgroup(const remap_apply_args *a, const Call &c, KParams p,
                     "row-group schedule for [row_begin, row_end), even "
                     "strides and 32-bit offsets");
     // f32 rows are half as long: two K tiles per wave keep the bytes per
-    // wave and row at 1 KiB (measured +7 % on config 3 with f32 fields)
-    int tiles = a->tune[2] == 0 ? (c.f32 ? 2 : 1) : a->tune[2];
+    // wave and row at 1 KiB (measured +7 % on config 3 with f32 fields).
+    // f64 with 128 < K <= 224 columns: one wave over both (the second only
+    // part full) beats two waves per group (config 3's map: K = 160 0.142
+    // vs 0.170 ms, K = 192 0.160 vs 0.177; from K = 256 one tile wins again)
+    int tiles = a->tune[2];
+    if (tiles == 0)
+        tiles = c.f32 ? 2 : (c.K > 128 && c.K <= 224) ? 2 : 1;
     if (tiles != 2 || c.K <= 128)
         tiles = 1;
     const int gpw = a->tune[3] > 0 ? a->tune[3] : 2;   // groups per wave
