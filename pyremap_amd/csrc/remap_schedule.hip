@@ -722,8 +722,9 @@ int remap_patches_build(const remap_csr *A, const int64_t *grid_dims,
 //      per non-empty row: the compute phase is LDS-issue-bound there).
 //   2. Else row groups when rows share columns at all (union / entries <=
 //      0.95): 2 x 4 groups inside 32 x 32 supertiles for entry-rich rows,
-//      2 K-tiles x 2 groups per wave (1 K-tile in masked mode); otherwise
-//      2 x 2 groups in row-major order, one group per wave.
+//      2 K-tiles per wave (1 in masked mode), one group per wave, single-
+//      wave workgroups; otherwise 2 x 2 groups in row-major order, one
+//      group per wave, 4-wave workgroups.
 //   3. Else the plain wave-per-row kernel -- in 32 x 32 tile order for
 //      entry-rich rows on a 2-D grid (keeps the stencil band in L2).
 //
@@ -964,9 +965,9 @@ int schedule_auto(const remap_csr *A, const double *frac_b,
             out->n_distinct = n_union;
             out->arena_used = arena.used;
             for (int mode = 0; mode < 3; ++mode) {
-                if (entry_rich)
-                    set_tune(out, mode, 10, 0,
-                             mode == REMAP_MODE_MASKED ? 1 : 2, 2);
+                if (entry_rich)   // single-wave workgroups, one group each
+                    set_tune(out, mode, 10, 1,
+                             mode == REMAP_MODE_MASKED ? 1 : 2, 1);
                 else
                     set_tune(out, mode, 10, 0, 0, 1);
             }

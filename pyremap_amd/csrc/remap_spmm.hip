@@ -287,7 +287,8 @@ typename GroupFn<XT>::type pick_rowgroup_shape(int unr, int tiles, int mode,
 
 template <typename XT>
 int launch_rowgroup(const remap_apply_args *a, const KParams &p, int tiles,
-                    int unr, bool fma, int64_t grid, hipStream_t stream)
+                    int unr, int wpb, bool fma, int64_t grid,
+                    hipStream_t stream)
 {
     typename GroupFn<XT>::type fn =
         a->group_rows == 8
@@ -296,8 +297,9 @@ int launch_rowgroup(const remap_apply_args *a, const KParams &p, int tiles,
     uint32_t lds_bytes = 0;
     REMAP_HIP_CHECK(diag_lds_throttle(a, reinterpret_cast<const void *>(fn),
                                       lds_bytes));
-    hipLaunchKernelGGL(fn, dim3(static_cast<uint32_t>(grid)), dim3(kBlock),
-                       lds_bytes, stream, p, a->flags, a->group_meta,
+    hipLaunchKernelGGL(fn, dim3(static_cast<uint32_t>(grid)),
+                       dim3(kWave * wpb), lds_bytes, stream, p, a->flags,
+                       a->group_meta,
                        a->group_col, a->group_w, a->group_mask, a->group_rid,
                        a->group_frac, static_cast<const XT *>(a->X));
     REMAP_HIP_CHECK(hipGetLastError());
@@ -499,17 +501,20 @@ int run_rowgroup(const remap_apply_args *a, const Call &c, KParams p,
         tiles = 1;
     const int gpw = a->tune[3] > 0 ? a->tune[3] : 2;   // groups per wave
     const int unr = a->tune[5] == 4 ? 4 : 8;   // union entries in flight
+    // waves per workgroup (tune[1], unused otherwise by this family)
+    const int wpb = (a->tune[1] == 1 || a->tune[1] == 2) ? a->tune[1]
+                                                         : kWavesPerBlock;
     p.rows_per_wave = gpw;
     int64_t grid;
     const int rc = shape_grid(
-        p, ceil_div(a->n_groups, (int64_t)kWavesPerBlock * gpw),
+        p, ceil_div(a->n_groups, (int64_t)wpb * gpw),
         ceil_div(c.K, (int64_t)kWave * 2 * tiles), a->tune[4] != 1, grid);
     if (rc != REMAP_OK)
         return rc;
-    return c.f32 ? launch_rowgroup<float>(a, p, tiles, unr, c.fma, grid,
+    return c.f32 ? launch_rowgroup<float>(a, p, tiles, unr, wpb, c.fma, grid,
                                           stream)
-                 : launch_rowgroup<double>(a, p, tiles, unr, c.fma, grid,
-                                           stream);
+                 : launch_rowgroup<double>(a, p, tiles, unr, wpb, c.fma,
+                                           grid, stream);
 }
 
 int run_patch(const remap_apply_args *a, const Call &c, KParams p,
