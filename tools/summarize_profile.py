@@ -23,6 +23,18 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 
 
+def newest(paths):
+    """gpurun MERGES a run's files into gpurun_out/: files of earlier runs
+    (other PIDs in their names) may still lie beside the current ones.  Keep
+    the newest file of every directory."""
+    best = {}
+    for q in paths:
+        d = os.path.dirname(q)
+        if d not in best or os.path.getmtime(q) > os.path.getmtime(best[d]):
+            best[d] = q
+    return sorted(best.values())
+
+
 def short(name):
     name = name.replace('(anonymous namespace)::', '').replace('void ', '')
     return name.split('(')[0][:70]
@@ -47,7 +59,8 @@ def main():
             src, 'trace_bench.json')).read().strip().splitlines()[-1])
     except (OSError, ValueError, IndexError):
         pass
-    stats = glob.glob(os.path.join(src, 'trace', '*', '*_kernel_stats.csv'))
+    stats = newest(glob.glob(os.path.join(src, 'trace', '*',
+                                          '*_kernel_stats.csv')))
     if stats:
         rows = list(csv.DictReader(open(stats[0])))
         with open(os.path.join(out, f'{tag}_kernel_stats.csv'), 'w') as f:
@@ -63,7 +76,8 @@ def main():
                      f"{float(r['AverageNs']):.0f} | {r['MinNs']} | "
                      f"{r['MaxNs']} |")
         L.append('')
-    trace = glob.glob(os.path.join(src, 'trace', '*', '*_kernel_trace.csv'))
+    trace = newest(glob.glob(os.path.join(src, 'trace', '*',
+                                          '*_kernel_trace.csv')))
     timed_avg = None
     if trace and live:
         steps, warmup = live['steps'], live['warmup']
@@ -114,7 +128,7 @@ def main():
     for wl in workloads:
         pmc = collections.OrderedDict()
         cfg = None
-        for path in sorted(glob.glob(os.path.join(
+        for path in newest(glob.glob(os.path.join(
                 src, f'pmc_{wl}_*', '*', '*_counter_collection.csv'))):
             per = collections.defaultdict(list)
             names = collections.Counter()
