@@ -194,9 +194,9 @@ typedef struct remap_apply_args {
      * accumulators from it; each row still adds its entries in ascending
      * column order, so results are unchanged.                              */
     const int64_t *group_meta;  /* (device) 2 * (n_groups + 1)              */
-    const int32_t *group_col;   /* (device) union entries (+ 8 readable)    */
+    const int32_t *group_col;   /* (device) union entries (+ 16 readable)   */
     const double *group_w;      /* (device) present weights (+ 64 readable) */
-    const int32_t *group_mask;  /* (device) union entries (+ 8)             */
+    const int32_t *group_mask;  /* (device) union entries (+ 16)            */
     const int32_t *group_rid;   /* (device) n_groups * group_rows           */
     const double *group_frac;   /* (device) n_groups * group_rows           */
     int64_t n_groups;
@@ -229,7 +229,7 @@ typedef struct remap_apply_args {
      * tune[2] K tiles per wave (1, 2 or 4)
      * tune[3] consecutive rows per wave
      * tune[4] block -> work map: 1 = as dispatched, 2 = XCD-contiguous
-     * tune[5] family 10: union entries in flight per wave (8, or 4)
+     * tune[5] family 10: union entries in flight per wave (8; or 4, 16)
      * tune[6..7] reserved, must be 0 (a -DREMAP_DIAG build of the library,
      *         tools/build_diag.py, reads bottleneck-analysis switches from
      *         them; this build rejects them) */
@@ -292,7 +292,7 @@ int remap_csr_from_coo(int64_t n_rows, int64_t n_cols, int64_t nnz,
  *                processing order the schedule assumes: pass it as
  *                remap_apply_args.row_order together with the schedule
  *   group_meta   (device) 2 * (n_groups + 1)     n_groups = ceil(n_rows / G)
- *   group_col, group_mask  (device) A.nnz + 8 each (union entries <= nnz)
+ *   group_col, group_mask  (device) A.nnz + 16 each (union entries <= nnz)
  *   group_w      (device) A.nnz + 64
  *   group_rid, group_frac  (device) n_groups * G
  *   n_union_out  (device) one int64: union entries actually used

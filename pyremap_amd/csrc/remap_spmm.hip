@@ -281,8 +281,9 @@ template <typename XT, int G>
 typename GroupFn<XT>::type pick_rowgroup_shape(int unr, int tiles, int mode,
                                                bool fma)
 {
-    return unr == 4 ? pick_rowgroup_tiles<XT, G, 4>(tiles, mode, fma)
-                    : pick_rowgroup_tiles<XT, G, 8>(tiles, mode, fma);
+    return unr == 4    ? pick_rowgroup_tiles<XT, G, 4>(tiles, mode, fma)
+           : unr == 16 ? pick_rowgroup_tiles<XT, G, 16>(tiles, mode, fma)
+                       : pick_rowgroup_tiles<XT, G, 8>(tiles, mode, fma);
 }
 
 template <typename XT>
@@ -500,7 +501,8 @@ int run_rowgroup(const remap_apply_args *a, const Call &c, KParams p,
     if (tiles != 2 || c.K <= 128)
         tiles = 1;
     const int gpw = a->tune[3] > 0 ? a->tune[3] : 2;   // groups per wave
-    const int unr = a->tune[5] == 4 ? 4 : 8;   // union entries in flight
+    // union entries in flight
+    const int unr = (a->tune[5] == 4 || a->tune[5] == 16) ? a->tune[5] : 8;
     // waves per workgroup (tune[1], unused otherwise by this family)
     const int wpb = (a->tune[1] == 1 || a->tune[1] == 2) ? a->tune[1]
                                                          : kWavesPerBlock;

@@ -59,6 +59,17 @@ __device__ __forceinline__ double mul_add(double a, double x, double acc)
     }
 }
 
+// The masked mode's normaliser, den += a * m with m = 1.0 (valid) or 0.0
+// (remap_numpy.py:265, `matrix.dot(in_mask)`): the product is EXACT (a, or a
+// signed zero), so one fused multiply-add rounds exactly once, to the very
+// value scipy's separate multiply and add give -- RN(a*m + den) ==
+// RN(RN(a*m) + den) -- including NaN / Inf weights and the sign of a zero
+// sum.  Same bits, one VALU instruction fewer, whatever REMAP_FLAG_FMA says.
+__device__ __forceinline__ double den_add(double a, double m, double den)
+{
+    return __builtin_fma(a, m, den);
+}
+
 __device__ __forceinline__ double readlane_f64(double v, int src_lane)
 {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
@@ -155,7 +166,7 @@ __device__ __forceinline__ void accumulate_entries(
                             const double xz = valid ? x : 0.0;
                             const double mz = valid ? 1.0 : 0.0;
                             acc[t][v] = mul_add<FMA>(a, xz, acc[t][v]);
-                            den[t][v] = mul_add<FMA>(a, mz, den[t][v]);
+                            den[t][v] = den_add(a, mz, den[t][v]);
                         } else {
                             acc[t][v] = mul_add<FMA>(a, x, acc[t][v]);
                         }

@@ -226,7 +226,7 @@ __global__ __launch_bounds__(kPatchBlock) void spmm_patch(
                 if constexpr (MODE == REMAP_MODE_MASKED) {
                     const bool valid = (x == x);
                     acc[0][v] = mul_add<FMA>(a, valid ? x : 0.0, acc[0][v]);
-                    den[0][v] = mul_add<FMA>(a, valid ? 1.0 : 0.0, den[0][v]);
+                    den[0][v] = den_add(a, valid ? 1.0 : 0.0, den[0][v]);
                 } else {
                     acc[0][v] = mul_add<FMA>(a, x, acc[0][v]);
                 }

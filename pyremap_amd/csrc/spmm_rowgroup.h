@@ -36,6 +36,10 @@ template <>
 struct I32Vec<8> {
     typedef int32_t type __attribute__((ext_vector_type(8), aligned(4)));
 };
+template <>
+struct I32Vec<16> {
+    typedef int32_t type __attribute__((ext_vector_type(16), aligned(4)));
+};
 template <int N>
 struct F64Vec;
 
@@ -136,6 +140,35 @@ __global__ __launch_bounds__(kBlock) void spmm_rowgroup(
             for (int uu = 0; uu < UNR; ++uu) {
                 if (uu < n) {
                     const int32_t bits = mv[uu];
+                    // masked mode, 8-row groups (entry-rich mappings: an
+                    // entry feeds ~4 member rows): the entry's values with
+                    // NaN -> 0 and its validity as 1.0 / 0.0 ONCE per entry,
+                    // reused by every member row that owns it.  Written
+                    // inside the member blocks the compare and three selects
+                    // were repeated per member: 8 VALU instructions per
+                    // product where 3 do (config 5 masked 31.9 -> 27.9 ms);
+                    // the empty asm keeps hipcc from sinking them back.  In
+                    // 4-row groups an entry has ~1.1 owners and the 4 extra
+                    // VGPRs cost a wave per SIMD: left in the member blocks.
+                    constexpr bool kHoist =
+                        MODE == REMAP_MODE_MASKED && G == 8;
+                    double xz[TILES][VEC], vf[TILES][VEC];
+#pragma unroll
+                    for (int t = 0; t < TILES; ++t)
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) {
+                            const double x = elem<xvec_t, VEC>(xv[uu][t], v);
+                            if constexpr (kHoist) {
+                                const bool valid = (x == x);
+                                xz[t][v] = valid ? x : 0.0;
+                                vf[t][v] = valid ? 1.0 : 0.0;
+                                asm volatile(""
+                                             : "+v"(xz[t][v]), "+v"(vf[t][v]));
+                            } else {
+                                xz[t][v] = x;
+                                vf[t][v] = 0.0;
+                            }
+                        }
 #pragma unroll
                     for (int m = 0; m < G; ++m) {
                         if (bits & (1 << m)) {
@@ -151,18 +184,23 @@ __global__ __launch_bounds__(kBlock) void spmm_rowgroup(
                             for (int t = 0; t < TILES; ++t)
 #pragma unroll
                                 for (int v = 0; v < VEC; ++v) {
-                                    const double x =
-                                        elem<xvec_t, VEC>(xv[uu][t], v);
-                                    if constexpr (MODE == REMAP_MODE_MASKED) {
+                                    if constexpr (kHoist) {
+                                        acc[m][t][v] = mul_add<FMA>(
+                                            a, xz[t][v], acc[m][t][v]);
+                                        den[m][t][v] = den_add(
+                                            a, vf[t][v], den[m][t][v]);
+                                    } else if constexpr (MODE ==
+                                                         REMAP_MODE_MASKED) {
+                                        const double x = xz[t][v];
                                         const bool valid = (x == x);
                                         acc[m][t][v] = mul_add<FMA>(
                                             a, valid ? x : 0.0, acc[m][t][v]);
-                                        den[m][t][v] = mul_add<FMA>(
+                                        den[m][t][v] = den_add(
                                             a, valid ? 1.0 : 0.0,
                                             den[m][t][v]);
                                     } else {
-                                        acc[m][t][v] =
-                                            mul_add<FMA>(a, x, acc[m][t][v]);
+                                        acc[m][t][v] = mul_add<FMA>(
+                                            a, xz[t][v], acc[m][t][v]);
                                     }
                                 }
                         }

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(kBlock) void spmm_rowlane(const KParams p,
         if constexpr (MODE == REMAP_MODE_MASKED) {
             const bool valid = (x == x);
             acc = mul_add<FMA>(a, valid ? x : 0.0, acc);
-            den = mul_add<FMA>(a, valid ? 1.0 : 0.0, den);
+            den = den_add(a, valid ? 1.0 : 0.0, den);
         } else {
             acc = mul_add<FMA>(a, x, acc);
         }

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(kBlock) void spmm_rowscalar(
                                 const bool valid = (x == x);
                                 acc[t][v] = mul_add<FMA>(
                                     a, valid ? x : 0.0, acc[t][v]);
-                                den[t][v] = mul_add<FMA>(
+                                den[t][v] = den_add(
                                     a, valid ? 1.0 : 0.0, den[t][v]);
                             } else {
                                 acc[t][v] = mul_add<FMA>(a, x, acc[t][v]);

@@ -782,7 +782,8 @@ def test_rowgroup_kernel_bitwise(dev, grid, K, rows):
             ref[ref_mask] = np.nan
         for tune in ([10], [10, 0, 2, 1], [10, 0, 1, 3, 1],
                      [10, 0, 1, 2, 0, 4], [10, 0, 2, 1, 0, 4],
-                     [10, 1, 2, 1], [10, 2, 1, 3], [10, 1, 1, 2, 1]):
+                     [10, 1, 2, 1], [10, 2, 1, 3], [10, 1, 1, 2, 1],
+                     [10, 0, 1, 1, 0, 16], [10, 1, 2, 2, 0, 16]):
             y = torch.full((m.n_b, K), 3.0, dtype=torch.float64, device=dev)
             mask = torch.full((m.n_b, K), 7, dtype=torch.uint8, device=dev)
             engine.apply_strided(plan, xd, y, n_batch=1, k_inner=K,

@@ -32,6 +32,10 @@ def main():
     ap.add_argument('--sets', type=int, default=2)
     ap.add_argument('--dtype', default='f64')
     ap.add_argument('--lds-kb', type=int, default=80)
+    ap.add_argument('--x-pad', type=int, default=0,
+                    help='extra elements between the rows of X')
+    ap.add_argument('--y-pad', type=int, default=0,
+                    help='extra elements between the rows of Y')
     ap.add_argument('--pmc', type=int, default=0,
                     help='counter mode: launch each variant N times in '
                          'order, no timing (run under rocprofv3 --pmc)')
@@ -55,12 +59,13 @@ def main():
     mode = {'fracb': engine.MODE_FRACB, 'masked': engine.MODE_MASKED,
             'raw': engine.MODE_RAW}[args.mode]
     dt = torch.float64 if args.dtype == 'f64' else torch.float32
-    xs = [torch.randn((m.n_a, K), device=dev, dtype=dt)
+    xs = [torch.randn((m.n_a, K + args.x_pad), device=dev, dtype=dt)
           for _ in range(args.sets)]
     if args.mode == 'masked':
         for x in xs:
             x[torch.rand(m.n_a, device=dev) < 0.25, :] = float('nan')
-    ys = [torch.empty((plan.n_b, K), device=dev, dtype=torch.float64)
+    ys = [torch.empty((plan.n_b, K + args.y_pad), device=dev,
+                      dtype=torch.float64)
           for _ in range(args.sets)]
     variants = []
     orders = {}
@@ -115,8 +120,9 @@ def main():
         plan.groups = group_sets.get(o)
         s = i % args.sets
         engine.apply_strided(plan, xs[s], ys[s], n_batch=1, k_inner=K,
-                             x_row_stride=K, x_batch_stride=0,
-                             y_row_stride=K, y_batch_stride=0, mode=mode,
+                             x_row_stride=K + args.x_pad, x_batch_stride=0,
+                             y_row_stride=K + args.y_pad, y_batch_stride=0,
+                             mode=mode,
                              threshold=0.01, flags=fl, tune=tune)
 
     if args.pmc:
