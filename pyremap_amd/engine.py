@@ -372,7 +372,8 @@ class RemapPlan:
         with torch.cuda.device(device):
             nbytes = ctypes.c_size_t(0)
             _check(lib.remap_csr_from_coo_workspace(
-                nnz, n_b, ctypes.byref(nbytes)), 'remap_csr_from_coo_workspace')
+                nnz, n_b, ctypes.byref(nbytes)),
+                'remap_csr_from_coo_workspace')
             ws = torch.empty(max(int(nbytes.value), 1), dtype=torch.uint8,
                              device=device)
             rowptr = torch.empty(n_b + 1, dtype=torch.int64, device=device)
@@ -705,9 +706,9 @@ class RemapPlan:
                 used = (int(sched.arena_used) + 255) // 256 * 256
                 small = arena[:used].clone()
                 shift = small.data_ptr() - arena.data_ptr()
-                for name, _ in _Schedule._fields_:
+                for name, ctype in _Schedule._fields_:
                     v = getattr(sched, name)
-                    if name != 'arena_used' and isinstance(v, int) and \
+                    if ctype is ctypes.c_void_p and v and \
                             arena.data_ptr() <= v < arena.data_ptr() + used:
                         setattr(sched, name, v + shift)
                 arena = small
@@ -857,6 +858,24 @@ def apply_strided(plan, X, Y, *, n_batch, k_inner, x_row_stride,
         x_dtype = DTYPE_F32
     else:
         raise TypeError(f'X must be float64 or float32, not {X.dtype}')
+    # the kernel addresses through raw pointers: the tensors must hold the
+    # last element the strides reach
+    for name, t, rows, rs, bs in (('X', X, plan.n_a, x_row_stride,
+                                   x_batch_stride),
+                                  ('Y', Y, plan.n_b, y_row_stride,
+                                   y_batch_stride),
+                                  ('mask_out', mask_out, plan.n_b,
+                                   y_row_stride, y_batch_stride)):
+        if t is None or n_batch <= 0 or k_inner <= 0 or rows <= 0:
+            continue
+        reach = (n_batch - 1) * bs + (rows - 1) * rs + k_inner
+        if min(rs, bs) < 0 or reach > t.numel():
+            raise ValueError(
+                f'{name} holds {t.numel()} elements; the strides (row {rs}, '
+                f'batch {bs}) reach {reach}')
+    if mask_out is not None and (mask_out.dtype != torch.uint8 or
+                                 mask_out.device != plan.device):
+        raise TypeError('mask_out must be a uint8 tensor on the plan device')
     args = _ApplyArgs()
     args.A.n_rows = plan.n_b
     args.A.n_cols = plan.n_a
@@ -1015,6 +1034,14 @@ def remap_tensor(plan, dst_grid_dims, field, remap_axes, mode, threshold=0.0,
                 f'out must be a contiguous float64 tensor of shape '
                 f'{tuple(out_shape)} on {plan.device}, got '
                 f'{out.dtype} {tuple(out.shape)} on {out.device}')
+
+    if mask_out is not None and (
+            mask_out.dtype != torch.uint8 or mask_out.device != plan.device or
+            tuple(mask_out.shape) != tuple(out_shape) or
+            not mask_out.is_contiguous()):
+        raise ValueError(
+            f'mask_out must be a contiguous uint8 tensor of shape '
+            f'{tuple(out_shape)} on {plan.device}')
 
     if direct:
         # strides do the permute/flatten of remap_numpy.py:254-256

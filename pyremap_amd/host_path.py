@@ -170,143 +170,160 @@ def remap_host_array(plan, dst_grid_dims, values, remap_axes, *, mode,
         out_h, pin_o = _host_buffer(out_shape, torch.float64)
         mask_h, pin_m = _host_buffer(out_shape, torch.uint8) \
             if want_mask else (None, 0)
-        x_d = torch.empty(values.shape, dtype=host.dtype, device=device)
+        try:
+            return _enqueue(plan, dst_grid_dims, values, host, remap_axes,
+                            lead, n_batch, in_place, mode, thr, want_mask,
+                            flags, host_mask, dst_shape, out_shape, out_h,
+                            mask_h, pin_o, pin_m, up, down, main)
+        except BaseException:
+            # nothing was handed out: the budget goes back
+            _release_pinned(pin_o + pin_m)
+            raise
 
-        banded = in_place and host_mask is None and mode != 'auto' and \
-            n_batch == 1 and lead == 0 and \
-            values.nbytes >= 4 * CHUNK_BYTES and plan.n_b == plan.n_b_global
-        if banded:
-            done = _banded_pipeline(plan, values, host, x_d, out_h, mask_h,
-                                    mode, thr, flags, up, down, main)
-            if done is not None:
-                return Pending(done, out_h, mask_h, (pin_o, pin_m))
-        if not in_place or host_mask is not None or mode == 'auto' or \
-                n_batch < 2:
-            # ---- one upload, one launch, one download -----------------
-            x_d.copy_(host, non_blocking=True)
-            poisoned = None
-            if host_mask is not None:
-                m_d = torch.from_numpy(np.ascontiguousarray(
-                    host_mask, dtype=np.bool_)).to(device, non_blocking=True)
-                # remap_numpy.py:263: matrix.dot(in_mask * in_field) lets an
-                # UNMASKED NaN through (NaN * 1) and counts it as valid in
-                # the denominator; the kernel, which reads the mask off NaNs,
-                # would renormalise it away.  Rare: find out; if so, hand the
-                # kernel a finite stand-in there (the denominator -- hence
-                # the output mask -- comes out as the reference's) and put
-                # the NaNs where the reference has them after the launch.
-                poison = torch.isnan(x_d) & ~m_d
-                poisoned = poison if bool(poison.any()) else None
-                x_d.masked_fill_(m_d, float('nan'))
-                if poisoned is not None:
-                    x_d.masked_fill_(poisoned, 0.0)
-            if mode == 'auto':
-                y_d = engine.remap_tensor_auto_mode(
-                    plan, dst_grid_dims, x_d, remap_axes, thr, flags=flags)
-                m_out = None
-            else:
-                emode = engine.MODE_MASKED if mode == 'masked' else \
-                    engine.MODE_FRACB
-                res = engine.remap_tensor(
-                    plan, dst_grid_dims, x_d, remap_axes, emode,
-                    threshold=thr if emode == engine.MODE_MASKED else 0.0,
-                    want_mask=want_mask, flags=flags)
-                y_d, m_out = res if want_mask else (res, None)
+
+def _enqueue(plan, dst_grid_dims, values, host, remap_axes, lead, n_batch,
+             in_place, mode, thr, want_mask, flags, host_mask, dst_shape,
+             out_shape, out_h, mask_h, pin_o, pin_m, up, down, main):
+    """The transfers and launches of :func:`remap_host_array`."""
+    torch = engine._torch()
+    device = plan.device
+    x_d = torch.empty(values.shape, dtype=host.dtype, device=device)
+
+    banded = in_place and host_mask is None and mode != 'auto' and \
+        n_batch == 1 and lead == 0 and \
+        values.nbytes >= 4 * CHUNK_BYTES and plan.n_b == plan.n_b_global
+    if banded:
+        done = _banded_pipeline(plan, values, host, x_d, out_h, mask_h,
+                                mode, thr, flags, up, down, main)
+        if done is not None:
+            return Pending(done, out_h, mask_h, (pin_o, pin_m))
+    if not in_place or host_mask is not None or mode == 'auto' or \
+            n_batch < 2:
+        # ---- one upload, one launch, one download -----------------
+        x_d.copy_(host, non_blocking=True)
+        poisoned = None
+        if host_mask is not None:
+            m_d = torch.from_numpy(np.ascontiguousarray(
+                host_mask, dtype=np.bool_)).to(device, non_blocking=True)
+            # remap_numpy.py:263: matrix.dot(in_mask * in_field) lets an
+            # UNMASKED NaN through (NaN * 1) and counts it as valid in
+            # the denominator; the kernel, which reads the mask off NaNs,
+            # would renormalise it away.  Rare: find out; if so, hand the
+            # kernel a finite stand-in there (the denominator -- hence
+            # the output mask -- comes out as the reference's) and put
+            # the NaNs where the reference has them after the launch.
+            poison = torch.isnan(x_d) & ~m_d
+            poisoned = poison if bool(poison.any()) else None
+            x_d.masked_fill_(m_d, float('nan'))
             if poisoned is not None:
-                # every destination cell that touches a poisoned entry is NaN
-                # (and NOT masked) in the reference: 0 * NaN = NaN through a
-                # RAW product marks them
-                p_field = torch.where(poisoned, float('nan'), 0.0).to(
-                    torch.float64)
-                hit = engine.remap_tensor(plan, dst_grid_dims, p_field,
-                                          remap_axes, engine.MODE_RAW,
-                                          flags=flags)
-                y_d = torch.where(torch.isnan(hit), float('nan'), y_d)
-            done = torch.cuda.Event()
-            done.record(main)
-            with torch.cuda.stream(down):
-                down.wait_event(done)
-                out_h.copy_(y_d, non_blocking=True)
-                if want_mask:
-                    mask_h.copy_(m_out, non_blocking=True)
-                finished = torch.cuda.Event()
-                finished.record(down)
-            # the device buffers must outlive the copies queued on `down`
-            y_d.record_stream(down)
-            if m_out is not None:
-                m_out.record_stream(down)
-            return Pending(finished, out_h, mask_h, (pin_o, pin_m))
-
-        # ---- pipelined: batches of leading dims, three streams ------------
-        emode = engine.MODE_MASKED if mode == 'masked' else engine.MODE_FRACB
-        y_d = torch.empty(out_shape, dtype=torch.float64, device=device)
-        m_d = torch.empty(out_shape, dtype=torch.uint8, device=device) \
-            if want_mask else None
-        lead_shape = list(values.shape[:lead])
-        xb = host.reshape([n_batch] + list(values.shape[lead:]))
-        xdb = x_d.reshape(xb.shape)
-        ydb = y_d.reshape([n_batch] + dst_shape +
-                          list(values.shape[lead + len(remap_axes):]))
-        ohb = out_h.reshape(ydb.shape)
-        mdb = m_d.reshape(ydb.shape) if want_mask else None
-        mhb = mask_h.reshape(ydb.shape) if want_mask else None
-        per_batch = max(xb[0].numel() * xb.element_size(),
-                        ydb[0].numel() * 8)
-        step = max(1, min(n_batch, CHUNK_BYTES // max(per_batch, 1)))
-        axes_b = [a - lead + 1 for a in remap_axes]
-        start = torch.cuda.Event()
-        start.record(main)
-        up.wait_event(start)
-        finished = None
-        chunks = [(b0, min(b0 + step, n_batch))
-                  for b0 in range(0, n_batch, step)]
-        # Uploads from PAGEABLE memory block the calling thread until the
-        # bytes are on the device, downloads into pinned memory do not: a
-        # helper thread feeds the `up` stream so that this thread can queue
-        # launches and downloads meanwhile (measured, 0.96 GB up + 1.06 GB
-        # down: 22 ms overlapped, 34 ms one after the other)
-        arrivals = queue.Queue()
-
-        def uploader():
-            try:
-                with torch.cuda.device(device), torch.cuda.stream(up):
-                    for b0, b1 in chunks:
-                        xdb[b0:b1].copy_(xb[b0:b1], non_blocking=True)
-                        ev = torch.cuda.Event()
-                        ev.record(up)
-                        arrivals.put(ev)
-            except BaseException as exc:   # noqa: BLE001 - handed over
-                arrivals.put(exc)
-
-        feeder = threading.Thread(target=uploader, daemon=True)
-        feeder.start()
-        for b0, b1 in chunks:
-            arrived = arrivals.get()
-            if isinstance(arrived, BaseException):
-                feeder.join()
-                raise arrived
-            main.wait_event(arrived)
-            engine.remap_tensor(
-                plan, dst_grid_dims, xdb[b0:b1], axes_b, emode,
+                x_d.masked_fill_(poisoned, 0.0)
+        if mode == 'auto':
+            y_d = engine.remap_tensor_auto_mode(
+                plan, dst_grid_dims, x_d, remap_axes, thr, flags=flags)
+            m_out = None
+        else:
+            emode = engine.MODE_MASKED if mode == 'masked' else \
+                engine.MODE_FRACB
+            res = engine.remap_tensor(
+                plan, dst_grid_dims, x_d, remap_axes, emode,
                 threshold=thr if emode == engine.MODE_MASKED else 0.0,
-                want_mask=want_mask, flags=flags, out=ydb[b0:b1],
-                mask_out=mdb[b0:b1] if want_mask else None)
-            computed = torch.cuda.Event()
-            computed.record(main)
-            with torch.cuda.stream(down):
-                down.wait_event(computed)
-                ohb[b0:b1].copy_(ydb[b0:b1], non_blocking=True)
-                if want_mask:
-                    mhb[b0:b1].copy_(mdb[b0:b1], non_blocking=True)
-                finished = torch.cuda.Event()
-                finished.record(down)
-        feeder.join()
-        x_d.record_stream(up)
+                want_mask=want_mask, flags=flags)
+            y_d, m_out = res if want_mask else (res, None)
+        if poisoned is not None:
+            # every destination cell that touches a poisoned entry is NaN
+            # (and NOT masked) in the reference: 0 * NaN = NaN through a
+            # RAW product marks them
+            p_field = torch.where(poisoned, float('nan'), 0.0).to(
+                torch.float64)
+            hit = engine.remap_tensor(plan, dst_grid_dims, p_field,
+                                      remap_axes, engine.MODE_RAW,
+                                      flags=flags)
+            y_d = torch.where(torch.isnan(hit), float('nan'), y_d)
+        done = torch.cuda.Event()
+        done.record(main)
+        with torch.cuda.stream(down):
+            down.wait_event(done)
+            out_h.copy_(y_d, non_blocking=True)
+            if want_mask:
+                mask_h.copy_(m_out, non_blocking=True)
+            finished = torch.cuda.Event()
+            finished.record(down)
+        # the device buffers must outlive the copies queued on `down`
         y_d.record_stream(down)
-        if m_d is not None:
-            m_d.record_stream(down)
-        del lead_shape
+        if m_out is not None:
+            m_out.record_stream(down)
         return Pending(finished, out_h, mask_h, (pin_o, pin_m))
+
+    # ---- pipelined: batches of leading dims, three streams ------------
+    emode = engine.MODE_MASKED if mode == 'masked' else engine.MODE_FRACB
+    y_d = torch.empty(out_shape, dtype=torch.float64, device=device)
+    m_d = torch.empty(out_shape, dtype=torch.uint8, device=device) \
+        if want_mask else None
+    lead_shape = list(values.shape[:lead])
+    xb = host.reshape([n_batch] + list(values.shape[lead:]))
+    xdb = x_d.reshape(xb.shape)
+    ydb = y_d.reshape([n_batch] + dst_shape +
+                      list(values.shape[lead + len(remap_axes):]))
+    ohb = out_h.reshape(ydb.shape)
+    mdb = m_d.reshape(ydb.shape) if want_mask else None
+    mhb = mask_h.reshape(ydb.shape) if want_mask else None
+    per_batch = max(xb[0].numel() * xb.element_size(),
+                    ydb[0].numel() * 8)
+    step = max(1, min(n_batch, CHUNK_BYTES // max(per_batch, 1)))
+    axes_b = [a - lead + 1 for a in remap_axes]
+    start = torch.cuda.Event()
+    start.record(main)
+    up.wait_event(start)
+    finished = None
+    chunks = [(b0, min(b0 + step, n_batch))
+              for b0 in range(0, n_batch, step)]
+    # Uploads from PAGEABLE memory block the calling thread until the
+    # bytes are on the device, downloads into pinned memory do not: a
+    # helper thread feeds the `up` stream so that this thread can queue
+    # launches and downloads meanwhile (measured, 0.96 GB up + 1.06 GB
+    # down: 22 ms overlapped, 34 ms one after the other)
+    arrivals = queue.Queue()
+
+    def uploader():
+        try:
+            with torch.cuda.device(device), torch.cuda.stream(up):
+                for b0, b1 in chunks:
+                    xdb[b0:b1].copy_(xb[b0:b1], non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(up)
+                    arrivals.put(ev)
+        except BaseException as exc:   # noqa: BLE001 - handed over
+            arrivals.put(exc)
+
+    feeder = threading.Thread(target=uploader, daemon=True)
+    feeder.start()
+    for b0, b1 in chunks:
+        arrived = arrivals.get()
+        if isinstance(arrived, BaseException):
+            feeder.join()
+            raise arrived
+        main.wait_event(arrived)
+        engine.remap_tensor(
+            plan, dst_grid_dims, xdb[b0:b1], axes_b, emode,
+            threshold=thr if emode == engine.MODE_MASKED else 0.0,
+            want_mask=want_mask, flags=flags, out=ydb[b0:b1],
+            mask_out=mdb[b0:b1] if want_mask else None)
+        computed = torch.cuda.Event()
+        computed.record(main)
+        with torch.cuda.stream(down):
+            down.wait_event(computed)
+            ohb[b0:b1].copy_(ydb[b0:b1], non_blocking=True)
+            if want_mask:
+                mhb[b0:b1].copy_(mdb[b0:b1], non_blocking=True)
+            finished = torch.cuda.Event()
+            finished.record(down)
+    feeder.join()
+    x_d.record_stream(up)
+    y_d.record_stream(down)
+    if m_d is not None:
+        m_d.record_stream(down)
+    del lead_shape
+    return Pending(finished, out_h, mask_h, (pin_o, pin_m))
 
 
 def _banded_pipeline(plan, values, host, x_d, out_h, mask_h, mode, thr,

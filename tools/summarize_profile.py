@@ -113,8 +113,10 @@ def main():
               'per-dispatch rows)', '',
               f'Kernel `{short(mine[-1]["Kernel_Name"])}`, grid '
               f'{main_grid} x {mine[-1]["Workgroup_Size_X"]}, '
-              f'{mine[-1]["VGPR_Count"]} VGPRs / {mine[-1]["SGPR_Count"]} '
-              f'SGPRs: the {steps} launches of the timed region average '
+              f'rocprofv3 columns VGPR_Count {mine[-1]["VGPR_Count"]} / '
+              f'SGPR_Count {mine[-1]["SGPR_Count"]} (the code object\'s '
+              f'.vgpr_count, which sets the occupancy, is what '
+              f'tools/kernel_regs.py prints: 60 for this kernel): the {steps} launches of the timed region average '
               f'**{timed_avg:.0f} ns** (min {min(timed)}, max {max(timed)}); '
               f'the bench line of the same run reports kernel_ms_mean = '
               f'{live["roofline"]["kernel_ms_mean"] * 1e6:.0f} ns (one HIP '
