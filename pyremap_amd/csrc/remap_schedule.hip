@@ -323,9 +323,9 @@ int groups_build(const remap_csr *A, const double *frac_b, int32_t G,
     REMAP_HIP_CHECK((rocprim::exclusive_scan(
         temp, tb, static_cast<const uint32_t *>(head), uidx, 0u,
         static_cast<size_t>(nnz), rocprim::plus<uint32_t>(), stream)));
-    REMAP_HIP_CHECK(hipMemsetAsync(gcol, 0, (nnz + 16) * sizeof(int32_t),
+    REMAP_HIP_CHECK(hipMemsetAsync(gcol, 0, (nnz + 32) * sizeof(int32_t),
                                    stream));
-    REMAP_HIP_CHECK(hipMemsetAsync(gmask, 0, (nnz + 16) * sizeof(int32_t),
+    REMAP_HIP_CHECK(hipMemsetAsync(gmask, 0, (nnz + 32) * sizeof(int32_t),
                                    stream));
     hipLaunchKernelGGL(fill_union, dim3(blocks_for(nnz)), dim3(kBlock), 0,
                        stream, nnz, n_a, G, k_out, head, uidx, gcol, gmask,
@@ -765,7 +765,7 @@ size_t arena_need(int64_t n_rows, int64_t nnz)
                          align_g(ne * 8);
     const size_t n_groups = nr / 4 + 2;
     const size_t group = align_g(2 * (n_groups + 1) * 8) +
-                         2 * align_g((ne + 16) * 4) + align_g((ne + 64) * 8) +
+                         2 * align_g((ne + 32) * 4) + align_g((ne + 64) * 8) +
                          align_g(n_groups * 8 * 4) + align_g(n_groups * 8 * 8);
     return order + (patch > group ? patch : group) + align_g(64);
 }
@@ -931,8 +931,8 @@ int schedule_auto(const remap_csr *A, const double *frac_b,
         const int64_t n_groups = (n_rows + G - 1) / G;
         arena.used = mark;
         int64_t *meta = arena.take<int64_t>(2 * (n_groups + 1));
-        int32_t *gcol = arena.take<int32_t>(nnz + 16);
-        int32_t *gmask = arena.take<int32_t>(nnz + 16);
+        int32_t *gcol = arena.take<int32_t>(nnz + 32);
+        int32_t *gmask = arena.take<int32_t>(nnz + 32);
         double *gw = arena.take<double>(nnz + 64);
         int32_t *rid = arena.take<int32_t>(n_groups * G);
         double *gfrac = arena.take<double>(n_groups * G);

@@ -623,8 +623,8 @@ class RemapPlan:
             st = 0           # no supertiles: row-major over the whole grid
         n_groups = (self.n_b + G - 1) // G
         meta = torch.empty((n_groups + 1, 2), dtype=torch.int64, device=dev)
-        col = torch.empty(self.nnz + 16, dtype=torch.int32, device=dev)
-        mask = torch.empty(self.nnz + 16, dtype=torch.int32, device=dev)
+        col = torch.empty(self.nnz + 32, dtype=torch.int32, device=dev)
+        mask = torch.empty(self.nnz + 32, dtype=torch.int32, device=dev)
         w = torch.empty(self.nnz + 64, dtype=torch.float64, device=dev)
         rid = torch.empty(n_groups * G, dtype=torch.int32, device=dev)
         frac = torch.empty(n_groups * G, dtype=torch.float64, device=dev)
@@ -648,8 +648,8 @@ class RemapPlan:
             nu = int(n_union)
         self.row_order = order
         # trim the union arrays to what is used (+ the readable pad)
-        self.groups = dict(meta=meta, col=col[:nu + 16].clone(),
-                           w=w, mask=mask[:nu + 16].clone(), rid=rid,
+        self.groups = dict(meta=meta, col=col[:nu + 32].clone(),
+                           w=w, mask=mask[:nu + 32].clone(), rid=rid,
                            frac=frac, n=n_groups, rows=G, order=order,
                            union=nu)
         return nu / self.nnz
@@ -750,9 +750,9 @@ class RemapPlan:
             self.groups = dict(
                 meta=view(sched.group_meta, 2 * (n_g + 1),
                           torch.int64).reshape(n_g + 1, 2),
-                col=view(sched.group_col, nu + 16, torch.int32),
+                col=view(sched.group_col, nu + 32, torch.int32),
                 w=view(sched.group_w, self.nnz + 64, torch.float64),
-                mask=view(sched.group_mask, nu + 16, torch.int32),
+                mask=view(sched.group_mask, nu + 32, torch.int32),
                 rid=view(sched.group_rid, n_g * G, torch.int32),
                 frac=view(sched.group_frac, n_g * G, torch.float64),
                 n=n_g, rows=G, order=order, union=nu)
