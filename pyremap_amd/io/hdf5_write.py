@@ -149,7 +149,9 @@ def write_netcdf4(filename, dimensions, variables, attrs=None,
         if arr.dtype.kind == 'b':
             arr = arr.astype(np.int8)
         if arr.dtype.kind in 'iuf':
-            arr = arr.astype(arr.dtype.newbyteorder('<'))
+            # (no copy when the data is little-endian already: a remapped
+            # field is as large as memory allows)
+            arr = arr.astype(arr.dtype.newbyteorder('<'), copy=False)
         if tuple(arr.shape) != tuple(dimensions[d] for d in dims):
             raise ValueError(f'{name}: shape {arr.shape} does not match '
                              f'dimensions {dims}')
@@ -294,5 +296,8 @@ def write_netcdf4(filename, dimensions, variables, attrs=None,
             put(ds.header_addr,
                 _object_header(dataset_messages(ds, gheap_addr)))
             if ds.data_addr is not None:
-                put(ds.data_addr, ds.data.tobytes())
+                # the array's own memory goes to the file (no tobytes copy)
+                put(ds.data_addr, ds.data.reshape(-1).view(np.uint8)
+                    if ds.data.dtype.kind in 'iuf' and ds.data.size
+                    else ds.data.tobytes())
         f.truncate(eof)

@@ -306,6 +306,36 @@ def _storable(arr, version):
     return arr
 
 
+#: elements are converted and written this many bytes at a time
+_WRITE_CHUNK = 16 << 20
+
+
+def _write_big_endian(f, data):
+    """
+    Write ``data`` in C order as big-endian bytes, ``_WRITE_CHUNK`` at a time
+    through one reusable buffer: a remapped field is as large as memory
+    allows, and ``astype('>f8').tobytes()`` would hold two more copies of it.
+    Returns the number of bytes written.
+    """
+    data = np.asarray(data)
+    if data.size == 0:
+        return 0
+    if data.dtype.kind == 'S' or data.dtype.itemsize == 1 or \
+            data.dtype.byteorder == '>':
+        raw = np.ascontiguousarray(data)
+        f.write(raw.reshape(-1).view(np.uint8))
+        return raw.nbytes
+    flat = data.reshape(-1) if data.flags['C_CONTIGUOUS'] else \
+        np.ascontiguousarray(data).reshape(-1)
+    step = max(1, _WRITE_CHUNK // data.dtype.itemsize)
+    buf = np.empty(min(step, flat.size), dtype=data.dtype.newbyteorder('>'))
+    for i in range(0, flat.size, step):
+        n = min(step, flat.size - i)
+        buf[:n] = flat[i:i + n]          # converts and swaps in one pass
+        f.write(buf[:n].view(np.uint8))
+    return flat.size * data.dtype.itemsize
+
+
 def write(filename, dimensions, variables, attrs=None, version=2):
     """
     Write a classic-format file.
@@ -395,25 +425,14 @@ def write(filename, dimensions, variables, attrs=None, version=2):
         for var, data, rec in prepared:
             if rec:
                 continue
-            raw = np.ascontiguousarray(
-                data.astype(data.dtype.newbyteorder('>')
-                            if data.dtype.kind != 'S' else data.dtype))
-            n = raw.nbytes
-            f.write(raw.tobytes())
+            n = _write_big_endian(f, data)
             f.write(b'\x00' * (_pad4(n) - n))
-        if rec_list:
-            big = [np.ascontiguousarray(
-                data.astype(data.dtype.newbyteorder('>')
-                            if data.dtype.kind != 'S' else data.dtype))
-                   for _, data, _ in rec_list]
-            for r in range(numrecs):
-                for raw in big:
-                    # slices keep the big-endian dtype (scalars would not)
-                    if r < raw.shape[0]:
-                        chunk = raw[r:r + 1].tobytes()
-                    else:
-                        chunk = b'\x00' * (raw[0:1].nbytes if raw.shape[0]
-                                           else 0)
-                    f.write(chunk)
-                    if not single_rec:
-                        f.write(b'\x00' * (_pad4(len(chunk)) - len(chunk)))
+        for r in range(numrecs if rec_list else 0):
+            for _, data, _ in rec_list:
+                if r < data.shape[0]:
+                    n = _write_big_endian(f, data[r:r + 1])
+                else:
+                    n = vsize(data, True) if data.shape[0] else 0
+                    f.write(b'\x00' * n)
+                if not single_rec:
+                    f.write(b'\x00' * (_pad4(n) - n))
