@@ -254,33 +254,49 @@ struct GroupFn {
                          const int32_t *, const double *, const XT *);
 };
 
-template <typename XT, int TILES, int G, int UNR>
+template <typename XT, int TILES, int G, int UNR, int VEC>
 typename GroupFn<XT>::type pick_rowgroup_mode(int mode, bool fma)
 {
     switch (mode) {
     case REMAP_MODE_RAW:
-        return fma ? spmm_rowgroup<XT, TILES, REMAP_MODE_RAW, true, G, UNR>
-                   : spmm_rowgroup<XT, TILES, REMAP_MODE_RAW, false, G, UNR>;
+        return fma ? spmm_rowgroup<XT, TILES, REMAP_MODE_RAW, true, G, UNR,
+                                   VEC>
+                   : spmm_rowgroup<XT, TILES, REMAP_MODE_RAW, false, G, UNR,
+                                   VEC>;
     case REMAP_MODE_FRACB:
-        return fma ? spmm_rowgroup<XT, TILES, REMAP_MODE_FRACB, true, G, UNR>
-                   : spmm_rowgroup<XT, TILES, REMAP_MODE_FRACB, false, G, UNR>;
+        return fma ? spmm_rowgroup<XT, TILES, REMAP_MODE_FRACB, true, G, UNR,
+                                   VEC>
+                   : spmm_rowgroup<XT, TILES, REMAP_MODE_FRACB, false, G, UNR,
+                                   VEC>;
     default:
-        return fma ? spmm_rowgroup<XT, TILES, REMAP_MODE_MASKED, true, G, UNR>
-                   : spmm_rowgroup<XT, TILES, REMAP_MODE_MASKED, false, G, UNR>;
+        return fma ? spmm_rowgroup<XT, TILES, REMAP_MODE_MASKED, true, G, UNR,
+                                   VEC>
+                   : spmm_rowgroup<XT, TILES, REMAP_MODE_MASKED, false, G,
+                                   UNR, VEC>;
     }
 }
 
 template <typename XT, int G, int UNR>
 typename GroupFn<XT>::type pick_rowgroup_tiles(int tiles, int mode, bool fma)
 {
-    return tiles == 1 ? pick_rowgroup_mode<XT, 1, G, UNR>(mode, fma)
-                      : pick_rowgroup_mode<XT, 2, G, UNR>(mode, fma);
+    return tiles == 1 ? pick_rowgroup_mode<XT, 1, G, UNR, 2>(mode, fma)
+                      : pick_rowgroup_mode<XT, 2, G, UNR, 2>(mode, fma);
 }
 
+// vec = elements per lane and tile: 2 (16-byte accesses; even strides and
+// level counts, 16-byte aligned bases), or 1 for everything else -- (Time,
+// nCells, nVertLevelsP1 = 61), L137, a view that starts at an odd element:
+// two tiles of 64 columns, so a wave still covers 128 columns per entry.
+// (Keeping two elements per lane there with element-aligned 16-byte
+// accesses -- pairs cut per batch, the odd last column fetched one element
+// early -- was built and measured: no faster than this, the misaligned wide
+// accesses are split by the memory pipeline; removed.)
 template <typename XT, int G>
-typename GroupFn<XT>::type pick_rowgroup_shape(int unr, int tiles, int mode,
-                                               bool fma)
+typename GroupFn<XT>::type pick_rowgroup_shape(int unr, int tiles, int vec,
+                                               int mode, bool fma)
 {
+    if (vec == 1)
+        return pick_rowgroup_mode<XT, 2, G, 8, 1>(mode, fma);
     return unr == 4    ? pick_rowgroup_tiles<XT, G, 4>(tiles, mode, fma)
            : unr == 16 ? pick_rowgroup_tiles<XT, G, 16>(tiles, mode, fma)
                        : pick_rowgroup_tiles<XT, G, 8>(tiles, mode, fma);
@@ -288,13 +304,13 @@ typename GroupFn<XT>::type pick_rowgroup_shape(int unr, int tiles, int mode,
 
 template <typename XT>
 int launch_rowgroup(const remap_apply_args *a, const KParams &p, int tiles,
-                    int unr, int wpb, bool fma, int64_t grid,
+                    int unr, int vec, int wpb, bool fma, int64_t grid,
                     hipStream_t stream)
 {
     typename GroupFn<XT>::type fn =
         a->group_rows == 8
-            ? pick_rowgroup_shape<XT, 8>(unr, tiles, a->mode, fma)
-            : pick_rowgroup_shape<XT, 4>(unr, tiles, a->mode, fma);
+            ? pick_rowgroup_shape<XT, 8>(unr, tiles, vec, a->mode, fma)
+            : pick_rowgroup_shape<XT, 4>(unr, tiles, vec, a->mode, fma);
     uint32_t lds_bytes = 0;
     REMAP_HIP_CHECK(diag_lds_throttle(a, reinterpret_cast<const void *>(fn),
                                       lds_bytes));
@@ -421,6 +437,7 @@ KParams base_params(const remap_apply_args *a, const Call &c)
     p.thr = a->threshold;
     p.K = static_cast<uint32_t>(c.K);
     p.k_inner = static_cast<uint32_t>(a->k_inner);
+    p.bpc = 0;
     p.n_rowblocks = p.n_blocks = p.blocks_per_xcd = 0;
     p.rows_per_wave = 0;
     p.xcd_map = 0;
@@ -434,7 +451,7 @@ bool hint_usable(const remap_apply_args *a, const Call &c)
         return false;  // the lane-per-(row, k) kernel owns small K
     switch (a->tune[0]) {
     case 10:
-        return c.group_ok && c.can_vec2 && c.small_offsets;
+        return c.group_ok && c.small_offsets;
     case 5:
         return c.patch_ok;
     case 6:
@@ -482,14 +499,39 @@ int shape_grid(KParams &p, int64_t n_rowblocks, int64_t n_chunks, bool xcd,
 
 int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// K tiles for the wave-per-row(-group) kernels: `cols` columns per tile.
+// Returns the number of K chunks (of `tiles` tiles each) and sets p.bpc:
+// whole batches per tile when the batches are short runs that are no whole
+// number of 128-byte lines -- (Time, nCells, 61 levels) -- and still fill
+// >= 3/4 of a tile; else the flat column list is cut every `cols` columns
+// (tile_offsets).  Measured on config 3's mapping, (Time, nCells, L) in
+// place, ms per launch flat -> batch-aligned: L = 61 0.59 -> 0.43, 57 0.66 ->
+// 0.54, 100 0.45 -> 0.42, 56 0.39 -> 0.36, 60 unchanged (0.43: its 480-byte
+// runs straddle lines wherever the tiles are cut); L = 48 (384-byte runs,
+// the flat cuts fall on line boundaries) 0.38 -> 0.40, hence the line rule.
+int64_t shape_tiles(KParams &p, const remap_apply_args *a, int64_t K,
+                    int cols, int tiles)
+{
+    p.bpc = 0;
+    const int64_t ki = a->k_inner;
+    if (a->n_batch > 1 && ki < cols && cols % ki != 0 && ki % 16 != 0) {
+        const int64_t m = cols / ki;
+        if (m * ki * 4 >= (int64_t)cols * 3) {
+            p.bpc = static_cast<uint32_t>(m);
+            return ceil_div(a->n_batch, m * tiles);
+        }
+    }
+    return ceil_div(K, (int64_t)cols * tiles);
+}
+
 int run_rowgroup(const remap_apply_args *a, const Call &c, KParams p,
                  hipStream_t stream)
 {
-    if (!c.group_ok || !c.can_vec2 || !c.small_offsets)
+    if (!c.group_ok || !c.small_offsets)
         return fail(REMAP_ERR_ARG,
                     "remap_apply_f64: the rowgroup kernel needs the "
-                    "row-group schedule for [row_begin, row_end), even "
-                    "strides and 32-bit offsets");
+                    "row-group schedule for [row_begin, row_end) and 32-bit "
+                    "offsets");
     // f32 rows are half as long: two K tiles per wave keep the bytes per
     // wave and row at 1 KiB (measured +7 % on config 3 with f32 fields).
     // f64 with 128 < K <= 224 columns: one wave over both (the second only
@@ -500,6 +542,10 @@ int run_rowgroup(const remap_apply_args *a, const Call &c, KParams p,
         tiles = c.f32 ? 2 : (c.K > 128 && c.K <= 224) ? 2 : 1;
     if (tiles != 2 || c.K <= 128)
         tiles = 1;
+    // odd strides or level counts: one element per lane and tile, two tiles
+    const int vec = c.can_vec2 ? 2 : 1;
+    if (vec == 1)
+        tiles = 2;
     const int gpw = a->tune[3] > 0 ? a->tune[3] : 2;   // groups per wave
     // union entries in flight
     const int unr = (a->tune[5] == 4 || a->tune[5] == 16) ? a->tune[5] : 8;
@@ -510,12 +556,12 @@ int run_rowgroup(const remap_apply_args *a, const Call &c, KParams p,
     int64_t grid;
     const int rc = shape_grid(
         p, ceil_div(a->n_groups, (int64_t)wpb * gpw),
-        ceil_div(c.K, (int64_t)kWave * 2 * tiles), a->tune[4] != 1, grid);
+        shape_tiles(p, a, c.K, kWave * vec, tiles), a->tune[4] != 1, grid);
     if (rc != REMAP_OK)
         return rc;
-    return c.f32 ? launch_rowgroup<float>(a, p, tiles, unr, wpb, c.fma, grid,
-                                          stream)
-                 : launch_rowgroup<double>(a, p, tiles, unr, wpb, c.fma,
+    return c.f32 ? launch_rowgroup<float>(a, p, tiles, unr, vec, wpb, c.fma,
+                                          grid, stream)
+                 : launch_rowgroup<double>(a, p, tiles, unr, vec, wpb, c.fma,
                                            grid, stream);
 }
 
@@ -641,7 +687,7 @@ int run_rowwave(const remap_apply_args *a, const Call &c, KParams p,
     int64_t grid;
     const int rc = shape_grid(
         p, ceil_div(c.n_rows, (int64_t)kWavesPerBlock * rpw),
-        ceil_div(c.K, (int64_t)kWave * vec * tiles),
+        shape_tiles(p, a, c.K, kWave * vec, tiles),
         a->tune[4] == 0 || a->tune[4] == 2, grid);
     if (rc != REMAP_OK)
         return rc;

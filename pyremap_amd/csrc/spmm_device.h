@@ -19,6 +19,8 @@ struct KParams {
     double thr;
     uint32_t K;
     uint32_t k_inner;
+    uint32_t bpc;          // whole batches per K tile (0: tiles cut the flat
+                           // column list every kWave * VEC columns)
     int32_t rows_per_wave;
     int32_t xcd_map;
     uint32_t x_range;      // bytes addressable from a source row base
@@ -226,6 +228,27 @@ __device__ __forceinline__ void tile_offsets(
     int64_t (&yoff)[TILES], bool (&act)[TILES])
 {
     constexpr int CH = kWave * VEC;
+    if (p.bpc) {
+        // Batch-aligned tiles: a tile holds `bpc` WHOLE batches (level
+        // columns of (Time, nCells, 60 levels): 2 x 60 of a wave's 128
+        // columns).  Cutting the flat column list every 128 columns instead
+        // splits a batch's 480-byte run between two waves -- two XCDs, two
+        // moments -- so the cache line at the cut is fetched twice and
+        // written in two partial pieces.
+        const uint32_t n_batch = p.K / p.k_inner;
+        const uint32_t cc = lane * VEC;
+        const uint32_t bi = cc / p.k_inner;
+        const uint32_t k = cc - bi * p.k_inner;
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) {
+            const uint32_t b =
+                (static_cast<uint32_t>(chunk) * TILES + t) * p.bpc + bi;
+            act[t] = bi < p.bpc && b < n_batch;
+            xoff[t] = act[t] ? static_cast<int64_t>(b) * p.bsx + k : 0;
+            yoff[t] = act[t] ? static_cast<int64_t>(b) * p.bsy + k : 0;
+        }
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < TILES; ++t) {
         const uint32_t kf = (static_cast<uint32_t>(chunk) * TILES + t) * CH +

@@ -52,7 +52,7 @@ struct F64Vec<8> {
     typedef double type __attribute__((ext_vector_type(8), aligned(8)));
 };
 
-template <typename XT, int TILES, int MODE, bool FMA, int G, int UNR>
+template <typename XT, int TILES, int MODE, bool FMA, int G, int UNR, int VEC>
 __global__ __launch_bounds__(kBlock) void spmm_rowgroup(
     const KParams p, const uint32_t flags,
     const int64_t *__restrict__ gmeta, const int32_t *__restrict__ gcol,
@@ -60,7 +60,6 @@ __global__ __launch_bounds__(kBlock) void spmm_rowgroup(
     const int32_t *__restrict__ grid, const double *__restrict__ gfrac,
     const XT *__restrict__ X)
 {
-    constexpr int VEC = 2;
     constexpr bool kPrefetch = (G == 8 && UNR <= 8);
     typedef typename XVec<XT, VEC>::type xvec_t;
     typedef typename I32Vec<UNR>::type ivec_t;

@@ -270,23 +270,40 @@ def test_layouts_bitwise(dev):
         ((5, 6, 300), [2]), ((2, 20, 15, 66), [1, 2]), ((20, 15), [0, 1]),
         ((3, 20, 15), [1, 2]), ((2, 3, 300, 2, 35), [2]),
         ((20, 7, 15), [0, 2]),
+        # level counts that do not divide a wave's 128 (64) columns: whole
+        # batches per K tile (60, 50, 61), the flat cut (100, 24), and
+        # batches left over in the last chunk
+        ((5, 300, 60), [1]), ((3, 300, 61), [1]), ((7, 300, 24), [1]),
+        ((5, 300, 100), [1]), ((5, 300, 50), [1]), ((2, 2, 300, 60), [2]),
     ]
-    for shape, axes in shapes:
-        f = rng.standard_normal(shape)
-        fn = f.copy()
-        fn[rng.random(shape) < 0.15] = np.nan
-        for field, mode, thr in ((f, engine.MODE_FRACB, None),
-                                 (fn, engine.MODE_MASKED, 0.1)):
-            arg = field if thr is None else np.ma.masked_array(
-                field, np.isnan(field))
-            ref = oracle.remap_numpy_array(csr, frac_b, (12, 9), arg, axes,
-                                           thr).filled(np.nan)
-            y = engine.remap_tensor(plan, (12, 9),
-                                    torch.from_numpy(field).to(dev), axes,
-                                    mode, threshold=thr or 0.0)
-            assert tuple(y.shape) == ref.shape, (shape, axes)
-            assert y.is_contiguous()
-            assert_bitwise(y.cpu().numpy(), ref, f'{shape} {axes}')
+    for schedule in (None, 4, 8):
+        if schedule is None:
+            plan.groups = None
+            plan.set_row_order(None)
+        else:
+            plan.build_groups((12, 9), rows=schedule)
+        for shape, axes in shapes:
+            if schedule is not None and shape[-1] < 24:
+                continue      # the few-fields kernel: covered above
+            f = rng.standard_normal(shape)
+            fn = f.copy()
+            fn[rng.random(shape) < 0.15] = np.nan
+            for field, mode, thr in ((f, engine.MODE_FRACB, None),
+                                     (fn, engine.MODE_MASKED, 0.1),
+                                     (f.astype(np.float32),
+                                      engine.MODE_FRACB, None)):
+                arg = field if thr is None else np.ma.masked_array(
+                    field, np.isnan(field))
+                ref = oracle.remap_numpy_array(csr, frac_b, (12, 9), arg,
+                                               axes, thr).filled(np.nan)
+                y = engine.remap_tensor(
+                    plan, (12, 9), torch.from_numpy(field).to(dev), axes,
+                    mode, threshold=thr or 0.0,
+                    tune=None if schedule is None else [10])
+                assert tuple(y.shape) == ref.shape, (shape, axes)
+                assert y.is_contiguous()
+                assert_bitwise(y.cpu().numpy(), ref,
+                               f'{shape} {axes} {schedule} {field.dtype}')
 
 
 def test_fma_flag_is_close_not_identical(problem, dev):
@@ -745,7 +762,7 @@ def test_auto_schedule_picks_by_reuse(dev):
 
 @pytest.mark.parametrize('rows', [8, 4])
 @pytest.mark.parametrize('grid', ['2d', '1d'])
-@pytest.mark.parametrize('K', [64, 128, 130, 320, 512])
+@pytest.mark.parametrize('K', [61, 64, 128, 130, 131, 320, 512])
 def test_rowgroup_kernel_bitwise(dev, grid, K, rows):
     from oracle import oracle
     from pyremap_amd import engine, synthetic
