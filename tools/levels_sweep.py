@@ -1,3 +1,11 @@
+#!/usr/bin/env python3
+"""
+(Time, nCells, nVertLevels) fields addressed in place on config 3's mapping,
+for the level counts real model output has (GPU box only): ms per launch,
+algorithmic GB/s and fraction of the 8 TB/s roofline per (Time, levels).
+
+    python tools/levels_sweep.py
+"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -6,9 +14,10 @@ dev = torch.device('cuda', 0)
 m = synthetic.make_config('config3', device=dev)
 plan = engine.RemapPlan.from_triplets(m.row, m.col, m.S, m.frac_b, m.n_a, m.n_b, device=dev)
 print(plan.auto_schedule(m.dst_dims))
-for T, L in ((8, 64), (8, 60), (8, 61), (10, 48), (8, 56), (5, 100), (8, 72), (8, 50), (9, 57)):
+for T, L in ((8, 64), (8, 60), (8, 61), (8, 80), (5, 100), (4, 128), (4, 137),
+             (16, 32), (1, 60), (1, 100)):
     xs = [torch.randn((T, m.n_a, L), device=dev, dtype=torch.float64) for _ in range(3)]
-    for mode, name in ((engine.MODE_FRACB, 'fracb'),):
+    for mode, name in ((engine.MODE_FRACB, 'fracb'), (engine.MODE_MASKED, 'masked')):
         if mode == engine.MODE_MASKED:
             for x in xs:
                 x[:, torch.rand(m.n_a, device=dev) < 0.25, L // 2:] = float('nan')
