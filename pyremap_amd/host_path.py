@@ -39,7 +39,18 @@ CHUNK_BYTES = 64 << 20
 #: bound.  Environment: PYREMAP_AMD_PINNED_LIMIT (bytes).
 PINNED_LIMIT = int(os.environ.get('PYREMAP_AMD_PINNED_LIMIT', 16 << 30))
 
+#: device buffers of the batch pipeline: this many chunk-sized slots each
+#: for the source and the result (bounded device memory whatever the field)
+RING_SLOTS = 4
+
+#: helper threads feeding pageable uploads (one stream each).  More than
+#: one does not help: two feeders on two streams were measured SLOWER (0.96 GB
+#: + 1.06 GB: 31-41 ms against 23.6; a 7.7 GB series 444-473 ms against
+#: 326-342) -- the runtime's pageable-copy staging is shared.
+N_UPLOADERS = 1
+
 _streams = {}
+_extra_streams = {}
 _pinned_alive = [0]
 _pinned_lock = threading.Lock()
 
@@ -73,6 +84,14 @@ def _side_streams(device):
         _streams[key] = (torch.cuda.Stream(device=device),
                          torch.cuda.Stream(device=device))
     return _streams[key]
+
+
+def _extra_stream(device, k):
+    torch = engine._torch()
+    key = (device.type, device.index, k)
+    if key not in _extra_streams:
+        _extra_streams[key] = torch.cuda.Stream(device=device)
+    return _extra_streams[key]
 
 
 def _prod(seq):
@@ -187,18 +206,20 @@ def _enqueue(plan, dst_grid_dims, values, host, remap_axes, lead, n_batch,
     """The transfers and launches of :func:`remap_host_array`."""
     torch = engine._torch()
     device = plan.device
-    x_d = torch.empty(values.shape, dtype=host.dtype, device=device)
-
+    single = not in_place or host_mask is not None or mode == 'auto' or \
+        n_batch < 2
     banded = in_place and host_mask is None and mode != 'auto' and \
         n_batch == 1 and lead == 0 and \
         values.nbytes >= 4 * CHUNK_BYTES and plan.n_b == plan.n_b_global
+    # (the batch pipeline below streams through chunk-sized buffers instead)
+    x_d = torch.empty(values.shape, dtype=host.dtype, device=device) \
+        if single or banded else None
     if banded:
         done = _banded_pipeline(plan, values, host, x_d, out_h, mask_h,
                                 mode, thr, flags, up, down, main)
         if done is not None:
             return Pending(done, out_h, mask_h, (pin_o, pin_m))
-    if not in_place or host_mask is not None or mode == 'auto' or \
-            n_batch < 2:
+    if single:
         # ---- one upload, one launch, one download -----------------
         x_d.copy_(host, non_blocking=True)
         poisoned = None
@@ -255,74 +276,115 @@ def _enqueue(plan, dst_grid_dims, values, host, remap_axes, lead, n_batch,
         return Pending(finished, out_h, mask_h, (pin_o, pin_m))
 
     # ---- pipelined: batches of leading dims, three streams ------------
+    # Device memory is a RING of chunk-sized buffers, not the whole field:
+    # a (Time, nCells, nVertLevels) series larger than HBM streams through
+    # (the reference holds it in RAM whole, remap_numpy.py:254-256; the
+    # result lives in host memory either way).
     emode = engine.MODE_MASKED if mode == 'masked' else engine.MODE_FRACB
-    y_d = torch.empty(out_shape, dtype=torch.float64, device=device)
-    m_d = torch.empty(out_shape, dtype=torch.uint8, device=device) \
-        if want_mask else None
-    lead_shape = list(values.shape[:lead])
-    xb = host.reshape([n_batch] + list(values.shape[lead:]))
-    xdb = x_d.reshape(xb.shape)
-    ydb = y_d.reshape([n_batch] + dst_shape +
-                      list(values.shape[lead + len(remap_axes):]))
-    ohb = out_h.reshape(ydb.shape)
-    mdb = m_d.reshape(ydb.shape) if want_mask else None
-    mhb = mask_h.reshape(ydb.shape) if want_mask else None
-    per_batch = max(xb[0].numel() * xb.element_size(),
-                    ydb[0].numel() * 8)
+    src_shape = list(values.shape[lead:])
+    tail_shape = list(values.shape[lead + len(remap_axes):])
+    xb = host.reshape([n_batch] + src_shape)
+    ohb = out_h.reshape([n_batch] + dst_shape + tail_shape)
+    mhb = mask_h.reshape(ohb.shape) if want_mask else None
+    per_batch = max(xb[0].numel() * xb.element_size(), ohb[0].numel() * 8)
     step = max(1, min(n_batch, CHUNK_BYTES // max(per_batch, 1)))
+    chunks = [(b0, min(b0 + step, n_batch))
+              for b0 in range(0, n_batch, step)]
+    ring = min(RING_SLOTS, len(chunks))
+    x_slots = [torch.empty([step] + src_shape, dtype=host.dtype,
+                           device=device) for _ in range(ring)]
+    y_slots = [torch.empty([step] + dst_shape + tail_shape,
+                           dtype=torch.float64, device=device)
+               for _ in range(ring)]
+    m_slots = [torch.empty(y_slots[0].shape, dtype=torch.uint8,
+                           device=device) for _ in range(ring)] \
+        if want_mask else None
     axes_b = [a - lead + 1 for a in remap_axes]
     start = torch.cuda.Event()
     start.record(main)
     up.wait_event(start)
     finished = None
-    chunks = [(b0, min(b0 + step, n_batch))
-              for b0 in range(0, n_batch, step)]
     # Uploads from PAGEABLE memory block the calling thread until the
     # bytes are on the device, downloads into pinned memory do not: a
     # helper thread feeds the `up` stream so that this thread can queue
     # launches and downloads meanwhile (measured, 0.96 GB up + 1.06 GB
     # down: 22 ms overlapped, 34 ms one after the other)
-    arrivals = queue.Queue()
+    # (For fields beyond the CPU caches the host memcpy inside a pageable
+    # upload, not PCIe, is the limit: a 7.7 GB series goes up and its 8.5 GB
+    # result comes down in 330 ms; see N_UPLOADERS.)
+    n_up = min(N_UPLOADERS, len(chunks))
+    ups = [up] + [_extra_stream(device, k) for k in range(1, n_up)]
+    for st in ups[1:]:
+        st.wait_event(start)
+    arrivals = [queue.Queue() for _ in range(n_up)]
+    consumed = [queue.Queue() for _ in range(n_up)]   # kernel-done events:
+    #                                                   an X slot is free
 
-    def uploader():
+    def uploader(k):
         try:
-            with torch.cuda.device(device), torch.cuda.stream(up):
-                for b0, b1 in chunks:
-                    xdb[b0:b1].copy_(xb[b0:b1], non_blocking=True)
+            with torch.cuda.device(device), torch.cuda.stream(ups[k]):
+                for i in range(k, len(chunks), n_up):
+                    b0, b1 = chunks[i]
+                    if i >= ring:
+                        free = consumed[k].get()
+                        if free is None:
+                            return           # the other side gave up
+                        ups[k].wait_event(free)
+                    x_slots[i % ring][:b1 - b0].copy_(xb[b0:b1],
+                                                      non_blocking=True)
                     ev = torch.cuda.Event()
-                    ev.record(up)
-                    arrivals.put(ev)
+                    ev.record(ups[k])
+                    arrivals[k].put(ev)
         except BaseException as exc:   # noqa: BLE001 - handed over
-            arrivals.put(exc)
+            arrivals[k].put(exc)
 
-    feeder = threading.Thread(target=uploader, daemon=True)
-    feeder.start()
-    for b0, b1 in chunks:
-        arrived = arrivals.get()
-        if isinstance(arrived, BaseException):
-            feeder.join()
-            raise arrived
-        main.wait_event(arrived)
-        engine.remap_tensor(
-            plan, dst_grid_dims, xdb[b0:b1], axes_b, emode,
-            threshold=thr if emode == engine.MODE_MASKED else 0.0,
-            want_mask=want_mask, flags=flags, out=ydb[b0:b1],
-            mask_out=mdb[b0:b1] if want_mask else None)
-        computed = torch.cuda.Event()
-        computed.record(main)
-        with torch.cuda.stream(down):
-            down.wait_event(computed)
-            ohb[b0:b1].copy_(ydb[b0:b1], non_blocking=True)
-            if want_mask:
-                mhb[b0:b1].copy_(mdb[b0:b1], non_blocking=True)
-            finished = torch.cuda.Event()
-            finished.record(down)
-    feeder.join()
-    x_d.record_stream(up)
-    y_d.record_stream(down)
-    if m_d is not None:
-        m_d.record_stream(down)
-    del lead_shape
+    feeders = [threading.Thread(target=uploader, args=(k,), daemon=True)
+               for k in range(n_up)]
+    for f in feeders:
+        f.start()
+    downloaded = []
+    try:
+        for i, (b0, b1) in enumerate(chunks):
+            arrived = arrivals[i % n_up].get()
+            if isinstance(arrived, BaseException):
+                raise arrived
+            n = b1 - b0
+            slot = i % ring
+            main.wait_event(arrived)
+            if i >= ring:
+                # the slot's previous result must be on its way out
+                main.wait_event(downloaded[i - ring])
+            engine.remap_tensor(
+                plan, dst_grid_dims, x_slots[slot][:n], axes_b, emode,
+                threshold=thr if emode == engine.MODE_MASKED else 0.0,
+                want_mask=want_mask, flags=flags, out=y_slots[slot][:n],
+                mask_out=m_slots[slot][:n] if want_mask else None)
+            computed = torch.cuda.Event()
+            computed.record(main)
+            # chunk i + ring takes this slot over
+            consumed[(i + ring) % n_up].put(computed)
+            with torch.cuda.stream(down):
+                down.wait_event(computed)
+                ohb[b0:b1].copy_(y_slots[slot][:n], non_blocking=True)
+                if want_mask:
+                    mhb[b0:b1].copy_(m_slots[slot][:n], non_blocking=True)
+                finished = torch.cuda.Event()
+                finished.record(down)
+            downloaded.append(finished)
+    except BaseException:
+        for q in consumed:
+            q.put(None)
+        for f in feeders:
+            f.join()
+        raise
+    for f in feeders:
+        f.join()
+    for st in ups:
+        for t in x_slots:
+            t.record_stream(st)
+
+    for t in y_slots + (m_slots or []):
+        t.record_stream(down)
     return Pending(finished, out_h, mask_h, (pin_o, pin_m))
 
 

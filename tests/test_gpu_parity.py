@@ -1402,6 +1402,25 @@ def test_host_arrays_pinned_pipelined_and_poisoned(dev):
                 assert np.array_equal(got[1], np.ma.getmaskarray(ref))
     finally:
         host_path.CHUNK_BYTES = old
+    # more chunks than ring slots: the device buffers are reused while the
+    # series streams through (7 batches, one per chunk, two slots)
+    old_ring = host_path.RING_SLOTS
+    host_path.CHUNK_BYTES = m.n_a * 40 * 8
+    host_path.RING_SLOTS = 2
+    try:
+        series = rng.standard_normal((7, m.n_a, 40))
+        series[3:, rng.random(m.n_a) < 0.3, 20:] = np.nan
+        ref = oracle.remap_numpy_array(
+            csr, mm['frac_b'], m.dst_dims,
+            np.ma.masked_array(series, np.isnan(series)), [1], 0.2)
+        data, mask = host_path.remap_host_array(
+            plan, m.dst_dims, series, [1], mode='masked', threshold=0.2,
+            want_mask=True).result()
+        assert_bitwise(data, np.ma.filled(ref, np.nan), 'ring of two')
+        assert np.array_equal(mask, np.ma.getmaskarray(ref))
+    finally:
+        host_path.CHUNK_BYTES = old
+        host_path.RING_SLOTS = old_ring
     # (n_a, K) fields: destination row blocks launched as their band of
     # source rows arrives, downloads under the remaining uploads
     flat = rng.standard_normal((m.n_a, 70))
