@@ -86,6 +86,21 @@ def _side_streams(device):
     return _streams[key]
 
 
+#: a field (source + result) larger than this fraction of the free device
+#: memory is not made resident whole to decide the masked/unmasked branch
+DEVICE_FRACTION = 0.5
+
+
+def _any_nan(values, chunk=CHUNK_BYTES):
+    """``np.isnan(values).any()`` with an early exit, chunk by chunk."""
+    flat = values.reshape(-1)
+    step = max(1, chunk // values.dtype.itemsize)
+    for i in range(0, flat.size, step):
+        if np.isnan(flat[i:i + step]).any():
+            return True
+    return False
+
+
 def _extra_stream(device, k):
     torch = engine._torch()
     key = (device.type, device.index, k)
@@ -185,6 +200,16 @@ def remap_host_array(plan, dst_grid_dims, values, remap_axes, *, mode,
     out_shape = list(values.shape[:lead]) + dst_shape + \
         list(values.shape[lead + len(remap_axes):])
 
+    if mode == 'auto' and in_place and n_batch >= 2 and host_mask is None:
+        # The branch is decided from the whole array (remap_numpy.py:201-204)
+        # and the device-side decision needs the whole array resident.  A
+        # series that would not leave HBM room takes the decision on the
+        # host instead -- chunk by chunk, stopping at the first NaN (ocean
+        # data shows one within the first levels) -- and then streams.
+        need = values.nbytes + _prod(out_shape) * 8
+        free, _ = torch.cuda.mem_get_info(device)
+        if need > DEVICE_FRACTION * free:
+            mode = 'masked' if _any_nan(values) else 'fracb'
     with torch.cuda.device(device):
         out_h, pin_o = _host_buffer(out_shape, torch.float64)
         mask_h, pin_m = _host_buffer(out_shape, torch.uint8) \

@@ -1418,6 +1418,23 @@ def test_host_arrays_pinned_pipelined_and_poisoned(dev):
             want_mask=True).result()
         assert_bitwise(data, np.ma.filled(ref, np.nan), 'ring of two')
         assert np.array_equal(mask, np.ma.getmaskarray(ref))
+        # a series "too large" to be resident whole: the NaN decision is
+        # taken on the host, the data streams
+        old_fraction = host_path.DEVICE_FRACTION
+        host_path.DEVICE_FRACTION = 0.0
+        try:
+            for field, masked in ((series, True), (series[:3], False)):
+                got = host_path.remap_host_array(
+                    plan, m.dst_dims, field, [1], mode='auto',
+                    threshold=0.2).result()
+                want = oracle.remap_numpy_array(
+                    csr, mm['frac_b'], m.dst_dims,
+                    np.ma.masked_array(field, np.isnan(field)) if masked
+                    else field, [1], 0.2 if masked else None)
+                assert_bitwise(got, np.ma.filled(want, np.nan),
+                               f'streamed auto, masked={masked}')
+        finally:
+            host_path.DEVICE_FRACTION = old_fraction
     finally:
         host_path.CHUNK_BYTES = old
         host_path.RING_SLOTS = old_ring
