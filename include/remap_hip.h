@@ -225,7 +225,8 @@ typedef struct remap_apply_args {
      *                         6 = 1 with row metadata through the scalar
      *                             cache (needs csr_pad >= 8; the default)
      * tune[1] doubles per lane per tile (1 or 2); family 10: waves per
-     *         workgroup (1, 2; else 4)
+     *         workgroup (1, 2; else 4); family 2: entries of a row fetched
+     *         together (1, 4 or 8)
      * tune[2] K tiles per wave (1, 2 or 4)
      * tune[3] consecutive rows per wave
      * tune[4] block -> work map: 1 = as dispatched, 2 = XCD-contiguous

@@ -90,20 +90,32 @@ kernel_fn pick_rowwave_shape(int vec, int tiles, int mode, bool fma)
     }
 }
 
-template <typename XT>
-kernel_fn pick_rowlane(int mode, bool fma)
+template <typename XT, int UNR>
+kernel_fn pick_rowlane_mode(int mode, bool fma)
 {
     switch (mode) {
     case REMAP_MODE_RAW:
-        return fma ? spmm_rowlane<XT, REMAP_MODE_RAW, true>
-                   : spmm_rowlane<XT, REMAP_MODE_RAW, false>;
+        return fma ? spmm_rowlane<XT, REMAP_MODE_RAW, true, UNR>
+                   : spmm_rowlane<XT, REMAP_MODE_RAW, false, UNR>;
     case REMAP_MODE_FRACB:
-        return fma ? spmm_rowlane<XT, REMAP_MODE_FRACB, true>
-                   : spmm_rowlane<XT, REMAP_MODE_FRACB, false>;
+        return fma ? spmm_rowlane<XT, REMAP_MODE_FRACB, true, UNR>
+                   : spmm_rowlane<XT, REMAP_MODE_FRACB, false, UNR>;
     default:
-        return fma ? spmm_rowlane<XT, REMAP_MODE_MASKED, true>
-                   : spmm_rowlane<XT, REMAP_MODE_MASKED, false>;
+        return fma ? spmm_rowlane<XT, REMAP_MODE_MASKED, true, UNR>
+                   : spmm_rowlane<XT, REMAP_MODE_MASKED, false, UNR>;
     }
+}
+
+// entries fetched together per lane: 4 (config 3's map, us per launch with
+// 1 / 4 / 8: K = 1 10.7 / 11.3 / 10.3 -- the launch floor; K = 12 33.9 /
+// 28.7 / 30.0; K = 32 70.5 / 59.8 / 67.1; config 1's bilinear map, K = 4:
+// 10.6 / 10.6 / 13.3); tune[1] = 1, 4 or 8 overrides
+template <typename XT>
+kernel_fn pick_rowlane(int unr, int mode, bool fma)
+{
+    return unr == 1   ? pick_rowlane_mode<XT, 1>(mode, fma)
+           : unr == 4 ? pick_rowlane_mode<XT, 4>(mode, fma)
+                      : pick_rowlane_mode<XT, 8>(mode, fma);
 }
 
 template <typename XT, int SUB, bool TREE>
@@ -620,8 +632,11 @@ int run_rowlane(const remap_apply_args *a, const Call &c, const KParams &p,
         return fail(REMAP_ERR_UNSUPPORTED,
                     "remap_apply_f64: grid of %lld blocks; split the rows",
                     (long long)grid);
-    return launch_plain(c.f32 ? pick_rowlane<float>(a->mode, c.fma)
-                              : pick_rowlane<double>(a->mode, c.fma),
+    int unr = a->tune[1];
+    if (unr != 1 && unr != 4 && unr != 8)
+        unr = 4;
+    return launch_plain(c.f32 ? pick_rowlane<float>(unr, a->mode, c.fma)
+                              : pick_rowlane<double>(unr, a->mode, c.fma),
                         a, p, grid, stream);
 }
 

@@ -1237,7 +1237,8 @@ FEW_LAYOUTS = [
 ]
 
 
-@pytest.mark.parametrize('tune', [None, [2], [3], [3, 4], [3, 8]])
+@pytest.mark.parametrize('tune', [None, [2], [2, 1], [2, 4], [3], [3, 4],
+                                  [3, 8]])
 @pytest.mark.parametrize('layout', FEW_LAYOUTS, ids=[f[0] for f in
                                                     FEW_LAYOUTS])
 def test_few_fields_kernels_bitwise(problem, dev, layout, tune):
