@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define REMAP_ABI_VERSION 16
+#define REMAP_ABI_VERSION 17
 
 enum {
     REMAP_OK = 0,

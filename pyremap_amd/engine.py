@@ -33,7 +33,7 @@ FLAG_TREE = 8
 DTYPE_F64 = 0
 DTYPE_F32 = 1
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 #: readable pad entries kept behind col/val (remap_csr.csr_pad)
 CSR_PAD = 8
