@@ -1,6 +1,8 @@
 // spmm_device.h -- KParams, loads/stores, the fused epilogue, the block map.
 // Part of remap_spmm.hip: included there inside namespace remap::(anonymous),
 // in the order given there; not a stand-alone header.
+constexpr uint32_t kBatchPerChunk = 0xffffffffu;   // KParams.bpc
+
 struct KParams {
     const int64_t *__restrict__ rowptr;
     const int32_t *__restrict__ col;
@@ -20,7 +22,9 @@ struct KParams {
     uint32_t K;
     uint32_t k_inner;
     uint32_t bpc;          // whole batches per K tile (0: tiles cut the flat
-                           // column list every kWave * VEC columns)
+                           // column list every kWave * VEC columns;
+                           // kBatchPerChunk: the tiles of a chunk share ONE
+                           // batch, tile t holding its columns from t * CH)
     int32_t rows_per_wave;
     int32_t xcd_map;
     uint32_t x_range;      // bytes addressable from a source row base
@@ -228,6 +232,18 @@ __device__ __forceinline__ void tile_offsets(
     int64_t (&yoff)[TILES], bool (&act)[TILES])
 {
     constexpr int CH = kWave * VEC;
+    if (p.bpc == kBatchPerChunk) {
+        // one batch per chunk: level runs longer than a tile (65, 81, 101
+        // levels at one element per lane) stay inside one wave
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) {
+            const uint32_t k = t * CH + lane * VEC;
+            act[t] = k < p.k_inner;
+            xoff[t] = act[t] ? chunk * p.bsx + k : 0;
+            yoff[t] = act[t] ? chunk * p.bsy + k : 0;
+        }
+        return;
+    }
     if (p.bpc) {
         // Batch-aligned tiles: a tile holds `bpc` WHOLE batches (level
         // columns of (Time, nCells, 60 levels): 2 x 60 of a wave's 128

@@ -275,6 +275,7 @@ def test_layouts_bitwise(dev):
         # batches left over in the last chunk
         ((5, 300, 60), [1]), ((3, 300, 61), [1]), ((7, 300, 24), [1]),
         ((5, 300, 100), [1]), ((5, 300, 50), [1]), ((2, 2, 300, 60), [2]),
+        ((3, 300, 65), [1]), ((2, 300, 101), [1]), ((2, 300, 127), [1]),
     ]
     for schedule in (None, 4, 8):
         if schedule is None:
