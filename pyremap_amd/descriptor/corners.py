@@ -60,7 +60,9 @@ def _cf_bounds(ds, var_name, shape, stacklevel):
 
 
 def _tolerance(bounds):
-    """1e-6 of the largest centre-to-vertex distance (``utility.py:132-136``)."""
+    """
+    1e-6 of the largest centre-to-vertex distance (``utility.py:132-136``).
+    """
     mid = bounds.mean(axis=-1, keepdims=True)
     return 1e-6 * np.abs(bounds - mid).max()
 

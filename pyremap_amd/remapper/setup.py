@@ -5,7 +5,6 @@ the behaviour of the reference's ``_setup_remapper``
 (``pyremap/remapper/descriptor.py:21-199``) for the grid kinds that can be
 described without pyproj.
 """
-import numpy as np
 
 from pyremap_amd.descriptor import (
     LatLon2DGridDescriptor,

@@ -24,7 +24,6 @@ on the GPU; with ``device='cpu'`` they serve the CPU tests.
   source cell goes unread (``cover``): configs 2, 3, 5 and the north-star
   headline H.
 """
-import math
 
 CONFIGS = {
     # name: kind, source, destination dims (C order), entries/row, fields
