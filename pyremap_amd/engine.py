@@ -313,6 +313,10 @@ class RemapPlan:
         self._extent_cache = {}
         #: launch tuning used when a call passes none (set by auto_schedule)
         self.default_tune = None
+        # schedule attributes are properties: every assignment invalidates
+        # the prefilled argument block launches start from (_prefilled)
+        self._sched_version = 0
+        self._args_cache = {}
         #: optional LDS-staging schedule (see build_patches)
         self.patches = None
         #: optional row-group schedule (see build_groups)
@@ -320,6 +324,75 @@ class RemapPlan:
         #: optional int32 permutation of the rows: the order in which work
         #: slots visit them (scheduling only; see set_row_order)
         self.row_order = None
+
+    def _sched_property(name):   # noqa: N805 - class-body helper
+        def get(self):
+            return self.__dict__.get('_' + name)
+
+        def put(self, value):
+            self.__dict__['_' + name] = value
+            self._sched_version += 1
+        return property(get, put)
+
+    patches = _sched_property('patches')
+    groups = _sched_property('groups')
+    row_order = _sched_property('row_order')
+    del _sched_property
+
+    def _prefilled(self, whole):
+        """
+        A fresh ``remap_apply_args`` with everything that belongs to the plan
+        filled in -- the CSR and, for a launch over the whole row range, the
+        row order and the schedule that goes with it -- copied from a block
+        built once per schedule version (a Dataset of small variables is
+        launch-overhead-bound: 2 launches per variable).
+        """
+        hit = self._args_cache.get(whole)
+        if hit is not None and hit[0] == self._sched_version:
+            return _ApplyArgs.from_buffer_copy(hit[1])
+        args = _ApplyArgs()
+        args.A.n_rows = self.n_b
+        args.A.n_cols = self.n_a
+        args.A.nnz = self.nnz
+        args.A.rowptr = self.rowptr.data_ptr()
+        args.A.col = self.col.data_ptr()
+        args.A.val = self.val.data_ptr()
+        args.A.max_row_nnz = self.max_row_nnz
+        args.A.csr_pad = self.csr_pad
+        order = self.row_order
+        if whole:
+            # (a stored order permutes the whole row range: partial ranges
+            # run without it, and without the schedules built on it)
+            args.row_order = order.data_ptr() if order is not None else None
+
+            def same_order(sched):
+                return (order is None) == (sched['order'] is None) and (
+                    order is None or
+                    order.data_ptr() == sched['order'].data_ptr())
+            patches = self.patches
+            if patches is not None and same_order(patches):
+                args.patch_ptr = patches['ptr'].data_ptr()
+                args.patch_ucol = patches['ucol'].data_ptr()
+                args.patch_rowptr = patches['rowptr'].data_ptr()
+                args.patch_lidx = patches['lidx'].data_ptr()
+                args.patch_val = patches['val'].data_ptr()
+                args.patch_rows = patches['rows']
+                args.patch_umax = patches['umax']
+                args.patch_emax = patches['emax']
+                args.patch_row_bytes = patches['row_bytes']
+                args.n_patches = patches['n']
+            groups = self.groups
+            if groups is not None and same_order(groups):
+                args.group_meta = groups['meta'].data_ptr()
+                args.group_col = groups['col'].data_ptr()
+                args.group_w = groups['w'].data_ptr()
+                args.group_mask = groups['mask'].data_ptr()
+                args.group_rid = groups['rid'].data_ptr()
+                args.group_frac = groups['frac'].data_ptr()
+                args.n_groups = groups['n']
+                args.group_rows = groups['rows']
+        self._args_cache[whole] = (self._sched_version, bytes(args))
+        return args
 
     # -- construction -------------------------------------------------------
     @classmethod
@@ -876,17 +949,10 @@ def apply_strided(plan, X, Y, *, n_batch, k_inner, x_row_stride,
     if mask_out is not None and (mask_out.dtype != torch.uint8 or
                                  mask_out.device != plan.device):
         raise TypeError('mask_out must be a uint8 tensor on the plan device')
-    args = _ApplyArgs()
-    args.A.n_rows = plan.n_b
-    args.A.n_cols = plan.n_a
-    args.A.nnz = plan.nnz
-    args.A.rowptr = plan.rowptr.data_ptr()
-    args.A.col = plan.col.data_ptr()
-    args.A.val = plan.val.data_ptr()
-    args.A.max_row_nnz = plan.max_row_nnz
-    args.A.csr_pad = plan.csr_pad
+    end = plan.n_b if row_end is None else row_end
+    args = plan._prefilled(row_begin == 0 and end == plan.n_b)
     args.row_begin = row_begin
-    args.row_end = plan.n_b if row_end is None else row_end
+    args.row_end = end
     args.X = X.data_ptr()
     args.x_dtype = x_dtype
     args.mode = mode
@@ -900,39 +966,6 @@ def apply_strided(plan, X, Y, *, n_batch, k_inner, x_row_stride,
     args.frac_b = plan.frac_b.data_ptr() if mode == MODE_FRACB else None
     args.threshold = float(threshold)
     args.mask_out = mask_out.data_ptr() if mask_out is not None else None
-    order = plan.row_order
-    if order is not None and (row_begin != 0 or
-                              args.row_end != plan.n_b):
-        order = None    # the stored order permutes the whole row range
-    args.row_order = order.data_ptr() if order is not None else None
-    patches = plan.patches
-    if patches is not None and row_begin == 0 and args.row_end == plan.n_b \
-            and (plan.row_order is None) == (patches['order'] is None) \
-            and (plan.row_order is None or
-                 plan.row_order.data_ptr() == patches['order'].data_ptr()):
-        args.patch_ptr = patches['ptr'].data_ptr()
-        args.patch_ucol = patches['ucol'].data_ptr()
-        args.patch_rowptr = patches['rowptr'].data_ptr()
-        args.patch_lidx = patches['lidx'].data_ptr()
-        args.patch_val = patches['val'].data_ptr()
-        args.patch_rows = patches['rows']
-        args.patch_umax = patches['umax']
-        args.patch_emax = patches['emax']
-        args.patch_row_bytes = patches['row_bytes']
-        args.n_patches = patches['n']
-    groups = plan.groups
-    if groups is not None and row_begin == 0 and args.row_end == plan.n_b \
-            and (plan.row_order is None) == (groups['order'] is None) \
-            and (plan.row_order is None or
-                 plan.row_order.data_ptr() == groups['order'].data_ptr()):
-        args.group_meta = groups['meta'].data_ptr()
-        args.group_col = groups['col'].data_ptr()
-        args.group_w = groups['w'].data_ptr()
-        args.group_mask = groups['mask'].data_ptr()
-        args.group_rid = groups['rid'].data_ptr()
-        args.group_frac = groups['frac'].data_ptr()
-        args.n_groups = groups['n']
-        args.group_rows = groups['rows']
     if gate is not None:
         if gate.dtype != torch.int32 or gate.device != plan.device:
             raise TypeError('gate must be an int32 tensor on the plan device')
@@ -950,10 +983,15 @@ def apply_strided(plan, X, Y, *, n_batch, k_inner, x_row_stride,
     if tune:
         for i, v in enumerate(tune):
             args.tune[i] = int(v)
-    with torch.cuda.device(plan.device):
-        _check(lib.remap_apply_f64(ctypes.byref(args),
-                                   _stream_ptr(plan.device)),
+    stream = ctypes.c_void_p(
+        torch.cuda.current_stream(plan.device).cuda_stream)
+    if torch.cuda.current_device() == plan.device.index:
+        _check(lib.remap_apply_f64(ctypes.byref(args), stream),
                'remap_apply_f64')
+    else:
+        with torch.cuda.device(plan.device):
+            _check(lib.remap_apply_f64(ctypes.byref(args), stream),
+                   'remap_apply_f64')
 
 
 def _prod(seq):
