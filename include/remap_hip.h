@@ -195,7 +195,7 @@ typedef struct remap_apply_args {
      * column order, so results are unchanged.                              */
     const int64_t *group_meta;  /* (device) 2 * (n_groups + 1)              */
     const int32_t *group_col;   /* (device) union entries (+ 32 readable)   */
-    const double *group_w;      /* (device) present weights (+ 64 readable) */
+    const double *group_w;      /* (device) present weights (+ 128 readable) */
     const int32_t *group_mask;  /* (device) union entries (+ 32)            */
     const int32_t *group_rid;   /* (device) n_groups * group_rows           */
     const double *group_frac;   /* (device) n_groups * group_rows           */
@@ -294,7 +294,7 @@ int remap_csr_from_coo(int64_t n_rows, int64_t n_cols, int64_t nnz,
  *                remap_apply_args.row_order together with the schedule
  *   group_meta   (device) 2 * (n_groups + 1)     n_groups = ceil(n_rows / G)
  *   group_col, group_mask  (device) A.nnz + 32 each (union entries <= nnz)
- *   group_w      (device) A.nnz + 64
+ *   group_w      (device) A.nnz + 128
  *   group_rid, group_frac  (device) n_groups * G
  *   n_union_out  (device) one int64: union entries actually used
  */

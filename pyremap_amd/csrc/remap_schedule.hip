@@ -314,7 +314,7 @@ int groups_build(const remap_csr *A, const double *frac_b, int32_t G,
     REMAP_HIP_CHECK((rocprim::radix_sort_pairs(
         temp, tb, static_cast<const uint64_t *>(k_in), k_out, A->val, gw,
         static_cast<size_t>(nnz), 0u, 64u, stream)));
-    REMAP_HIP_CHECK(hipMemsetAsync(gw + nnz, 0, 64 * sizeof(double), stream));
+    REMAP_HIP_CHECK(hipMemsetAsync(gw + nnz, 0, 128 * sizeof(double), stream));
     // 3. union entries
     hipLaunchKernelGGL(flag_union_heads, dim3(blocks_for(nnz)), dim3(kBlock),
                        0, stream, nnz, G, k_out, head);
@@ -765,7 +765,7 @@ size_t arena_need(int64_t n_rows, int64_t nnz)
                          align_g(ne * 8);
     const size_t n_groups = nr / 4 + 2;
     const size_t group = align_g(2 * (n_groups + 1) * 8) +
-                         2 * align_g((ne + 32) * 4) + align_g((ne + 64) * 8) +
+                         2 * align_g((ne + 32) * 4) + align_g((ne + 128) * 8) +
                          align_g(n_groups * 8 * 4) + align_g(n_groups * 8 * 8);
     return order + (patch > group ? patch : group) + align_g(64);
 }
@@ -933,7 +933,7 @@ int schedule_auto(const remap_csr *A, const double *frac_b,
         int64_t *meta = arena.take<int64_t>(2 * (n_groups + 1));
         int32_t *gcol = arena.take<int32_t>(nnz + 32);
         int32_t *gmask = arena.take<int32_t>(nnz + 32);
-        double *gw = arena.take<double>(nnz + 64);
+        double *gw = arena.take<double>(nnz + 128);
         int32_t *rid = arena.take<int32_t>(n_groups * G);
         double *gfrac = arena.take<double>(n_groups * G);
         if (!gfrac)

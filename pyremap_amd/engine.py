@@ -698,7 +698,7 @@ class RemapPlan:
         meta = torch.empty((n_groups + 1, 2), dtype=torch.int64, device=dev)
         col = torch.empty(self.nnz + 32, dtype=torch.int32, device=dev)
         mask = torch.empty(self.nnz + 32, dtype=torch.int32, device=dev)
-        w = torch.empty(self.nnz + 64, dtype=torch.float64, device=dev)
+        w = torch.empty(self.nnz + 128, dtype=torch.float64, device=dev)
         rid = torch.empty(n_groups * G, dtype=torch.int32, device=dev)
         frac = torch.empty(n_groups * G, dtype=torch.float64, device=dev)
         order = torch.empty(self.n_b, dtype=torch.int32, device=dev) \
@@ -824,7 +824,7 @@ class RemapPlan:
                 meta=view(sched.group_meta, 2 * (n_g + 1),
                           torch.int64).reshape(n_g + 1, 2),
                 col=view(sched.group_col, nu + 32, torch.int32),
-                w=view(sched.group_w, self.nnz + 64, torch.float64),
+                w=view(sched.group_w, self.nnz + 128, torch.float64),
                 mask=view(sched.group_mask, nu + 32, torch.int32),
                 rid=view(sched.group_rid, n_g * G, torch.int32),
                 frac=view(sched.group_frac, n_g * G, torch.float64),

@@ -781,7 +781,7 @@ def test_rowgroup_kernel_bitwise(dev, grid, K, rows):
     assert (plan.row_order is not None) == (grid == '2d')
     assert plan.groups['rows'] == rows
     # the weights are stored once each: nnz of them (+ the readable pad)
-    assert plan.groups['w'].numel() == plan.nnz + 64
+    assert plan.groups['w'].numel() == plan.nnz + 128
     csr = oracle.coo_to_csr(mm['row'] - 1, mm['col'] - 1, mm['S'], m.n_b,
                             m.n_a)
     rng = np.random.default_rng(K)
