@@ -22,6 +22,8 @@ from collections import OrderedDict
 
 import numpy as np
 
+from pyremap_amd.io import _parallel
+
 SIGNATURE = b'\x89HDF\r\n\x1a\n'
 
 MSG_DATASPACE = 0x01
@@ -780,8 +782,18 @@ class Dataset(_Object):
                 filled = self._filled(count)
                 return filled.reshape(shape) if typ.dtype is not None \
                     else filled
-            return self._finish(mm[address:address + count * typ.size],
-                                count)
+            nbytes = count * typ.size
+            if typ.kind == 'numeric' and typ.dtype is not None and \
+                    nbytes >= _parallel.MIN_BYTES:
+                # a large contiguous dataset: one pass, on several cores,
+                # straight from the mapping (slicing an mmap copies it once
+                # and decode() once more)
+                view = np.frombuffer(mm, dtype=np.uint8, count=nbytes,
+                                     offset=address).view(typ.dtype)
+                out = _parallel.convert(view, typ.dtype)
+                del view
+                return out.reshape(shape)
+            return self._finish(mm[address:address + nbytes], count)
         if cls != 2:
             raise NotImplementedError(f'data layout class {cls}')
         if typ.dtype is None:

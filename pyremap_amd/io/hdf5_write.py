@@ -24,6 +24,8 @@ from collections import OrderedDict
 
 import numpy as np
 
+from pyremap_amd.io import _parallel
+
 UNDEF = 0xFFFFFFFFFFFFFFFF
 _SIG = b'\x89HDF\r\n\x1a\n'
 _PURE_DIM = 'This is a netCDF dimension but not a netCDF variable.'
@@ -131,10 +133,12 @@ class _Dataset:
 
 
 def write_netcdf4(filename, dimensions, variables, attrs=None,
-                  unlimited=()):
+                  unlimited=(), nan_fill=None):
     """
     ``dimensions``: ordered name -> length; ``variables``: iterable of
     ``(name, dims, ndarray, attrs)``; ``attrs``: global attributes;
+    ``nan_fill``: variable name -> value stored in place of its NaNs
+    (substituted chunk by chunk while writing);
     ``unlimited`` is accepted and ignored: record dimensions are written at
     their current length (HDF5 allows unlimited maxima only with chunked
     storage; this writer stores contiguously).
@@ -251,9 +255,13 @@ def write_netcdf4(filename, dimensions, variables, attrs=None,
 
     # -- pass 2: bytes -------------------------------------------------------
     with open(filename, 'wb') as f:
-        def put(addr, blob):
+        def put(addr, blob, fill=None):
             f.seek(addr)
-            f.write(blob)
+            if isinstance(blob, np.ndarray):
+                # large arrays: several cores
+                _parallel.write_at(f, blob, nan_fill=fill)
+            else:
+                f.write(blob)
 
         sb = _SIG + struct.pack('<BBBBBBBB', 0, 0, 0, 0, 0, 8, 8, 0)
         sb += struct.pack('<HHI', leaf_k, internal_k, 0)
@@ -297,7 +305,7 @@ def write_netcdf4(filename, dimensions, variables, attrs=None,
                 _object_header(dataset_messages(ds, gheap_addr)))
             if ds.data_addr is not None:
                 # the array's own memory goes to the file (no tobytes copy)
-                put(ds.data_addr, ds.data.reshape(-1).view(np.uint8)
+                put(ds.data_addr, ds.data
                     if ds.data.dtype.kind in 'iuf' and ds.data.size
-                    else ds.data.tobytes())
+                    else ds.data.tobytes(), (nan_fill or {}).get(name))
         f.truncate(eof)

@@ -19,7 +19,7 @@ from collections import OrderedDict
 import numpy as np
 
 from pyremap_amd import xr_lite
-from pyremap_amd.io import netcdf3
+from pyremap_amd.io import _parallel, netcdf3
 
 #: netCDF4.default_fillvals (netCDF4 is not installed here)
 DEFAULT_FILLVALS = {
@@ -60,12 +60,13 @@ def _decode(data, attrs):
         if data.dtype.kind != 'f':
             data = data.astype(np.float32 if data.dtype.itemsize <= 2
                                else np.float64)
-        else:
+        elif not (data.flags['WRITEABLE'] and data.flags['C_CONTIGUOUS']):
             data = np.array(data, copy=True)
+        # (else: the readers hand over fresh arrays nobody else holds)
         for fv in fills:
             fv = np.asarray(fv).astype(data.dtype)
             if not np.isnan(fv):
-                data[data == fv] = np.nan
+                _parallel.replace_value(data, fv, np.nan)
         if scale is not None:
             encoding['scale_factor'] = scale
             data = data * np.asarray(scale, dtype=data.dtype)
@@ -159,11 +160,14 @@ def write_netcdf(ds, filename, format='NETCDF3_64BIT', fillvalues=None,
         data = np.asarray(var.values)
         attrs = OrderedDict((k, v) for k, v in var.attrs.items()
                             if k != '_FillValue')
-        if data.dtype.kind == 'f' and np.isnan(data).any():
+        nan_fill = None
+        if data.dtype.kind == 'f' and _parallel.any_nan(data):
             key = f'{data.dtype.kind}{data.dtype.itemsize}'
             if key in fillvalues:
+                # the writers substitute the fill value chunk by chunk: no
+                # full-size mask or copy of a field as large as memory allows
                 fv = np.asarray(fillvalues[key]).astype(data.dtype)
-                data = np.where(np.isnan(data), fv, data)
+                nan_fill = fv
                 attrs['_FillValue'] = fv
         if data.dtype.kind in 'SU' and data.dtype.itemsize != 1:
             # fixed-width strings -> char array with a string dimension
@@ -180,7 +184,8 @@ def write_netcdf(ds, filename, format='NETCDF3_64BIT', fillvalues=None,
                 dimensions.setdefault(dim, None)
             else:
                 dimensions.setdefault(dim, int(size))
-        out_vars.append(netcdf3.Variable(name, dims, data, attrs))
+        out_vars.append(netcdf3.Variable(name, dims, data, attrs,
+                                         nan_fill=nan_fill))
     # the record dimension must lead its variables; demote it otherwise
     for dim in [d for d, length in dimensions.items() if length is None]:
         if any(dim in v.dims[1:] for v in out_vars):
@@ -211,7 +216,9 @@ def write_netcdf(ds, filename, format='NETCDF3_64BIT', fillvalues=None,
                       [(v.name, v.dims, v.data, v.attrs) for v in out_vars],
                       attrs=attrs,
                       unlimited=[d for d, n in dimensions.items()
-                                 if n is None])
+                                 if n is None],
+                      nan_fill={v.name: v.nan_fill for v in out_vars
+                                if v.nan_fill is not None})
         return
     netcdf3.write(filename, dimensions, out_vars, attrs=attrs,
                   version=version)

@@ -19,6 +19,8 @@ from collections import OrderedDict
 
 import numpy as np
 
+from pyremap_amd.io import _parallel
+
 NC_DIMENSION = 10
 NC_VARIABLE = 11
 NC_ATTRIBUTE = 12
@@ -48,12 +50,16 @@ def _pad4(n):
 class Variable:
     """A variable of a classic-format file."""
 
-    def __init__(self, name, dims, data, attrs=None, is_record=False):
+    def __init__(self, name, dims, data, attrs=None, is_record=False,
+                 nan_fill=None):
         self.name = name
         self.dims = tuple(dims)
         self.data = data
         self.attrs = OrderedDict(attrs) if attrs else OrderedDict()
         self.is_record = is_record
+        #: when writing: the value stored in place of NaNs (the writer
+        #: substitutes it chunk by chunk; ``data`` keeps its NaNs)
+        self.nan_fill = nan_fill
 
     @property
     def dtype(self):
@@ -220,7 +226,7 @@ def read(filename):
                                  offset=begin).reshape(shape)
             rec = False
         if dt.kind != 'S':
-            data = data.astype(dt.newbyteorder('='))
+            data = _parallel.convert(data, dt.newbyteorder('='))
         else:
             data = np.array(data)
         nc.variables[name] = Variable(name, dims, data, attrs, rec)
@@ -306,34 +312,18 @@ def _storable(arr, version):
     return arr
 
 
-#: elements are converted and written this many bytes at a time
-_WRITE_CHUNK = 16 << 20
-
-
-def _write_big_endian(f, data):
+def _write_big_endian(f, data, nan_fill=None):
     """
-    Write ``data`` in C order as big-endian bytes, ``_WRITE_CHUNK`` at a time
-    through one reusable buffer: a remapped field is as large as memory
-    allows, and ``astype('>f8').tobytes()`` would hold two more copies of it.
-    Returns the number of bytes written.
+    Write ``data`` in C order as big-endian bytes through small reusable
+    buffers (a remapped field is as large as memory allows:
+    ``astype('>f8').tobytes()`` would hold two more copies of it), large
+    arrays on several cores.  Returns the number of bytes written.
     """
     data = np.asarray(data)
-    if data.size == 0:
-        return 0
-    if data.dtype.kind == 'S' or data.dtype.itemsize == 1 or \
-            data.dtype.byteorder == '>':
-        raw = np.ascontiguousarray(data)
-        f.write(raw.reshape(-1).view(np.uint8))
-        return raw.nbytes
-    flat = data.reshape(-1) if data.flags['C_CONTIGUOUS'] else \
-        np.ascontiguousarray(data).reshape(-1)
-    step = max(1, _WRITE_CHUNK // data.dtype.itemsize)
-    buf = np.empty(min(step, flat.size), dtype=data.dtype.newbyteorder('>'))
-    for i in range(0, flat.size, step):
-        n = min(step, flat.size - i)
-        buf[:n] = flat[i:i + n]          # converts and swaps in one pass
-        f.write(buf[:n].view(np.uint8))
-    return flat.size * data.dtype.itemsize
+    if data.dtype.kind == 'S' or data.dtype.itemsize == 1:
+        return _parallel.write_at(f, data)
+    return _parallel.write_at(f, data, data.dtype.newbyteorder('>'),
+                              nan_fill=nan_fill)
 
 
 def write(filename, dimensions, variables, attrs=None, version=2):
@@ -425,12 +415,12 @@ def write(filename, dimensions, variables, attrs=None, version=2):
         for var, data, rec in prepared:
             if rec:
                 continue
-            n = _write_big_endian(f, data)
+            n = _write_big_endian(f, data, var.nan_fill)
             f.write(b'\x00' * (_pad4(n) - n))
         for r in range(numrecs if rec_list else 0):
-            for _, data, _ in rec_list:
+            for var, data, _ in rec_list:
                 if r < data.shape[0]:
-                    n = _write_big_endian(f, data[r:r + 1])
+                    n = _write_big_endian(f, data[r:r + 1], var.nan_fill)
                 else:
                     n = vsize(data, True) if data.shape[0] else 0
                     f.write(b'\x00' * n)
