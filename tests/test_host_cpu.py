@@ -613,3 +613,43 @@ def test_integration_stub_matches_the_binding():
     names = re.findall(r"\('(\w+)',", block)
     assert names == [f[0] for f in engine._Schedule._fields_]
     assert f'remap_abi_version() == {engine.ABI_VERSION}' in text
+
+
+@pytest.mark.parametrize('fmt', ['NETCDF3_64BIT_DATA', 'NETCDF3_64BIT',
+                                 'NETCDF4'])
+def test_threaded_file_io_writes_the_same_bytes(tmp_path, fmt, monkeypatch):
+    """
+    Large arrays are converted / fill-substituted / written in chunks on
+    several threads (pyremap_amd/io/_parallel.py).  With the size thresholds
+    lowered so that small arrays take that route: the files are byte for byte
+    the ones the serial route writes, and they read back to the same values.
+    """
+    from pyremap_amd import DataArray, Dataset
+    from pyremap_amd.io import _parallel
+    from pyremap_amd.io.netcdf import open_dataset, write_netcdf
+    rng = np.random.default_rng(5)
+    ds = Dataset(attrs={'title': 'threads'})
+    big = rng.standard_normal((3, 257, 33))
+    big[1, 100:140, :] = np.nan
+    ds['holed'] = DataArray(big, dims=('Time', 'nCells', 'lev'))
+    ds['f32'] = DataArray(rng.standard_normal((3, 257)).astype(np.float32),
+                          dims=('Time', 'nCells'))
+    ds['static'] = DataArray(rng.standard_normal((257, 33)),
+                             dims=('nCells', 'lev'))
+    ds['count'] = DataArray(np.arange(257 * 33, dtype=np.int32).reshape(
+        257, 33), dims=('nCells', 'lev'))
+    serial = str(tmp_path / 'serial.nc')
+    write_netcdf(ds, serial, format=fmt, unlimited_dims=['Time'])
+    assert _parallel._workers() >= 1
+    monkeypatch.setattr(_parallel, 'MIN_BYTES', 1024)
+    monkeypatch.setattr(_parallel, 'CHUNK_BYTES', 4096)
+    monkeypatch.setattr(_parallel, '_workers', lambda: 4)
+    threaded = str(tmp_path / 'threaded.nc')
+    write_netcdf(ds, threaded, format=fmt, unlimited_dims=['Time'])
+    assert open(serial, 'rb').read() == open(threaded, 'rb').read()
+    back = open_dataset(threaded)          # threaded conversion on the way in
+    for name in ds.data_vars:
+        a, b = ds[name].values, back[name].values
+        assert a.dtype == b.dtype and np.array_equal(a, b, equal_nan=True), \
+            name
+    assert np.isnan(big).sum() == np.isnan(back['holed'].values).sum()
