@@ -76,16 +76,22 @@ def _decode(data, attrs):
     return data, attrs, encoding
 
 
-def open_dataset(filename, mask_and_scale=True):
-    """Read ``filename`` into a :class:`pyremap_amd.Dataset`."""
+def open_dataset(filename, mask_and_scale=True, variables=None):
+    """
+    Read ``filename`` into a :class:`pyremap_amd.Dataset`.  ``variables``:
+    read only these data variables (and the coordinate variables); the rest
+    of the file is not touched.
+    """
     if not os.path.exists(filename):
         raise FileNotFoundError(filename)
     fmt = file_format(filename)
     if fmt is None:
         raise ValueError(f'{filename}: not a NetCDF file')
+    if variables is not None:
+        variables = set(variables)
     if fmt == 'NETCDF4':
-        return _open_hdf5(filename, mask_and_scale)
-    nc = netcdf3.read(filename)
+        return _open_hdf5(filename, mask_and_scale, variables)
+    nc = netcdf3.read(filename, variables=variables)
     ds = xr_lite.Dataset(attrs=nc.attrs)
     ds.encoding = {
         'format': fmt,
@@ -107,7 +113,7 @@ def open_dataset(filename, mask_and_scale=True):
     return ds
 
 
-def _open_hdf5(filename, mask_and_scale):
+def _open_hdf5(filename, mask_and_scale, variables=None):
     """NetCDF-4 through this package's own HDF5 reader (no h5py/netCDF4)."""
     from pyremap_amd.io.netcdf4_lite import NetCDF4File
     with NetCDF4File(filename) as nc:
@@ -116,6 +122,9 @@ def _open_hdf5(filename, mask_and_scale):
                        'unlimited_dims': list(nc.unlimited),
                        'dim_order': list(nc.dimensions)}
         for name, var in nc.variables.items():
+            if variables is not None and name not in variables and \
+                    tuple(var.dims) != (name,):
+                continue
             data = var.read()
             if isinstance(data, list):
                 # variable-length strings: an object array of str

@@ -140,8 +140,13 @@ class _Reader:
         return out
 
 
-def read(filename):
-    """Read a whole classic-format file into a :class:`NetCDF3File`."""
+def read(filename, variables=None):
+    """
+    Read a classic-format file into a :class:`NetCDF3File`: every variable,
+    or -- ``variables`` given -- only those named plus the coordinate
+    variables (a variable that is 1-D along the dimension of its own name);
+    the others are not touched on disk.
+    """
     buf = np.memmap(filename, dtype=np.uint8, mode='r')
     if bytes(buf[:3]) != b'CDF' or buf[3] not in (1, 2, 5):
         raise ValueError(f'{filename}: not a NetCDF classic (CDF-1/2/5) file')
@@ -204,6 +209,9 @@ def read(filename):
 
     for name, dimids, attrs, nc_type, vsize, begin in headers:
         dims = [dim_names[d] for d in dimids]
+        if variables is not None and name not in variables and \
+                dims != [name]:
+            continue
         dt = _TYPES[nc_type]
         if is_rec(dimids):
             inner = [nc.dimensions[d] for d in dims[1:]]

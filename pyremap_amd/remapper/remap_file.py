@@ -45,7 +45,9 @@ def _remap_file(remapper, in_filename, out_filename, variable_list,
                 overwrite, renormalize, logger, replace_mpas_fill):
     if not _validate_inputs(remapper, out_filename, overwrite):
         return
-    ds = open_dataset(in_filename)
+    # (with a variable list only those variables -- and the coordinates --
+    # are read: the rest of the file is not touched)
+    ds = open_dataset(in_filename, variables=variable_list)
     if variable_list is not None:
         missing = [v for v in variable_list if v not in ds]
         if missing:

@@ -653,3 +653,23 @@ def test_threaded_file_io_writes_the_same_bytes(tmp_path, fmt, monkeypatch):
         assert a.dtype == b.dtype and np.array_equal(a, b, equal_nan=True), \
             name
     assert np.isnan(big).sum() == np.isnan(back['holed'].values).sum()
+
+
+@pytest.mark.parametrize('fmt', ['NETCDF3_64BIT_DATA', 'NETCDF4'])
+def test_open_dataset_reads_only_the_requested_variables(tmp_path, fmt):
+    """`ncremap(variable_list=...)` must not read the rest of the file."""
+    from pyremap_amd import DataArray, Dataset
+    from pyremap_amd.io.netcdf import open_dataset, write_netcdf
+    rng = np.random.default_rng(1)
+    ds = Dataset()
+    for name in ('a', 'b', 'c'):
+        ds[name] = DataArray(rng.standard_normal((2, 7)),
+                             dims=('Time', 'nCells'))
+    ds._set_coord('nCells', DataArray(np.arange(7.0), dims=('nCells',)))
+    path = str(tmp_path / 'three.nc')
+    write_netcdf(ds, path, format=fmt)
+    some = open_dataset(path, variables=['b'])
+    assert list(some.data_vars) == ['b'] and list(some.coords) == ['nCells']
+    assert np.array_equal(some['b'].values, ds['b'].values)
+    every = open_dataset(path)
+    assert sorted(every.data_vars) == ['a', 'b', 'c']
