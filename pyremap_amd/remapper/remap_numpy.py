@@ -287,7 +287,10 @@ def _remap_numpy_array(remapper, in_field, remap_axes,
         # to when the mask is isnan(field), :201-204 and :263): the mask goes
         # up beside the data and is burnt in on the device
         host_mask = np.ma.getmaskarray(in_field)
-        if not host_mask.any():
+        if not host_mask.any() and not host_path._any_nan(
+                np.ascontiguousarray(data)):
+            # nothing masked and no NaN an empty mask would have to protect
+            # (an UNMASKED NaN goes through in the reference, :263)
             host_mask = None
     out, mask = host_path.remap_host_array(
         plan, dst_grid_dims, data, remap_axes,

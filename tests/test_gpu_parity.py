@@ -1528,6 +1528,27 @@ def test_host_arrays_pinned_pipelined_and_poisoned(dev):
     assert np.array_equal(got_mask, ref_mask)
     assert_bitwise(np.where(ref_mask, 0.0, data),
                    np.where(ref_mask, 0.0, ref_data), 'poisoned entry')
+    # a MaskedArray that masks NOTHING: still the masked branch (the
+    # normaliser is A . 1, not frac_b), and a NaN it holds goes through
+    from types import SimpleNamespace
+    from pyremap_amd.remapper import remap_numpy as rn
+    fake = SimpleNamespace(
+        _matrix=plan, engine_flags=0,
+        _ds_map=SimpleNamespace(dst_grid_dims=m.dst_dims))
+    clean = rng.standard_normal((m.n_a, 6))
+    dirty = clean.copy()
+    dirty[7, 2] = np.nan
+    for values in (clean, dirty):
+        arr = np.ma.masked_array(values, mask=False)
+        want = oracle.remap_numpy_array(csr, mm['frac_b'], m.dst_dims, arr,
+                                        [0], 0.05)
+        got = rn._remap_numpy_array(fake, arr, [0], 0.05)
+        wm = np.ma.getmaskarray(want)
+        assert np.array_equal(np.ma.getmaskarray(got), wm)
+        assert_bitwise(np.where(wm, 0.0, np.ma.getdata(got)),
+                       np.where(wm, 0.0, np.ma.getdata(want)),
+                       'empty mask')
+    assert np.isnan(np.ma.getdata(want)[~wm]).any()
 
 
 @pytest.mark.parametrize('rows', [8, 4])
