@@ -25,12 +25,20 @@
  *                                             (remap_groups_build() and
  *                                             remap_patches_build() are its
  *                                             two builders, also exported)
+ *   pyremap/remapper/remap_numpy.py:72-139    `_load_mapping` as a whole and
+ *                                   223-297   `_remap_numpy_array` as a whole
+ *                                             behind one opaque handle whose
+ *                                             device memory the library owns
+ *                                             -> remap_plan_create() /
+ *                                             remap_plan_apply() /
+ *                                             remap_plan_destroy()
  *
  * Conventions: extern "C"; plain pointers and sizes only; every pointer
  * marked (device) is an address in the current HIP device's memory (e.g.
  * torch.Tensor.data_ptr()); all launches are asynchronous on the caller's
  * hipStream_t (passed as void*; NULL = the null stream); nothing is allocated,
- * freed or synchronised inside the apply call, so it is graph-capturable.
+ * freed or synchronised inside the apply calls, so they are graph-capturable
+ * (only remap_plan_create / _destroy allocate and free device memory).
  * Return value: REMAP_OK (0) or a negative REMAP_ERR_*; the message of the
  * last failure on the calling thread is available from remap_last_error().
  *
@@ -47,7 +55,7 @@
 extern "C" {
 #endif
 
-#define REMAP_ABI_VERSION 17
+#define REMAP_ABI_VERSION 18
 
 enum {
     REMAP_OK = 0,
@@ -393,6 +401,70 @@ int remap_schedule_auto(const remap_csr *A, const double *frac_b,
                         int64_t row_offset, void *arena, size_t arena_bytes,
                         void *workspace, size_t workspace_bytes,
                         remap_schedule *schedule_out, void *stream);
+
+/*
+ * The whole path behind ONE opaque handle, device memory owned by the
+ * library (hipMalloc / hipFree) -- for a binder without an allocator of its
+ * own; the entry points above never allocate and suit a host layer that has
+ * one (pyremap_amd keeps everything in torch tensors).
+ *
+ * remap_plan_create = `_load_mapping` (remap_numpy.py:72-139): the mapping
+ *   file's triplets become the device CSR scipy would build (:134-137:
+ *   sorted, duplicates summed), frac_b is copied, and the mapping gets its
+ *   kernel schedule (remap_schedule_auto).  Cache the handle where the
+ *   reference caches `remapper._matrix`.
+ *     row, col (int32, `index_base`-based), S, frac_b: HOST arrays when
+ *       host_input != 0 (the library uploads them), device arrays otherwise;
+ *       not retained either way
+ *     dst_grid_dims (HOST): C-order dims of the destination grid, n_dims =
+ *       1 or 2 (0: no grid known -- the plain kernels)
+ *   Synchronous on `stream`.  REMAP_ERR_ARG if a triplet is out of range.
+ * remap_plan_apply = `_remap_numpy_array` (:223-297): one fused launch over
+ *   all rows, asynchronous on `stream`; field layout and modes as in
+ *   remap_apply_args (same names, same meaning).
+ * remap_plan_destroy frees the device memory (the caller makes sure no
+ *   launch still uses it).
+ */
+typedef struct remap_plan remap_plan;
+
+typedef struct remap_plan_info {
+    int64_t n_a;
+    int64_t n_b;
+    int64_t nnz;                 /* after duplicate summing                  */
+    int64_t max_row_nnz;
+    int32_t family;              /* remap_schedule.family chosen             */
+    int32_t group_rows;
+    double ratio;
+    size_t device_bytes;         /* device memory the plan holds             */
+} remap_plan_info;
+
+typedef struct remap_field {
+    const void *X;               /* (device) source field                    */
+    int32_t x_dtype;             /* REMAP_DTYPE_*                            */
+    int32_t mode;                /* REMAP_MODE_*                             */
+    int64_t n_batch;
+    int64_t k_inner;
+    int64_t x_row_stride;        /* elements                                 */
+    int64_t x_batch_stride;
+    double *Y;                   /* (device) float64 result                  */
+    int64_t y_row_stride;
+    int64_t y_batch_stride;
+    double threshold;            /* REMAP_MODE_MASKED                        */
+    uint8_t *mask_out;           /* (device) or NULL                         */
+    const int32_t *gate;         /* (device) or NULL: see remap_apply_args   */
+    int32_t gate_value;
+    uint32_t flags;              /* REMAP_FLAG_FMA, REMAP_FLAG_TREE          */
+} remap_field;
+
+int remap_plan_create(int64_t n_b, int64_t n_a, int64_t n_s,
+                      const int32_t *row, const int32_t *col, const double *S,
+                      int32_t index_base, const double *frac_b,
+                      int32_t host_input, const int64_t *dst_grid_dims,
+                      int32_t n_dims, void *stream, remap_plan **plan_out);
+void remap_plan_destroy(remap_plan *plan);
+int remap_plan_query(const remap_plan *plan, remap_plan_info *info_out);
+int remap_plan_apply(const remap_plan *plan, const remap_field *field,
+                     void *stream);
 
 /*
  * OR 1 into *flag (device int32, zeroed by the caller) if any of the n

@@ -14,7 +14,8 @@ INCLUDE = os.path.join(_REPO, 'include')
 LIB_DIR = os.path.join(_PKG, '_lib')
 LIB_PATH = os.environ.get('REMAP_HIP_LIB') or \
     os.path.join(LIB_DIR, 'libremap_hip.so')
-SOURCES = ['remap_spmm.hip', 'remap_csr.hip', 'remap_schedule.hip']
+SOURCES = ['remap_spmm.hip', 'remap_csr.hip', 'remap_schedule.hip',
+           'remap_plan.hip']
 ARCH = 'gfx950'
 
 

@@ -33,7 +33,7 @@ FLAG_TREE = 8
 DTYPE_F64 = 0
 DTYPE_F32 = 1
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 #: readable pad entries kept behind col/val (remap_csr.csr_pad)
 CSR_PAD = 8
@@ -46,6 +46,8 @@ EXPORTS = (
     'remap_groups_workspace', 'remap_groups_build',
     'remap_patches_workspace', 'remap_patches_build',
     'remap_schedule_sizes', 'remap_schedule_auto',
+    'remap_plan_create', 'remap_plan_destroy', 'remap_plan_query',
+    'remap_plan_apply',
 )
 
 
@@ -140,6 +142,39 @@ class _Schedule(ctypes.Structure):
     ]
 
 
+class _PlanInfo(ctypes.Structure):     # struct remap_plan_info
+    _fields_ = [
+        ('n_a', ctypes.c_int64),
+        ('n_b', ctypes.c_int64),
+        ('nnz', ctypes.c_int64),
+        ('max_row_nnz', ctypes.c_int64),
+        ('family', ctypes.c_int32),
+        ('group_rows', ctypes.c_int32),
+        ('ratio', ctypes.c_double),
+        ('device_bytes', ctypes.c_size_t),
+    ]
+
+
+class _Field(ctypes.Structure):        # struct remap_field
+    _fields_ = [
+        ('X', ctypes.c_void_p),
+        ('x_dtype', ctypes.c_int32),
+        ('mode', ctypes.c_int32),
+        ('n_batch', ctypes.c_int64),
+        ('k_inner', ctypes.c_int64),
+        ('x_row_stride', ctypes.c_int64),
+        ('x_batch_stride', ctypes.c_int64),
+        ('Y', ctypes.c_void_p),
+        ('y_row_stride', ctypes.c_int64),
+        ('y_batch_stride', ctypes.c_int64),
+        ('threshold', ctypes.c_double),
+        ('mask_out', ctypes.c_void_p),
+        ('gate', ctypes.c_void_p),
+        ('gate_value', ctypes.c_int32),
+        ('flags', ctypes.c_uint32),
+    ]
+
+
 _lib = None
 
 
@@ -214,6 +249,20 @@ def load_library():
         ctypes.POINTER(ctypes.c_int64), ctypes.c_int32, ctypes.c_int64,
         ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
         ctypes.POINTER(_Schedule), ctypes.c_void_p]
+    lib.remap_plan_create.restype = ctypes.c_int
+    lib.remap_plan_create.argtypes = [
+        ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
+        ctypes.c_int32, ctypes.POINTER(ctypes.c_int64), ctypes.c_int32,
+        ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
+    lib.remap_plan_destroy.restype = None
+    lib.remap_plan_destroy.argtypes = [ctypes.c_void_p]
+    lib.remap_plan_query.restype = ctypes.c_int
+    lib.remap_plan_query.argtypes = [ctypes.c_void_p,
+                                     ctypes.POINTER(_PlanInfo)]
+    lib.remap_plan_apply.restype = ctypes.c_int
+    lib.remap_plan_apply.argtypes = [ctypes.c_void_p,
+                                     ctypes.POINTER(_Field), ctypes.c_void_p]
     lib.remap_scan_nan.restype = ctypes.c_int
     lib.remap_scan_nan.argtypes = [ctypes.c_void_p, ctypes.c_int32,
                                    ctypes.c_int64, ctypes.c_void_p,

@@ -1605,7 +1605,9 @@ def test_integration_stub_runs_on_the_c_abi_alone(dev):
     from pyremap_amd import engine, synthetic
     text = open(os.path.join(os.path.dirname(os.path.dirname(
         os.path.abspath(__file__))), 'INTEGRATION.md')).read()
-    code = text[text.index('```python') + len('```python'):]
+    # (the lower-level stub: the block that declares struct remap_apply_args)
+    code = text[:text.index('class _Args(ctypes.Structure)')]
+    code = text[code.rindex('```python') + len('```python'):]
     code = code[:code.index('```')]
     code = code.replace("'libremap_hip.so'", repr(engine.library_path()))
     ns = {}
@@ -1642,6 +1644,71 @@ def test_integration_stub_runs_on_the_c_abi_alone(dev):
                 False, 0.0)
     assert torch.equal(torch.nan_to_num(plain, nan=1e300),
                        torch.nan_to_num(Y2, nan=1e300))
+
+
+def test_integration_plan_stub_runs_on_the_c_abi_alone(dev):
+    """
+    The FIRST stub of INTEGRATION.md -- the opaque plan handle, device memory
+    owned by the library -- executed as printed: host triplets in, bit for
+    bit the oracle out (frac_b and masked branch, conservative and bilinear
+    mappings, i.e. the row-group and the LDS-patch schedule), out-of-range
+    triplets refused, the handle freed.
+    """
+    import ctypes
+    from oracle import oracle
+    from pyremap_amd import engine, synthetic
+    text = open(os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), 'INTEGRATION.md')).read()
+    code = text[text.index('```python') + len('```python'):]
+    code = code[:code.index('```')]
+    assert 'remap_plan_create' in code and '_Args' not in code
+    code = code.replace("'libremap_hip.so'", repr(engine.library_path()))
+    ns = {}
+    exec(compile(code, 'INTEGRATION.md', 'exec'), ns)
+    lib = engine.load_library()
+    rng = np.random.default_rng(16)
+    for m, family in ((synthetic.conservative_map(3000, (30, 44), 1, 7,
+                                                  seed=12), 10),
+                      (synthetic.bilinear_map((13, 17), (60, 75), seed=3),
+                       5)):
+        mm = m.numpy()
+        plan = ns['Plan'](mm['row'], mm['col'], mm['S'], mm['frac_b'],
+                          m.n_b, m.n_a, list(m.dst_dims))
+        info = engine._PlanInfo()
+        assert lib.remap_plan_query(plan._handle, ctypes.byref(info)) == 0
+        ref_csr = oracle.coo_to_csr(mm['row'] - 1, mm['col'] - 1, mm['S'],
+                                    m.n_b, m.n_a)
+        assert (info.n_a, info.n_b, info.nnz) == (m.n_a, m.n_b,
+                                                  len(ref_csr.data))
+        assert info.family == family and info.device_bytes > 0
+        for K in (192, 7):
+            x = rng.standard_normal((m.n_a, K))
+            xm = x.copy()
+            xm[rng.random(m.n_a) < 0.25, :] = np.nan
+            for field, masked in ((x, False), (xm, True)):
+                X = torch.from_numpy(field).to(dev)
+                Y = torch.full((m.n_b, K), 9.0, dtype=torch.float64,
+                               device=dev)
+                M = torch.zeros((m.n_b, K), dtype=torch.uint8, device=dev)
+                plan.apply(X, Y, K, masked, 0.2, mask_out=M)
+                ref, ref_mask = oracle.remap_flat(ref_csr, mm['frac_b'],
+                                                  field, masked, 0.2)
+                ref[ref_mask] = np.nan
+                assert_bitwise(Y.cpu().numpy(), ref,
+                               f'plan stub family {family} K={K} '
+                               f'masked={masked}')
+                assert np.array_equal(M.cpu().numpy().astype(bool),
+                                      ref_mask)
+        torch.cuda.synchronize()
+        del plan                       # remap_plan_destroy
+    bad_row = mm['row'].copy()
+    bad_row[5] = m.n_b + 3
+    with pytest.raises(RuntimeError, match='outside'):
+        ns['Plan'](bad_row, mm['col'], mm['S'], mm['frac_b'], m.n_b, m.n_a,
+                   list(m.dst_dims))
+    with pytest.raises(RuntimeError, match='destination grid'):
+        ns['Plan'](mm['row'], mm['col'], mm['S'], mm['frac_b'], m.n_b,
+                   m.n_a, [3, 5])
 
 
 @pytest.mark.parametrize('case', ['2d', '1d', 'shard', 'bilinear'])

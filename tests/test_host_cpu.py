@@ -54,6 +54,9 @@ def test_struct_layout_matches_header():
         [f[0] for f in engine._ApplyArgs._fields_]
     assert fields('remap_schedule') == \
         [f[0] for f in engine._Schedule._fields_]
+    assert fields('remap_plan_info') == \
+        [f[0] for f in engine._PlanInfo._fields_]
+    assert fields('remap_field') == [f[0] for f in engine._Field._fields_]
 
 
 def test_no_gpu_means_loud_failure():
@@ -612,7 +615,11 @@ def test_integration_stub_matches_the_binding():
     block = block[:block.index('def build_schedule')]
     names = re.findall(r"\('(\w+)',", block)
     assert names == [f[0] for f in engine._Schedule._fields_]
-    assert f'remap_abi_version() == {engine.ABI_VERSION}' in text
+    block = text[text.index('class _Field(ctypes.Structure)'):]
+    block = block[:block.index('def _check')]
+    names = re.findall(r"\('(\w+)',", block)
+    assert names == [f[0] for f in engine._Field._fields_]
+    assert text.count(f'remap_abi_version() == {engine.ABI_VERSION}') == 2
 
 
 @pytest.mark.parametrize('fmt', ['NETCDF3_64BIT_DATA', 'NETCDF3_64BIT',
