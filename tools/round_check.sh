@@ -1,7 +1,9 @@
 #!/bin/bash
-# One GPU-box pass: parity suite, the bench line of every workload, profiles.
-#   tools/round_check.sh <tag>           then, back in the build container:
-#   python tools/summarize_profile.py <tag> config3 headline config4 config5
+# One GPU-box pass: the parity suite, rocprofv3 profiles, the multi-rank
+# rehearsals on this one GPU, the bench line of every workload.
+#   gpurun -- 'bash tools/round_check.sh r02'      then, back in the build
+#   container:  python tools/summarize_profile.py r02 config3 headline config4 config5
+# (delete gpurun_out/prof_<tag> first: gpurun merges, it does not replace)
 set -u
 TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -11,6 +13,11 @@ python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1
 echo "pytest exit $?" >> gpurun_out/pytest_gpu.log
 tail -3 gpurun_out/pytest_gpu.log
 bash tools/profile.sh "$TAG" config3 headline config4 config5 > "gpurun_out/profile_$TAG.log" 2>&1
+# N > 1 as the driver launches it, rehearsed with gloo and the ranks sharing
+# this GPU (RCCL refuses several ranks on one device); and the distributed
+# code path on one rank over RCCL
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29544 bench.py --gpus 2 --steps 20 --warmup 5 --backend gloo > gpurun_out/b_gloo2.json 2> gpurun_out/b_gloo2.err
+python bench.py --steps 20 --warmup 5 --force-dist --no-cpu > gpurun_out/b_fd.json 2> gpurun_out/b_fd.err
 for w in config2 config4 config5 headline; do
   python bench.py --workload $w --steps 30 --warmup 5 --sets 1 --no-cpu --no-extra > gpurun_out/bench_$w.json 2> gpurun_out/bench_$w.err
 done
@@ -18,10 +25,11 @@ python bench.py --steps 20 --warmup 5 > gpurun_out/bench_n1.json 2> gpurun_out/b
 python - <<'PY'
 import glob
 import json
-for f in sorted(glob.glob('gpurun_out/bench_*.json')):
+for f in sorted(glob.glob('gpurun_out/bench_*.json')) + \
+        ['gpurun_out/b_gloo2.json', 'gpurun_out/b_fd.json']:
     try:
         d = json.loads(open(f).read().strip().splitlines()[-1])
-        print(f, d['config'].get('schedule', {}).get('family'),
+        print(f, d['n_gpus'], d['config'].get('schedule', {}).get('family'),
               round(d['roofline']['kernel_ms_mean'], 4),
               round(d['roofline']['frac'], 4))
     except Exception as e:   # noqa: BLE001
