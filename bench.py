@@ -13,9 +13,10 @@ batch of 512 synthetic fields that are already resident in HBM.
 N > 1 (launched by torch.distributed.run, one rank per GPU): destination
 rows are sharded over the ranks (nnz-balanced contiguous ranges), rank 0's
 source field reaches the ranks ONCE before the timed region (timed
-separately: `multi_gpu.broadcast_ms` for one RCCL broadcast,
-`multi_gpu.bands_ms` when each rank receives only the band of source rows its
-shard references), and the timed steps contain no collective.  The problem
+separately: `multi_gpu.broadcast_ms` for one RCCL broadcast; after the
+metric, under a watchdog, `multi_gpu.bands_ms` when each rank receives only
+the band of source rows its shard references, point to point), and the timed
+steps contain no collective.  The problem
 size is fixed, so this is strong scaling.  `multi_gpu.pipelined_*` is the
 whole job WITH the exchange, K-chunks pipelined behind the kernel.
 
@@ -288,34 +289,21 @@ def prepare(name, args, rank, world, dist, K=None, mode=None, layout=None,
 
 def time_exchange(w, dist):
     """
-    The ONE exchange step of the sharded path, timed on its own, two ways:
-    one RCCL broadcast of the whole field, and only the band of source rows
-    each shard references (point to point).  Leaves every rank holding rank
-    0's fields.
+    The ONE exchange step of the sharded path in its collective form -- one
+    RCCL broadcast of the whole field -- timed on its own; leaves every rank
+    holding rank 0's fields.  (The point-to-point form: time_bands.)
     """
     import torch
     out = {}
     x = w.fields[0]
-    rows_first = w.layout == 'nk'
-    for how in ('broadcast', 'bands'):
-        if how == 'bands' and (not rows_first or
-                               dist.get_backend() != 'nccl'):
-            continue   # (gloo moves GPU tensors point to point via the host)
-        times = []
-        try:
-            for _ in range(3):
-                barrier(dist)
-                t0 = time.perf_counter()
-                if how == 'broadcast':
-                    dist.broadcast(x, src=0)
-                else:
-                    w.remap.distribute(x, src=0, how='bands')
-                torch.cuda.synchronize()
-                times.append((time.perf_counter() - t0) * 1e3)
-            out[f'{how}_ms'] = min(times)
-        except RuntimeError as exc:   # gloo rehearsal: no GPU send/recv
-            out[f'{how}_ms'] = None
-            out[f'{how}_error'] = str(exc).splitlines()[0][:200]
+    times = []
+    for _ in range(3):
+        barrier(dist)
+        t0 = time.perf_counter()
+        dist.broadcast(x, src=0)
+        torch.cuda.synchronize()
+        times.append((time.perf_counter() - t0) * 1e3)
+    out['broadcast_ms'] = min(times)
     for x in w.fields:            # every set resident everywhere
         dist.broadcast(x, src=0)
     torch.cuda.synchronize()
@@ -324,6 +312,31 @@ def time_exchange(w, dist):
                                                       w.plan.n_a)
     out['field_bytes'] = x.numel() * x.element_size()
     return out
+
+
+def time_bands(w, dist):
+    """
+    The point-to-point form of the exchange (each rank receives only the band
+    of source rows its shard references), timed AFTER the metric: it is the
+    one part of this file that has never run on more than one GPU, and a
+    watchdog (see main) reports the metric without it should it not return.
+    """
+    import torch
+    if w.layout != 'nk' or dist.get_backend() != 'nccl':
+        return {}      # (gloo moves GPU tensors point to point via the host)
+    x = w.fields[0]
+    times = []
+    try:
+        for _ in range(3):
+            barrier(dist)
+            t0 = time.perf_counter()
+            w.remap.distribute(x, src=0, how='bands')
+            torch.cuda.synchronize()
+            times.append((time.perf_counter() - t0) * 1e3)
+        return {'bands_ms': min(times)}
+    except RuntimeError as exc:
+        return {'bands_ms': None,
+                'bands_error': str(exc).splitlines()[0][:200]}
 
 
 def time_pipelined(w, args, dist, reps=5, n_batches=4):
@@ -616,66 +629,27 @@ def measure_extras(ready, args, dist, extra):
             extra[tag] = {'error': f'{type(exc).__name__}: {exc}'}
 
 
-def main():
-    args = parse_args()
-    import torch
-    rank, world, local, dist = init_dist(args)
-    device = torch.device('cuda', local)
-    from pyremap_amd import engine
-    engine.require_gpu()
+def print_line(line):
+    """The JSON line is the LAST thing on stdout ... through C stdio, which a
+    pipe makes fully buffered: flush it first, or RCCL's version banner lands
+    behind the line at exit."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    sys.stdout.flush()
+    print(json.dumps(line), flush=True)
 
-    extra = {}
-    # everything is PREPARED first (host work, GPU mostly idle), then all
-    # measurements run back to back; the metric workload last
-    main_w = prepare(args.workload, args, rank, world, dist)
-    ready = prepare_extras(args, rank, world, dist, extra)
-    ceiling = copy_ceiling(device)
-    pipelined = None
-    res = None
-    if args.metric_first:
-        res = measure(main_w, args, dist)
-    measure_extras(ready, args, dist, extra)
-    if res is None:
-        res = measure(main_w, args, dist)
+
+#: seconds the optional point-to-point measurements of an N > 1 run may take
+#: before the metric is reported without them
+OPTIONAL_TIMEOUT_S = int(os.environ.get('BENCH_OPTIONAL_TIMEOUT_S', 150))
+
+
+def compose_line(args, res, world, ceiling, cpu, extra, pipelined):
+    """The one JSON line, from what has been measured."""
     K = res['K']
-    # a long run behind it, for the record: the steady-state launch time
-    a = torch.cuda.Event(enable_timing=True)
-    b = torch.cuda.Event(enable_timing=True)
-    a.record()
-    for i in range(100):
-        main_w.launch(i)
-    b.record()
-    torch.cuda.synchronize()
-    res['kernel_ms_steady_100_more'] = a.elapsed_time(b) / 100
-    if main_w.sharded:
-        pipelined = time_pipelined(main_w, args, dist)
-    # per-rank kernel numbers -> the slowest rank prices the roofline
-    if dist is not None:
-        t = torch.tensor([res['kernel_ms_mean']], device=device,
-                         dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        res['kernel_ms_mean_max_rank'] = float(t.item())
-    del ready
-
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu:
-        cpu = cpu_baseline(main_w.full, main_w.m, main_w.fields[0],
-                           res['mode'], args.cpu_seconds)
-    if world == 1 and not args.no_extra and args.workload == 'config3':
-        main_w.fields = main_w.outs = None
-        torch.cuda.empty_cache()
-        try:
-            extra['host_buffers_pcie_inclusive'] = pcie_inclusive(args)
-        except Exception as exc:  # noqa: BLE001
-            extra['host_buffers_pcie_inclusive'] = {
-                'error': f'{type(exc).__name__}: {exc}'}
-
-    if rank != 0:
-        if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
-
     traffic, traffic_src = load_traffic(args.workload, K, res['mode'])
     kernel_ms = res.get('kernel_ms_mean_max_rank', res['kernel_ms_mean'])
     achieved = res['bytes_alg'] / (kernel_ms * 1e-3) / 1e9
@@ -748,21 +722,103 @@ def main():
         'multi_gpu': multi,
         'extra': extra,
     }
+    return line
+
+
+def main():
+    args = parse_args()
+    import torch
+    rank, world, local, dist = init_dist(args)
+    device = torch.device('cuda', local)
+    from pyremap_amd import engine
+    engine.require_gpu()
+
+    extra = {}
+    # everything is PREPARED first (host work, GPU mostly idle), then all
+    # measurements run back to back; the metric workload last
+    main_w = prepare(args.workload, args, rank, world, dist)
+    ready = prepare_extras(args, rank, world, dist, extra)
+    ceiling = copy_ceiling(device)
+    pipelined = None
+    res = None
+    if args.metric_first:
+        res = measure(main_w, args, dist)
+    measure_extras(ready, args, dist, extra)
+    if res is None:
+        res = measure(main_w, args, dist)
+    # a long run behind it, for the record: the steady-state launch time
+    a = torch.cuda.Event(enable_timing=True)
+    b = torch.cuda.Event(enable_timing=True)
+    a.record()
+    for i in range(100):
+        main_w.launch(i)
+    b.record()
+    torch.cuda.synchronize()
+    res['kernel_ms_steady_100_more'] = a.elapsed_time(b) / 100
+    # per-rank kernel numbers -> the slowest rank prices the roofline
+    if dist is not None:
+        t = torch.tensor([res['kernel_ms_mean']], device=device,
+                         dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        res['kernel_ms_mean_max_rank'] = float(t.item())
+    watchdog = None
+    if main_w.sharded:
+        # The metric is in hand.  What follows uses RCCL point to point,
+        # which no test could exercise on more than one GPU: should it not
+        # return, every rank leaves after OPTIONAL_TIMEOUT_S and rank 0
+        # prints the line without these numbers.
+        import threading
+
+        def bail():
+            if rank == 0:
+                late = dict(res['exchange'] or {})
+                late['optional_measurements'] = (
+                    f'timed out after {OPTIONAL_TIMEOUT_S} s: point-to-point '
+                    f'bands / pipelined exchange not measured')
+                res['exchange'] = late
+                print_line(compose_line(args, res, world, ceiling, None,
+                                        extra, None))
+            os._exit(0)
+        watchdog = threading.Timer(OPTIONAL_TIMEOUT_S, bail)
+        watchdog.daemon = True
+        watchdog.start()
+        if os.environ.get('BENCH_TEST_HANG'):      # exercises the watchdog
+            time.sleep(10 ** 6)
+        bands = time_bands(main_w, dist)
+        if res['exchange'] is not None:
+            res['exchange'].update(bands)
+        pipelined = time_pipelined(main_w, args, dist)
+        barrier(dist)
+        watchdog.cancel()
+    del ready
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        cpu = cpu_baseline(main_w.full, main_w.m, main_w.fields[0],
+                           res['mode'], args.cpu_seconds)
+    if world == 1 and not args.no_extra and args.workload == 'config3':
+        main_w.fields = main_w.outs = None
+        torch.cuda.empty_cache()
+        try:
+            extra['host_buffers_pcie_inclusive'] = pcie_inclusive(args)
+        except Exception as exc:  # noqa: BLE001
+            extra['host_buffers_pcie_inclusive'] = {
+                'error': f'{type(exc).__name__}: {exc}'}
+
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    line = compose_line(args, res, world, ceiling, cpu, extra, pipelined)
     # the JSON line is the LAST thing on stdout: every rank is done first
     # (RCCL prints a version banner on stdout when its communicator comes up
     # or goes down, whichever happens to be later)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    try:
-        # ... through C stdio, which a pipe makes fully buffered: flush it,
-        # or the banner lands behind the JSON line at exit
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
-    except OSError:
-        pass
-    sys.stdout.flush()
-    print(json.dumps(line), flush=True)
+    print_line(line)
 
 
 if __name__ == '__main__':
