@@ -1837,3 +1837,35 @@ def test_sharded_remap_ranks_sharing_one_gpu(world, tmp_path):
         for key in ('bands', 'broadcast', 'auto', 'pipelined'):
             assert notes[key] == 1, (rank, key, notes)
         assert notes['band_frac'] < 1.0
+
+
+def test_bench_multi_rank_line_survives_a_hung_exchange(tmp_path):
+    """
+    `bench.py --gpus 2` as the driver launches it (torch.distributed.run, one
+    process per rank; here gloo, both ranks on this GPU): the JSON line
+    carries the sharded metric and the exchange timings -- and when the
+    optional point-to-point part never returns (BENCH_TEST_HANG), the
+    watchdog still gets the metric line out with exit code 0.
+    """
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+            '--nproc-per-node', '2', '--master-addr', '127.0.0.1']
+    bench = [os.path.join(repo, 'bench.py'), '--gpus', '2', '--steps', '5',
+             '--warmup', '2', '--backend', 'gloo', '--no-extra']
+    for port, env_extra in (('29571', {}),
+                            ('29572', {'BENCH_TEST_HANG': '1',
+                                       'BENCH_OPTIONAL_TIMEOUT_S': '5'})):
+        env = dict(os.environ, **env_extra)
+        proc = subprocess.run(base + ['--master-port', port] + bench,
+                              capture_output=True, text=True, env=env,
+                              timeout=600, cwd=str(tmp_path))
+        assert proc.returncode == 0, proc.stderr[-2000:]
+        line = json.loads(proc.stdout.strip().splitlines()[-1])
+        assert line['n_gpus'] == 2 and line['scaling'] == 'strong'
+        assert line['value'] > 0 and 0 < line['roofline']['frac'] < 1
+        multi = line['multi_gpu']
+        assert multi['broadcast_ms'] > 0 and multi['kernel_phase_ms'] > 0
+        assert ('optional_measurements' in multi) == bool(env_extra)
