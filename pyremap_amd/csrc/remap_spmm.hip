@@ -220,7 +220,8 @@ typename ScalarFn<XT>::type pick_rowscalar(int vec, int tiles, int mode,
                                            bool fma)
 {
     if (vec == 1)
-        return pick_rowscalar_mode<XT, 1, 1>(mode, fma);
+        return tiles == 1 ? pick_rowscalar_mode<XT, 1, 1>(mode, fma)
+                          : pick_rowscalar_mode<XT, 1, 2>(mode, fma);
     return tiles == 1 ? pick_rowscalar_mode<XT, 2, 1>(mode, fma)
                       : pick_rowscalar_mode<XT, 2, 2>(mode, fma);
 }
@@ -688,8 +689,11 @@ int run_rowwave(const remap_apply_args *a, const Call &c, KParams p,
     int tiles = a->tune[2];
     if (tiles == 0)
         tiles = ((family == 1 || c.f32) && c.K >= 256) ? 2 : 1;  // measured
-    if (vec == 1)
-        tiles = 1;
+    if (vec == 1) {
+        // odd strides / level counts: two 64-column tiles keep a wave over
+        // 128 columns (rowscalar only; tune[2] = 1 forces one)
+        tiles = (family == 6 && c.K > 64 && a->tune[2] != 1) ? 2 : 1;
+    }
     if (tiles != 1 && tiles != 2 && tiles != 4)
         return fail(REMAP_ERR_ARG, "remap_apply_f64: tune[2] = %d", tiles);
     if (family == 6 && tiles == 4)
