@@ -197,6 +197,8 @@ TUNES = [
     # scalar-cache metadata family
     (6, 1, 1, 1, 2, 0), (6, 1, 1, 5, 1, 0), (6, 2, 1, 4, 2, 0),
     (6, 2, 2, 3, 2, 0), (6, 2, 2, 8, 1, 0), (6, 0, 0, 0, 0, 0),
+    # one element per lane, two 64-column tiles (odd strides take this)
+    (6, 1, 2, 3, 2, 0), (6, 1, 0, 4, 1, 0),
 ]
 
 
