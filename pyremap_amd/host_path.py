@@ -91,6 +91,13 @@ def _side_streams(device):
 DEVICE_FRACTION = 0.5
 
 
+def _sampled_nan(values, samples=1 << 16):
+    """Is there a NaN among ~``samples`` evenly strided elements?"""
+    flat = values.reshape(-1)
+    step = max(1, flat.size // samples)
+    return bool(np.isnan(flat[::step]).any())
+
+
 def _any_nan(values, chunk=CHUNK_BYTES):
     """``np.isnan(values).any()`` with an early exit, chunk by chunk."""
     flat = values.reshape(-1)
@@ -200,6 +207,14 @@ def remap_host_array(plan, dst_grid_dims, values, remap_axes, *, mode,
     out_shape = list(values.shape[:lead]) + dst_shape + \
         list(values.shape[lead + len(remap_axes):])
 
+    if mode == 'auto' and host_mask is None and values.dtype.kind == 'f' \
+            and values.nbytes >= 4 * CHUNK_BYTES and _sampled_nan(values):
+        # A NaN was SEEN (a strided sample of the array: microseconds), so
+        # the branch is decided -- masked -- before anything is uploaded, and
+        # the field takes the pipelined routes below instead of waiting whole
+        # on the device for the NaN scan (ocean fields: 36 -> 23 ms per GB).
+        # No NaN in the sample decides nothing: the device scan stays.
+        mode = 'masked'
     if mode == 'auto' and in_place and n_batch >= 2 and host_mask is None:
         # The branch is decided from the whole array (remap_numpy.py:201-204)
         # and the device-side decision needs the whole array resident.  A

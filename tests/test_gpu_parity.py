@@ -1426,6 +1426,25 @@ def test_host_arrays_pinned_pipelined_and_poisoned(dev):
             want_mask=True).result()
         assert_bitwise(data, np.ma.filled(ref, np.nan), 'ring of two')
         assert np.array_equal(mask, np.ma.getmaskarray(ref))
+        # 'auto' on a field whose NaNs a strided sample finds: the branch is
+        # known before the upload, the field streams (no device-side wait)
+        seen = []
+        real_enqueue = host_path._enqueue
+
+        def spy(plan_, dims_, values_, host_, axes_, lead_, nb_, inpl_,
+                mode_, *rest):
+            seen.append(mode_)
+            return real_enqueue(plan_, dims_, values_, host_, axes_, lead_,
+                                nb_, inpl_, mode_, *rest)
+        host_path._enqueue = spy
+        try:
+            got = host_path.remap_host_array(
+                plan, m.dst_dims, series, [1], mode='auto',
+                threshold=0.2).result()
+        finally:
+            host_path._enqueue = real_enqueue
+        assert seen == ['masked']
+        assert_bitwise(got, np.ma.filled(ref, np.nan), 'sampled NaN')
         # a series "too large" to be resident whole: the NaN decision is
         # taken on the host, the data streams
         old_fraction = host_path.DEVICE_FRACTION
