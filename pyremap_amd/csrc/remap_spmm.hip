@@ -309,7 +309,8 @@ typename GroupFn<XT>::type pick_rowgroup_shape(int unr, int tiles, int vec,
                                                int mode, bool fma)
 {
     if (vec == 1)
-        return pick_rowgroup_mode<XT, 2, G, 8, 1>(mode, fma);
+        return tiles == 1 ? pick_rowgroup_mode<XT, 1, G, 8, 1>(mode, fma)
+                          : pick_rowgroup_mode<XT, 2, G, 8, 1>(mode, fma);
     return unr == 4    ? pick_rowgroup_tiles<XT, G, 4>(tiles, mode, fma)
            : unr == 16 ? pick_rowgroup_tiles<XT, G, 16>(tiles, mode, fma)
                        : pick_rowgroup_tiles<XT, G, 8>(tiles, mode, fma);
@@ -565,10 +566,17 @@ int run_rowgroup(const remap_apply_args *a, const Call &c, KParams p,
         tiles = c.f32 ? 2 : (c.K > 128 && c.K <= 224) ? 2 : 1;
     if (tiles != 2 || c.K <= 128)
         tiles = 1;
-    // odd strides or level counts: one element per lane and tile, two tiles
-    const int vec = c.can_vec2 ? 2 : 1;
+    // odd strides or level counts: one element per lane and tile, two tiles.
+    // At most 64 columns (ONE 3-D field: (1, nCells, 60 levels)): one element
+    // per lane fills the wave where two leave half of it idle -- config 3's
+    // map, us per launch, two -> one element: masked 60 levels 83 -> 67, 64:
+    // 80 -> 65, 33: 76 -> 54; frac_b 33 levels 59 -> 53, 48 / 60: a tie, 64
+    // (and 2 x 32): 67 -> 70, hence "fewer than 64" outside the masked mode
+    const bool narrow =
+        c.K <= 64 && (a->mode == REMAP_MODE_MASKED || c.K < 64);
+    const int vec = (c.can_vec2 && !narrow) ? 2 : 1;
     if (vec == 1)
-        tiles = 2;
+        tiles = c.K > 64 ? 2 : 1;
     const int gpw = a->tune[3] > 0 ? a->tune[3] : 2;   // groups per wave
     // union entries in flight
     const int unr = (a->tune[5] == 4 || a->tune[5] == 16) ? a->tune[5] : 8;
