@@ -680,3 +680,21 @@ def test_open_dataset_reads_only_the_requested_variables(tmp_path, fmt):
     assert np.array_equal(some['b'].values, ds['b'].values)
     every = open_dataset(path)
     assert sorted(every.data_vars) == ['a', 'b', 'c']
+
+
+def test_nan_decisions_taken_on_the_host():
+    """The two host-side NaN questions of pyremap_amd/host_path.py: a strided
+    sample that may only answer "yes", and the chunked exact scan."""
+    from pyremap_amd import host_path
+    from pyremap_amd.io import _parallel
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((3, 1000, 17))
+    assert not host_path._sampled_nan(x) and not host_path._any_nan(x)
+    assert not _parallel.any_nan(x)
+    y = x.copy()
+    y[2, 999, 16] = np.nan                      # the very last element
+    assert host_path._any_nan(y, chunk=4096) and _parallel.any_nan(y)
+    z = x.copy()
+    z[1, ::3, 5:] = np.nan                      # a sea floor: the sample sees it
+    assert host_path._sampled_nan(z, samples=256)
+    assert not _parallel.any_nan(np.arange(10))  # integers hold no NaN
