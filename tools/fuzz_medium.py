@@ -1,0 +1,111 @@
+#!/usr/bin/env python3
+"""
+Time-bounded fuzz at medium size (GPU box only): mappings of 5 000-80 000
+source cells onto 100-300 x 100-400 grids -- hundreds of workgroups per
+launch, every K tile rule (flat, whole batches per tile, one batch per
+chunk, one or two elements per lane) -- as `(n, K)` and `(Time, n, levels)`
+fields, float32 / float64, frac_b / masked, whole plan and a row shard, bit
+for bit against the oracle.
+
+    python tools/fuzz_medium.py [seconds=480] [first_seed=0]
+"""
+import os
+import sys
+import time
+
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+sys.path.insert(0, os.path.join(root, 'tests'))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from helpers import assert_bitwise  # noqa: E402
+from oracle import oracle  # noqa: E402
+from pyremap_amd import engine, synthetic  # noqa: E402
+
+LEVELS = [7, 16, 33, 48, 60, 61, 64, 65, 72, 80, 100, 101, 127, 130]
+
+
+def one(seed, dev):
+    rng = np.random.default_rng(10_000 + seed)
+    my, mx = int(rng.integers(100, 300)), int(rng.integers(100, 400))
+    kind = rng.choice(['conservative', 'rich', 'bilinear'])
+    if kind == 'bilinear':
+        m = synthetic.bilinear_map((int(rng.integers(20, 120)),
+                                    int(rng.integers(20, 150))), (my, mx),
+                                   seed=seed, device=dev)
+    else:
+        lo, hi = (1, 7) if kind == 'conservative' else (10, 24)
+        m = synthetic.conservative_map(int(rng.integers(5000, 80000)),
+                                       (my, mx), lo, hi, seed=seed,
+                                       device=dev, signed=kind == 'rich')
+    plan = engine.RemapPlan.from_triplets(m.row, m.col, m.S, m.frac_b, m.n_a,
+                                          m.n_b, device=dev)
+    sched = plan.auto_schedule(m.dst_dims) if rng.random() < 0.85 else None
+    rowptr, col, val = plan.to_host_csr()
+    csr = oracle.OracleCSR(rowptr, col, val, (m.n_b, m.n_a))
+    frac_b = m.frac_b.cpu().numpy()
+    for case in range(3):
+        if rng.random() < 0.4:
+            shape, axis = [m.n_a, int(rng.choice([40, 61, 128, 200, 257]))], 0
+        else:
+            shape = [int(rng.integers(1, 6)), m.n_a, int(rng.choice(LEVELS))]
+            axis = 1
+        dtype = rng.choice([np.float64, np.float32])
+        field = rng.standard_normal(shape).astype(dtype)
+        masked = bool(rng.random() < 0.5)
+        arg, thr = field, None
+        if masked:
+            cells = rng.random(m.n_a) < 0.2
+            if axis == 0:
+                field[cells, shape[1] // 2:] = np.nan
+            else:
+                field[:, cells, shape[2] // 2:] = np.nan
+            thr = float(rng.choice([0.0, 0.05, 0.5]))
+            arg = np.ma.masked_array(field, mask=np.isnan(field))
+        ref = oracle.remap_numpy_array(csr, frac_b, m.dst_dims, arg, [axis],
+                                       thr)
+        ref = np.ma.filled(ref.astype(np.float64), np.nan) \
+            if np.ma.isMaskedArray(ref) else np.asarray(ref)
+        x = torch.from_numpy(field).to(dev)
+        emode = engine.MODE_MASKED if masked else engine.MODE_FRACB
+        y = engine.remap_tensor(plan, m.dst_dims, x, [axis], emode,
+                                threshold=thr or 0.0)
+        what = (f'seed {seed} case {case}: {kind} {m.n_a}->{my}x{mx} '
+                f'{sched and sched.get("family")} shape {shape} '
+                f'{np.dtype(dtype).name} masked={masked} thr {thr}')
+        assert tuple(y.shape) == ref.shape, what
+        assert_bitwise(y.cpu().numpy(), ref, what)
+        r = int(rng.integers(0, 3))
+        shard = plan.shard(r, 3)
+        shard.auto_schedule(m.dst_dims)
+        ys = engine.remap_tensor(shard, None, x, [axis], emode,
+                                 threshold=thr or 0.0)
+        lead = shape[:axis]
+        flat = ref.reshape(tuple(lead) + (m.n_b,) + tuple(shape[axis + 1:]))
+        lo = shard.row_offset
+        want = np.take(flat, np.arange(lo, lo + shard.n_b), axis=axis)
+        assert_bitwise(ys.cpu().numpy(), want, what + f' shard {r}/3')
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 480.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    dev = torch.device('cuda', 0)
+    t0, n, bad = time.time(), 0, []
+    while time.time() - t0 < budget and len(bad) < 4:
+        try:
+            one(seed, dev)
+            n += 1
+        except Exception as exc:   # noqa: BLE001 - reported
+            print('SEED', seed, 'FAILED', type(exc).__name__, str(exc)[:400])
+            bad.append(seed)
+        seed += 1
+    print(f'seeds ok: {n}, failed: {bad}, next seed {seed}, '
+          f'{time.time() - t0:.0f} s')
+    return 1 if bad else 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())
