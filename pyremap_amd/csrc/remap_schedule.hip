@@ -890,7 +890,7 @@ int schedule_auto(const remap_csr *A, const double *frac_b,
                 if (rc != REMAP_OK)
                     return rc;
                 const int64_t footprint = (st3[1] + 1) * row_bytes +
-                                          st3[2] * 12 + rows * 16 + 32;
+                                          st3[2] * 12 + rows * 24 + 32;
                 if (footprint > kAutoLdsBudget)
                     continue;   // does not fit: the next, smaller tile
                 fits = true;

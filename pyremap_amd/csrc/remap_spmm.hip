@@ -33,6 +33,8 @@
 //    the chunk-major work list, so the ~nnz/n_a re-touches of a source row by
 //    neighbouring destination rows hit that XCD's L2 instead of going back
 //    to Infinity Cache / HBM eight times.
+#include <type_traits>
+
 #include "remap_common.h"
 
 namespace remap {

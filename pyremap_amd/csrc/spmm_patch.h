@@ -34,17 +34,19 @@ constexpr int kPatchWaves = kPatchBlock / kWave;
 
 // LDS image of one workgroup (row_bytes = 1024 or 512 per staged row chunk):
 //   [0, (umax + 1) * row_bytes)  the distinct source-row chunks
-//   then                   val  f64[emax]   the patch's weights, slot order
+//   then                   hdr  16 B[rows]  per row: element offset of its
+//                                           Y row (int64), first entry, one
+//                                           past its last entry (int32 each)
+//                                           -- ONE 16-byte read per row
+//                          val  f64[emax]   the patch's weights, slot order
 //                          fb   f64[rows]   frac_b of the patch's rows
 //                          lidx i32[emax]   their local row indices
-//                          rptr i32[rows+1] entry offsets of the patch's rows
-//                          rid  i32[rows]   the rows' ids
 __host__ __device__ inline uint32_t patch_lds_bytes(int umax, int emax,
                                                     int rows, int row_bytes)
 {
     return (static_cast<uint32_t>(umax) + 1u) * row_bytes +
            static_cast<uint32_t>(emax) * 12u +
-           static_cast<uint32_t>(rows) * 16u + 32u;
+           static_cast<uint32_t>(rows) * 24u + 32u;
 }
 
 // WC = columns per K-chunk: 128 (two doubles per lane, 1 KiB per staged row)
@@ -92,12 +94,15 @@ __global__ __launch_bounds__(kPatchBlock) void spmm_patch(
     }
     const int sub = lane / (kWave / kRowsPerDma);  // which row of the pair
 
-    double *lds_val =
-        reinterpret_cast<double *>(lds + (umax + 1) * kRowBytes);
+    struct alignas(16) RowHeader {   // what a wave needs to start a row
+        int64_t ybase;        // element offset of the row in Y (row * ldy)
+        int32_t s, e;         // its entries [s, e) in lds_val / lds_lidx
+    };
+    RowHeader *lds_hdr =
+        reinterpret_cast<RowHeader *>(lds + (umax + 1) * kRowBytes);
+    double *lds_val = reinterpret_cast<double *>(lds_hdr + patch_rows);
     double *lds_fb = lds_val + emax;
     int32_t *lds_lidx = reinterpret_cast<int32_t *>(lds_fb + patch_rows);
-    int32_t *lds_rptr = lds_lidx + emax;
-    int32_t *lds_rid = lds_rptr + patch_rows + 1;
 
     // 1. gather: distinct source rows by LDS-DMA, the patch's entries by
     //    plain loads (they are contiguous: patch-major CSR).  The phase is a
@@ -121,7 +126,8 @@ __global__ __launch_bounds__(kPatchBlock) void spmm_patch(
     const int32_t rid_ld = ro[tc];
     const int32_t my_rid =
         row_order ? rid_ld : static_cast<int32_t>(slot0 + tc);
-    const int32_t my_rp = prow[local0 + (tid <= nrows ? tid : nrows)];
+    const int32_t my_rp = prow[local0 + (tid < nrows ? tid : nrows)];
+    const int32_t my_rp1 = prow[local0 + (tid < nrows ? tid + 1 : nrows)];
     constexpr int kPre = 2;  // entry batches held in registers meanwhile
     double ev[kPre];
     int32_t el[kPre];
@@ -164,12 +170,17 @@ __global__ __launch_bounds__(kPatchBlock) void spmm_patch(
         lds_val[t] = pval[e0 + t];
         lds_lidx[t] = plidx[e0 + t];
     }
-    if (tid <= nrows)
-        lds_rptr[tid] = my_rp - e0;
+    bool plain_row = true;   // frac_b == 1: the row needs no normalising
     if (tid < nrows) {
-        lds_rid[tid] = my_rid;
-        if constexpr (MODE == REMAP_MODE_FRACB)
+        RowHeader h;
+        h.ybase = static_cast<int64_t>(my_rid) * p.ldy;
+        h.s = my_rp - e0;
+        h.e = my_rp1 - e0;
+        lds_hdr[tid] = h;
+        if constexpr (MODE == REMAP_MODE_FRACB) {
             lds_fb[tid] = my_fb;
+            plain_row = my_fb == 1.0;
+        }
     }
     // 2. everything landed, visible to every wave.  The LDS-DMA rows are
     //    tracked by vmcnt, and a workgroup barrier on gfx950 drains only
@@ -177,61 +188,111 @@ __global__ __launch_bounds__(kPatchBlock) void spmm_patch(
     //    emit this wait today, from register dependencies; nothing obliges it
     //    to), so no wave passes the barrier with rows still in flight.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // (the barrier also answers: is frac_b 1 on every row of the patch? --
+    // bilinear maps: yes everywhere -- then the compute loop below runs
+    // without loading, testing or dividing by it)
+    const bool all_plain =
+        MODE == REMAP_MODE_FRACB ? __syncthreads_and(plain_row) != 0
+                                 : (__syncthreads(), false);
 
-    // 3. compute the patch's rows from LDS
+    // 3. compute the patch's rows from LDS.  The patch kernel is the one
+    //    instruction-issue-bound kernel of the library (DESIGN.md section 6:
+    //    its time follows the clock), so the row loop is kept short: one
+    //    16-byte header read per row, the Y offset precomputed at gather
+    //    time, and no frac_b handling at all when it is 1 on the whole patch.
     const char *mine = lds + lane * (VEC * 8);
-    // the next row's header (id, entry range, frac_b) is read while this
-    // row is being computed: short rows (4 entries of a bilinear map) are a
-    // chain of LDS round trips otherwise
-    int32_t nx_rid = 0, nx_s = 0, nx_e = 0;
-    double nx_fb = 0.0;
-    if (wave < nrows) {
-        nx_rid = lds_rid[wave];
-        nx_s = lds_rptr[wave];
-        nx_e = lds_rptr[wave + 1];
-        if constexpr (MODE == REMAP_MODE_FRACB)
-            nx_fb = lds_fb[wave];
-    }
-    for (int r = wave; r < nrows; r += kPatchWaves) {
-        const int64_t i = __builtin_amdgcn_readfirstlane(nx_rid);
-        const int s = __builtin_amdgcn_readfirstlane(nx_s);
-        const int e = __builtin_amdgcn_readfirstlane(nx_e);
-        const double fb_row = nx_fb;
-        if (r + kPatchWaves < nrows) {
-            nx_rid = lds_rid[r + kPatchWaves];
-            nx_s = lds_rptr[r + kPatchWaves];
-            nx_e = lds_rptr[r + kPatchWaves + 1];
-            if constexpr (MODE == REMAP_MODE_FRACB)
-                nx_fb = lds_fb[r + kPatchWaves];
+    auto rows_loop = [&](auto plain_tag) {
+        constexpr bool PLAIN = decltype(plain_tag)::value;
+        // the next row's header (and frac_b) is read while this row is being
+        // computed: short rows (4 entries of a bilinear map) are a chain of
+        // LDS round trips otherwise
+        RowHeader nx = {0, 0, 0};
+        double nx_fb = 0.0;
+        if (wave < nrows) {
+            nx = lds_hdr[wave];
+            if constexpr (MODE == REMAP_MODE_FRACB && !PLAIN)
+                nx_fb = lds_fb[wave];
         }
-        double acc[1][VEC];
-        double den[1][VEC];
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-            acc[0][v] = 0.0;
-            den[0][v] = 0.0;
-        }
-#pragma unroll 4
-        for (int jj = s; jj < e; ++jj) {
-            // (index, weight) by LDS broadcast (same address in every lane);
-            // measured faster than one coalesced read + v_readlane
-            const int32_t li = lds_lidx[jj];
-            const double a = lds_val[jj];
-            const xvec_t xq = *reinterpret_cast<const xvec_t *>(
-                mine + li * kRowBytes);
+        for (int r = wave; r < nrows; r += kPatchWaves) {
+            const int64_t ybase =
+                (static_cast<int64_t>(__builtin_amdgcn_readfirstlane(
+                     static_cast<int32_t>(nx.ybase >> 32)))
+                 << 32) |
+                static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(
+                    static_cast<int32_t>(nx.ybase)));
+            const int s = __builtin_amdgcn_readfirstlane(nx.s);
+            const int e = __builtin_amdgcn_readfirstlane(nx.e);
+            const double fb_row = nx_fb;
+            if (r + kPatchWaves < nrows) {
+                nx = lds_hdr[r + kPatchWaves];
+                if constexpr (MODE == REMAP_MODE_FRACB && !PLAIN)
+                    nx_fb = lds_fb[r + kPatchWaves];
+            }
+            double acc[1][VEC];
+            double den[1][VEC];
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
-                const double x = elem<xvec_t, VEC>(xq, v);
-                if constexpr (MODE == REMAP_MODE_MASKED) {
-                    const bool valid = (x == x);
-                    acc[0][v] = mul_add<FMA>(a, valid ? x : 0.0, acc[0][v]);
-                    den[0][v] = den_add(a, valid ? 1.0 : 0.0, den[0][v]);
-                } else {
-                    acc[0][v] = mul_add<FMA>(a, x, acc[0][v]);
+                acc[0][v] = 0.0;
+                den[0][v] = 0.0;
+            }
+#pragma unroll 4
+            for (int jj = s; jj < e; ++jj) {
+                // (index, weight) by LDS broadcast (same address in every
+                // lane); measured faster than one coalesced read + v_readlane
+                const int32_t li = lds_lidx[jj];
+                const double a = lds_val[jj];
+                const xvec_t xq = *reinterpret_cast<const xvec_t *>(
+                    mine + li * kRowBytes);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    const double x = elem<xvec_t, VEC>(xq, v);
+                    if constexpr (MODE == REMAP_MODE_MASKED) {
+                        const bool valid = (x == x);
+                        acc[0][v] =
+                            mul_add<FMA>(a, valid ? x : 0.0, acc[0][v]);
+                        den[0][v] =
+                            den_add(a, valid ? 1.0 : 0.0, den[0][v]);
+                    } else {
+                        acc[0][v] = mul_add<FMA>(a, x, acc[0][v]);
+                    }
                 }
             }
+            if (!act[0])
+                continue;
+            double y[VEC];
+            bool ok[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                if constexpr (MODE == REMAP_MODE_RAW || PLAIN) {
+                    // (x / 1.0 == x exactly)
+                    ok[v] = true;
+                    y[v] = acc[0][v];
+                } else if constexpr (MODE == REMAP_MODE_FRACB) {
+                    ok[v] = fb_row > 0.0;
+                    y[v] = !ok[v] ? __builtin_nan("")
+                           : (fb_row == 1.0) ? acc[0][v]
+                                             : acc[0][v] / fb_row;
+                } else {
+                    ok[v] = den[0][v] > p.thr;
+                    y[v] = ok[v] ? acc[0][v] / den[0][v]
+                                 : __builtin_nan("");
+                }
+            }
+            const int64_t o = ybase + yoff[0];
+            if (REMAP_DIAG_SKIP_STORE(p, y[0]))
+                continue;
+            store_y<VEC>(p.Y + o, y);
+#ifndef REMAP_STAMPS
+            if (p.mask_out) {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v)
+                    p.mask_out[o + v] = ok[v] ? 0 : 1;
+            }
+#endif
         }
-        finish_row<VEC, 1, MODE>(p, i, fb_row, act, yoff, acc, den);
-    }
+    };
+    if (all_plain)
+        rows_loop(std::true_type());
+    else
+        rows_loop(std::false_type());
 }

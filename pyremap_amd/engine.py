@@ -689,9 +689,9 @@ class RemapPlan:
                     _ptr(lidx), _ptr(pval), _ptr(stats), _ptr(ws),
                     ws.numel(), _stream_ptr(dev)), 'remap_patches_build')
                 distinct, umax, emax = (int(v) for v in stats.cpu())
-                # entries staged next to the rows: 12 B each (+16 B per row)
+                # entries staged next to the rows: 12 B each (+24 B per row)
                 footprint = (umax + 1) * row_bytes + emax * 12 + \
-                    rows * 16 + 32
+                    rows * 24 + 32
                 if footprint <= lds_budget:
                     break
                 if rows == 1:
