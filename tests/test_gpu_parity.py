@@ -1890,3 +1890,72 @@ def test_bench_multi_rank_line_survives_a_hung_exchange(tmp_path):
         multi = line['multi_gpu']
         assert multi['broadcast_ms'] > 0 and multi['kernel_phase_ms'] > 0
         assert ('optional_measurements' in multi) == bool(env_extra)
+
+
+def test_plan_handle_device_inputs_and_strided_fields(dev):
+    """
+    The opaque plan handle beyond what INTEGRATION.md's stub uses: triplets
+    given as DEVICE arrays (host_input = 0), a `(Time, nCells, levels)` field
+    addressed in place through remap_field's strides, float32 input, the
+    masked branch with a byte mask -- against the oracle, bit for bit.
+    """
+    import ctypes
+    from oracle import oracle
+    from pyremap_amd import engine, synthetic
+    lib = engine.load_library()
+    m = synthetic.conservative_map(4000, (36, 50), 1, 7, seed=44)
+    mm = m.numpy()
+    dims = (ctypes.c_int64 * 2)(*m.dst_dims)
+    row = torch.as_tensor(mm['row'], dtype=torch.int32, device=dev)
+    col = torch.as_tensor(mm['col'], dtype=torch.int32, device=dev)
+    S = torch.as_tensor(mm['S'], dtype=torch.float64, device=dev)
+    fb = torch.as_tensor(mm['frac_b'], dtype=torch.float64, device=dev)
+    handle = ctypes.c_void_p()
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = lib.remap_plan_create(
+        m.n_b, m.n_a, S.numel(), row.data_ptr(), col.data_ptr(),
+        S.data_ptr(), 1, fb.data_ptr(), 0, dims, 2, stream,
+        ctypes.byref(handle))
+    assert rc == 0, lib.remap_last_error()
+    del row, col, S, fb                       # not retained by the plan
+    try:
+        csr = oracle.coo_to_csr(mm['row'] - 1, mm['col'] - 1, mm['S'], m.n_b,
+                                m.n_a)
+        rng = np.random.default_rng(3)
+        T, L = 3, 60
+        for dtype in (np.float64, np.float32):
+            field = rng.standard_normal((T, m.n_a, L)).astype(dtype)
+            field[:, rng.random(m.n_a) < 0.2, 30:] = np.nan
+            for masked in (False, True):
+                arg = np.ma.masked_array(field, np.isnan(field)) if masked \
+                    else field
+                ref = oracle.remap_numpy_array(csr, mm['frac_b'], m.dst_dims,
+                                               arg, [1],
+                                               0.1 if masked else None)
+                X = torch.from_numpy(field).to(dev)
+                Y = torch.full((T, m.n_b, L), 5.0, dtype=torch.float64,
+                               device=dev)
+                M = torch.zeros((T, m.n_b, L), dtype=torch.uint8, device=dev)
+                f = engine._Field()
+                f.X, f.Y = X.data_ptr(), Y.data_ptr()
+                f.x_dtype = engine.DTYPE_F64 if dtype == np.float64 \
+                    else engine.DTYPE_F32
+                f.mode = engine.MODE_MASKED if masked else engine.MODE_FRACB
+                f.n_batch, f.k_inner = T, L
+                f.x_row_stride, f.x_batch_stride = L, m.n_a * L
+                f.y_row_stride, f.y_batch_stride = L, m.n_b * L
+                f.threshold = 0.1
+                f.mask_out = M.data_ptr()
+                rc = lib.remap_plan_apply(handle, ctypes.byref(f), stream)
+                assert rc == 0, lib.remap_last_error()
+                got = Y.cpu().numpy().reshape((T,) + tuple(m.dst_dims) + (L,))
+                want = np.ma.filled(np.ma.masked_array(ref).astype(
+                    np.float64), np.nan)
+                what = f'plan handle {np.dtype(dtype).name} masked={masked}'
+                assert_bitwise(got, want, what)
+                assert np.array_equal(
+                    M.cpu().numpy().astype(bool).reshape(got.shape),
+                    np.ma.getmaskarray(np.ma.masked_array(ref))), what
+        torch.cuda.synchronize()
+    finally:
+        lib.remap_plan_destroy(handle)
