@@ -1959,3 +1959,27 @@ def test_plan_handle_device_inputs_and_strided_fields(dev):
         torch.cuda.synchronize()
     finally:
         lib.remap_plan_destroy(handle)
+
+
+def test_c_abi_from_plain_c(tmp_path):
+    """examples/c_abi_plan.c -- gcc, no Python, no C++: the plan handle from
+    C, every value compared in C with a sequential multiply-then-add."""
+    import shutil
+    import subprocess
+    from pyremap_amd import engine
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gcc = shutil.which('gcc')
+    if gcc is None or not os.path.exists('/opt/rocm/lib/libamdhip64.so'):
+        pytest.skip('needs gcc and the HIP runtime library')
+    lib_dir = os.path.dirname(engine.library_path())
+    exe = str(tmp_path / 'c_abi_plan')
+    subprocess.run(
+        [gcc, '-O2', '-ffp-contract=off', '-D__HIP_PLATFORM_AMD__',
+         '-I/opt/rocm/include', '-I' + os.path.join(repo, 'include'),
+         os.path.join(repo, 'examples', 'c_abi_plan.c'), '-o', exe,
+         '-L' + lib_dir, '-lremap_hip', '-L/opt/rocm/lib', '-lamdhip64',
+         '-Wl,-rpath,' + lib_dir, '-Wl,-rpath,/opt/rocm/lib', '-lm'],
+        check=True, capture_output=True, text=True)
+    proc = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert proc.returncode == 0, proc.stdout + proc.stderr
+    assert ' 0 differ' in proc.stdout and 'gfx950' in proc.stdout
