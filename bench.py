@@ -64,7 +64,7 @@ def parse_args():
                     help="'nk': field (n_a, K); 'tnl': (T=8, n_a, K/8); "
                          "'tn': (T=K, n_a)")
     ap.add_argument('--locality', default='raster',
-                    choices=['raster', 'none'])
+                    choices=['raster', 'mesh', 'scatter', 'none'])
     ap.add_argument('--shard', default='rows', choices=['rows', 'fields'])
     ap.add_argument('--sets', type=int, default=3,
                     help='distinct X/Y buffer sets rotated over the steps')

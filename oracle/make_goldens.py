@@ -429,6 +429,48 @@ def golden_g2(ref):
 
 
 # --------------------------------------------------------------------------
+# G6: the REAL QU240 cell numbering (icosahedral-bisection order, nothing
+# like the destination raster): cell centres from the reference's mesh
+# fixture, overlap-like weights to the 1-degree grid by nearest centres,
+# columns = the mesh's own cell ids, the reference's fixture fields
+# --------------------------------------------------------------------------
+
+def golden_g6(ref):
+    import torch
+    from scipy.io import netcdf_file
+
+    from pyremap_amd import synthetic
+    base = os.path.join(REF, 'tests', 'test_interpolate')
+    with netcdf_file(os.path.join(base, 'mpasMesh.nc'), 'r',
+                     mmap=False) as nc:
+        lat = np.array(nc.variables['latCell'][:], dtype=np.float64)
+        lon = np.array(nc.variables['lonCell'][:], dtype=np.float64)
+    cells = os.path.join(OUT, 'qu240_cells.npz')
+    np.savez_compressed(cells, latCell=lat, lonCell=lon)
+    print(f'wrote {cells}: {lat.shape[0]} cell centres')
+    with netcdf_file(os.path.join(base, 'timeSeries.0002-01-01.nc'), 'r',
+                     mmap=False) as nc:
+        ssh = np.array(nc.variables['timeMonthly_avg_ssh'][:],
+                       dtype=np.float64)
+        mld = np.array(nc.variables['timeMonthly_avg_tThreshMLD'][:],
+                       dtype=np.float64)
+    sm = synthetic.knn_map(torch.from_numpy(lat), torch.from_numpy(lon),
+                           (180, 360), k_hi=4, seed=6)
+    m = sm.numpy()
+    rng = np.random.default_rng(606)
+    both = np.stack([ssh[0], mld[0]], axis=1)       # (nCells, 2)
+    land = both.copy()
+    land[rng.random(7153) < 0.25, :] = np.nan
+    cases = [
+        dict(field=ssh, remap_axes=[1], thr=None),
+        dict(field=mld, remap_axes=[1], thr=0.01),
+        dict(field=land, remap_axes=[0], thr=0.01),
+    ]
+    run_array_cases(ref, 'g6_qu240_real_numbering', m, ['nCells'],
+                    ['lat', 'lon'], cases)
+
+
+# --------------------------------------------------------------------------
 # G3: Dataset / DataArray level (a2, a3, a4) and the error messages
 # --------------------------------------------------------------------------
 
@@ -609,6 +651,7 @@ def main():
     golden_g3(ref)
     golden_unstable(ref)
     golden_g5(ref)
+    golden_g6(ref)
 
 
 if __name__ == '__main__':

@@ -22,7 +22,12 @@ on the GPU; with ``device='cpu'`` they serve the CPU tests.
   ``frac_b = 0``; every source cell the draws missed is then given to the
   destination cell that contains it, so -- like a real overlap map -- no
   source cell goes unread (``cover``): configs 2, 3, 5 and the north-star
-  headline H.
+  headline H.  ``locality='mesh'`` keeps that geometry and RENUMBERS the
+  source cells the way an MPAS mesh numbers its cells (:func:`mesh_numbering`)
+  -- no real mesh is numbered along the destination raster;
+  ``locality='scatter'`` renumbers them at random (no id locality at all).
+* :func:`knn_map`          overlap-like weights from REAL cell centres (the
+  QU240 mesh of the reference's test fixtures) to a regular lat-lon grid.
 """
 
 CONFIGS = {
@@ -193,7 +198,7 @@ def conservative_map(n_a, dst_dims, k_lo, k_hi, seed=0, device='cpu',
             k[a:b].unsqueeze(1)
         sel = order[take]                      # window slots, row-major
         r = rows[a:b].unsqueeze(1).expand(n, win)[take]
-        if locality == 'raster':
+        if locality in ('raster', 'mesh', 'scatter'):
             oy = sel // win_x - half_y
             ox = sel % win_x - half_x
             qy = torch.clamp(jy[r] + oy, 0, my - 1)
@@ -224,7 +229,7 @@ def conservative_map(n_a, dst_dims, k_lo, k_hi, seed=0, device='cpu',
     S = torch.cat(chunks_val) if chunks_val else \
         torch.zeros(0, device=dev, dtype=torch.float64)
 
-    if cover and locality == 'raster' and row.numel():
+    if cover and locality != 'none' and row.numel():
         # A conservative map touches EVERY source cell (each one overlaps at
         # least the destination cell it lies in).  The random draws above
         # miss some (1 % on config 3, 20 % on the headline, whose source is
@@ -243,6 +248,23 @@ def conservative_map(n_a, dst_dims, k_lo, k_hi, seed=0, device='cpu',
             col = torch.cat([col, orphan])
             S = torch.cat([S, w])
 
+    if locality == 'mesh':
+        # same overlaps, the source cells numbered as a mesh generator
+        # numbers them: a column permutation of the 'raster' matrix
+        ocean_rows = ocean.nonzero().squeeze(1)
+        owner = torch.clamp((torch.arange(n_a, device=dev,
+                                          dtype=torch.float64) / ratio)
+                            .to(torch.int64), 0, n_ocean - 1)
+        sub = torch.arange(n_a, device=dev, dtype=torch.float64) / ratio - \
+            owner.to(torch.float64)
+        q = ocean_rows[owner]
+        col = mesh_numbering(jy[q].to(torch.float64),
+                             jx[q].to(torch.float64) + sub, seed=seed)[col]
+
+    if locality == 'scatter':
+        # same overlaps, source ids at random: no id locality whatsoever
+        col = torch.randperm(n_a, generator=gen, device=dev)[col]
+
     # scale rows to sum to frac_b in (0, 1]
     rowsum = torch.zeros(n_b, device=dev, dtype=torch.float64)
     rowsum.index_add_(0, row, S)
@@ -251,6 +273,192 @@ def conservative_map(n_a, dst_dims, k_lo, k_hi, seed=0, device='cpu',
     frac_b = torch.where(k > 0, frac_b, torch.zeros_like(frac_b))
     safe = torch.where(rowsum.abs() > 1e-3, rowsum, torch.ones_like(rowsum))
     S = S * (frac_b / safe)[row]
+    if shuffle:
+        row, col, S = _shuffle(row, col, S, gen)
+    return SyntheticMap((row + 1).to(torch.int32), (col + 1).to(torch.int32),
+                        S, frac_b, n_a, n_b, (n_a,), (my, mx))
+
+
+def mesh_numbering(py, px, seed=0, scramble=True):
+    """
+    Number cells the way an MPAS mesh does, given their positions (any two
+    coordinates in which neighbours are close): returns the int64 tensor
+    ``new_id[cell]``, a permutation of ``range(len(py))``.
+
+    MPAS meshes made by icosahedral bisection (the reference's QU240 fixture,
+    ``tests/test_interpolate/mpasMesh.nc``) number the coarsest points first
+    and every refinement level behind the previous ones, the new points of a
+    level in the order of the (coarser) points they were created around.
+    Measured on that file: a cell's id neighbours are its spatial neighbours
+    (the rings of 6 around a parent: median distance between consecutive ids
+    1.7 cell spacings), but of a cell's spatial neighbours only 20 % have an
+    id within 2 of its own and 75 % are more than n/6 away (median n/2.8); the
+    ids met along one 1-degree latitude row span 90 % of the id range.
+
+    The same construction on a quad hierarchy: cells are ranked along a
+    Morton curve through their positions (the top of the hierarchy scrambled,
+    as the icosahedron's faces come in no raster order); the base-4 digits of
+    the rank are the path through the hierarchy; a cell whose lowest non-zero
+    digit is digit t belongs to level t (3/4 of the cells to the finest), its
+    parent is the cell with that digit cleared, and level t is numbered
+    behind all coarser levels, its cells sorted by their parent's NEW id.
+    """
+    torch = _torch()
+    dev = py.device
+    n = int(py.shape[0])
+    if n == 0:
+        return torch.zeros(0, dtype=torch.int64, device=dev)
+    py = py.to(torch.float64)
+    px = px.to(torch.float64)
+    ey = float(py.max() - py.min()) + 1e-9
+    ex = float(px.max() - px.min()) + 1e-9
+    spacing = max((ey * ex / n) ** 0.5, 1e-12)
+    scale = min(4.0 / spacing, ((1 << 20) - 1) / max(ey, ex))
+    qy = ((py - py.min()) * scale).to(torch.int64)
+    qx = ((px - px.min()) * scale).to(torch.int64)
+    code = torch.zeros(n, dtype=torch.int64, device=dev)
+    for bit in range(20):
+        code |= ((qx >> bit) & 1) << (2 * bit)
+        code |= ((qy >> bit) & 1) << (2 * bit + 1)
+    # rank along the curve (ties: input order)
+    by_code = torch.argsort(code, stable=True)
+    rank = torch.empty(n, dtype=torch.int64, device=dev)
+    rank[by_code] = torch.arange(n, device=dev)
+    digits = 1
+    while 4 ** digits < n:
+        digits += 1
+    if scramble and digits >= 3:
+        bs = 4 ** (digits - 2)
+        whole = n // bs
+        g = torch.Generator(device='cpu')
+        g.manual_seed(int(seed) + 7919)
+        perm = torch.arange((n + bs - 1) // bs, dtype=torch.int64)
+        perm[:whole] = torch.randperm(whole, generator=g)
+        rank = perm.to(dev)[rank // bs] * bs + rank % bs
+    # trailing zero base-4 digits = level (0: finest); rank 0 is the root
+    level = torch.full((n,), digits, dtype=torch.int64, device=dev)
+    for t in range(digits - 1, -1, -1):
+        level = torch.where((rank >> (2 * t)) & 3 != 0,
+                            torch.full_like(level, t), level)
+    cell_of_rank = torch.empty(n, dtype=torch.int64, device=dev)
+    cell_of_rank[rank] = torch.arange(n, device=dev)
+    new_of_rank = torch.zeros(n, dtype=torch.int64, device=dev)
+    done = 1                                  # the root keeps id 0
+    for t in range(digits - 1, -1, -1):
+        r = (level[cell_of_rank] == t).nonzero().squeeze(1)   # ranks, level t
+        if r.numel() == 0:
+            continue
+        d = (r >> (2 * t)) & 3
+        parent = r & ~(3 << (2 * t))
+        key = new_of_rank[parent] * 4 + d
+        new_of_rank[r[torch.argsort(key, stable=True)]] = \
+            done + torch.arange(r.numel(), device=dev)
+        done += int(r.numel())
+    return new_of_rank[rank]
+
+
+def numbering_stats(py, px, ids=None, row_of=None):
+    """
+    The statistics :func:`mesh_numbering` is calibrated with, for cells at
+    positions ``(py, px)`` carrying ``ids`` (default: their index):
+    median distance between consecutive ids in mean cell spacings, the id
+    jumps between each cell and its 4 nearest neighbours (fraction within 2,
+    median / n), and -- with ``row_of`` (an integer per cell: the destination
+    grid row it lies in) -- the median fraction of the id range one such row
+    spans.  Brute force in chunks: for tests and DESIGN.md, not for the path.
+    """
+    torch = _torch()
+    n = int(py.shape[0])
+    ids = torch.arange(n) if ids is None else ids.cpu()
+    py, px = py.cpu().to(torch.float64), px.cpu().to(torch.float64)
+    pos = torch.stack([py, px], 1)
+    by_id = torch.argsort(ids)
+    p = pos[by_id]
+    ey = float(py.max() - py.min()) + 1e-9
+    ex = float(px.max() - px.min()) + 1e-9
+    spacing = (ey * ex / n) ** 0.5
+    step = (p[1:] - p[:-1]).norm(dim=1) / spacing
+    g = torch.Generator()
+    g.manual_seed(0)
+    sample = torch.randperm(n, generator=g)[:2000]
+    jumps = []
+    for a in range(0, sample.numel(), 250):
+        sidx = sample[a:a + 250]
+        d = torch.cdist(pos[sidx], pos)
+        nn = d.topk(5, largest=False).indices[:, 1:]
+        jumps.append((ids[nn] - ids[sidx].unsqueeze(1)).abs().flatten())
+    jumps = torch.cat(jumps).to(torch.float64)
+    out = dict(n=n, consecutive_id_distance_median=float(step.median()),
+               neighbour_jump_within_2=float((jumps <= 2).double().mean()),
+               neighbour_jump_median_over_n=float(jumps.median()) / n,
+               neighbour_jump_q25_over_n=float(jumps.quantile(0.25)) / n)
+    if row_of is not None:
+        row_of = row_of.cpu()
+        spans = []
+        for r in torch.unique(row_of).tolist():
+            sel = ids[row_of == r]
+            if sel.numel() >= 8:
+                spans.append(float(sel.max() - sel.min()) / n)
+        if spans:
+            out['row_id_span_median'] = float(
+                torch.tensor(spans).median())
+    return out
+
+
+def knn_map(lat_src, lon_src, dst_dims, k_hi=4, seed=0, device='cpu',
+            reach=1.2, shuffle=True):
+    """
+    Overlap-like weights from REAL cell centres (radians; e.g. ``latCell`` /
+    ``lonCell`` of the QU240 mesh, ``tests/golden/qu240_cells.npz``) to a
+    regular ``dst_dims = (nlat, nlon)`` global grid: every destination cell
+    takes the (at most ``k_hi``) source cells whose centres lie within
+    ``reach`` source spacings of its own, weights falling off linearly with
+    distance, rows scaled to ``frac_b``; destination cells with no source
+    cell in reach (land on an ocean mesh) stay empty with ``frac_b = 0``.
+    The column indices are the mesh's own cell numbers -- what a mapping file
+    made from that mesh holds.
+    """
+    torch = _torch()
+    dev = torch.device(device)
+    gen = _gen(seed, dev)
+    lat = torch.as_tensor(lat_src, dtype=torch.float64, device=dev)
+    lon = torch.as_tensor(lon_src, dtype=torch.float64, device=dev)
+    n_a = int(lat.shape[0])
+    my, mx = (int(d) for d in dst_dims)
+    n_b = my * mx
+    src = torch.stack([lat.cos() * lon.cos(), lat.cos() * lon.sin(),
+                       lat.sin()], 1)
+    # mean spacing of the source cells where there are any (chord length)
+    d_nn = []
+    for a in range(0, min(n_a, 2000), 500):
+        d = torch.cdist(src[a:a + 500], src)
+        d_nn.append(d.topk(2, largest=False).values[:, 1])
+    spacing = float(torch.cat(d_nn).median())
+    dlat = (torch.arange(my, device=dev, dtype=torch.float64) + 0.5) * \
+        (torch.pi / my) - torch.pi / 2
+    dlon = (torch.arange(mx, device=dev, dtype=torch.float64) + 0.5) * \
+        (2 * torch.pi / mx) - torch.pi
+    rows, cols, vals = [], [], []
+    per = max(1, (1 << 25) // max(n_a, 1))
+    for a in range(0, n_b, per):
+        r = torch.arange(a, min(a + per, n_b), device=dev)
+        la, lo = dlat[r // mx], dlon[r % mx]
+        dst = torch.stack([la.cos() * lo.cos(), la.cos() * lo.sin(),
+                           la.sin()], 1)
+        d, idx = torch.cdist(dst, src).topk(k_hi, largest=False)
+        w = 1.0 - d / (reach * spacing)
+        keep = w > 0
+        rows.append(r.unsqueeze(1).expand_as(idx)[keep])
+        cols.append(idx[keep])
+        vals.append(w[keep] + 0.05)
+    row, col, S = torch.cat(rows), torch.cat(cols), torch.cat(vals)
+    rowsum = torch.zeros(n_b, device=dev, dtype=torch.float64)
+    rowsum.index_add_(0, row, S)
+    frac_b = torch.rand(n_b, generator=gen, device=dev,
+                        dtype=torch.float64) * 0.9 + 0.1
+    frac_b = torch.where(rowsum > 0, frac_b, torch.zeros_like(frac_b))
+    S = S * (frac_b / torch.where(rowsum > 0, rowsum,
+                                  torch.ones_like(rowsum)))[row]
     if shuffle:
         row, col, S = _shuffle(row, col, S, gen)
     return SyntheticMap((row + 1).to(torch.int32), (col + 1).to(torch.int32),

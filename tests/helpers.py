@@ -8,7 +8,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(REPO, 'tests', 'golden')
 
 
-def golden_files(pattern='g[0125]_*.npz'):
+def golden_files(pattern='g[01256]_*.npz'):
     return sorted(glob.glob(os.path.join(GOLDEN, pattern)))
 
 

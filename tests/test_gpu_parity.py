@@ -595,20 +595,26 @@ def test_config3_full_size_bitwise_and_properties(dev):
                            torch.nan_to_num(y, nan=1e300)), tune
 
 
-@pytest.mark.parametrize('name, mode', [
-    ('config3', 'masked'), ('headline', 'fracb'), ('config4', 'fracb'),
-    ('config5', 'fracb'), ('config5', 'masked')])
-def test_full_size_sampled_rows_bitwise(dev, name, mode):
+@pytest.mark.parametrize('name, mode, locality', [
+    ('config3', 'masked', 'raster'), ('headline', 'fracb', 'raster'),
+    ('config4', 'fracb', 'raster'), ('config5', 'fracb', 'raster'),
+    ('config5', 'masked', 'raster'), ('config3', 'masked', 'mesh'),
+    ('headline', 'fracb', 'mesh'), ('config5', 'fracb', 'mesh'),
+    ('config5', 'masked', 'scatter')])
+def test_full_size_sampled_rows_bitwise(dev, name, mode, locality):
     """
     Every BASELINE configuration at its FULL size, as `Remapper` would run it
     (auto-selected schedule): a few thousand destination rows -- the first,
     the last and a random sample -- are recomputed by the CPU oracle from
     their own CSR rows and must match bit for bit; and the plain
     wave-per-row kernel must agree with the scheduled one on EVERY row.
+    ``locality``: how the synthetic source mesh is numbered -- along the
+    destination raster, as an MPAS mesh numbers its cells
+    (``synthetic.mesh_numbering``), or at random.
     """
     from oracle import oracle
     from pyremap_amd import engine, synthetic
-    m = synthetic.make_config(name, device=dev)
+    m = synthetic.make_config(name, device=dev, locality=locality)
     K = synthetic.CONFIGS[name]['K']
     plan = engine.RemapPlan.from_triplets(m.row, m.col, m.S, m.frac_b,
                                           m.n_a, m.n_b, device=dev)

@@ -1,0 +1,117 @@
+"""
+The synthetic source-cell numberings (pyremap_amd/synthetic.py), without a
+GPU: `mesh_numbering` is a permutation with the statistics of the reference's
+real QU240 mesh (tests/golden/qu240_cells.npz = latCell / lonCell of
+tests/test_interpolate/mpasMesh.nc), `locality='mesh'` is a pure column
+permutation of the raster-numbered map, `knn_map` on the real cell centres
+gives a well-formed mapping that carries the mesh's own ids.
+"""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+
+from pyremap_amd import synthetic  # noqa: E402
+
+
+@pytest.fixture(scope='module')
+def qu240(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'qu240_cells.npz'))
+    return torch.from_numpy(g['latCell']), torch.from_numpy(g['lonCell'])
+
+
+def test_mesh_numbering_is_a_permutation():
+    g = torch.Generator().manual_seed(5)
+    for n in (1, 2, 3, 4, 5, 16, 17, 63, 64, 65, 1000, 4097):
+        py, px = torch.rand(n, generator=g), torch.rand(n, generator=g) * 2
+        ids = synthetic.mesh_numbering(py, px, seed=n)
+        assert ids.dtype == torch.int64
+        assert sorted(ids.tolist()) == list(range(n)), n
+    assert synthetic.mesh_numbering(torch.zeros(0), torch.zeros(0)).numel() \
+        == 0
+    # deterministic in the seed
+    a = synthetic.mesh_numbering(py, px, seed=3)
+    assert torch.equal(a, synthetic.mesh_numbering(py, px, seed=3))
+
+
+def test_mesh_numbering_is_calibrated_to_the_real_qu240_mesh(qu240):
+    """
+    The real mesh (icosahedral bisection order) and the synthetic numbering
+    of as many random points agree on what matters to a gather: consecutive
+    ids are spatial neighbours, most spatial neighbours are far away in id,
+    and one destination latitude row meets ids from the whole range -- none
+    of which holds for the raster numbering the round-2 benchmarks used.
+    """
+    lat, lon = (torch.rad2deg(t) for t in qu240)
+    row_of = torch.floor(lat).long()
+    real = synthetic.numbering_stats(lat, lon, None, row_of=row_of)
+    assert 1.0 < real['consecutive_id_distance_median'] < 2.0
+    assert 0.15 < real['neighbour_jump_within_2'] < 0.3
+    assert 0.25 < real['neighbour_jump_median_over_n'] < 0.45
+    assert real['row_id_span_median'] > 0.7
+
+    g = torch.Generator().manual_seed(1)
+    n = lat.shape[0]
+    py = torch.rand(n, generator=g) * 180
+    px = torch.rand(n, generator=g) * 360
+    row_of = torch.floor(py).long()
+    mesh = synthetic.numbering_stats(
+        py, px, synthetic.mesh_numbering(py, px, seed=0), row_of=row_of)
+    assert 1.0 < mesh['consecutive_id_distance_median'] < 2.0
+    assert 0.15 < mesh['neighbour_jump_within_2'] < 0.35
+    assert 0.2 < mesh['neighbour_jump_median_over_n'] < 0.45
+    assert mesh['row_id_span_median'] > 0.7
+
+    raster = synthetic.numbering_stats(
+        py, px, torch.argsort(torch.argsort(torch.floor(py) * 360 + px)),
+        row_of=row_of)
+    assert raster['neighbour_jump_median_over_n'] < 0.02
+    assert raster['row_id_span_median'] < 0.02
+
+
+@pytest.mark.parametrize('locality', ['mesh', 'scatter'])
+def test_renumbered_map_is_a_column_permutation(locality):
+    a = synthetic.conservative_map(9000, (48, 96), 2, 7, seed=4)
+    b = synthetic.conservative_map(9000, (48, 96), 2, 7, seed=4,
+                                   locality=locality)
+    assert (a.n_a, a.n_b, a.n_s) == (b.n_a, b.n_b, b.n_s)
+    if locality == 'mesh':        # same draws: same rows, weights, frac_b
+        assert torch.equal(a.row, b.row)
+        assert torch.equal(a.S, b.S)
+        assert torch.equal(a.frac_b, b.frac_b)
+        ca, cb = a.col.long() - 1, b.col.long() - 1
+        perm = torch.full((a.n_a,), -1, dtype=torch.long)
+        perm[ca] = cb
+        assert torch.equal(perm[ca], cb)
+        assert perm.unique().numel() == a.n_a      # every cell, once
+    # every source cell is still referenced; ids of one destination row span
+    # most of the id range (raster: well under 10 %)
+    assert b.col.unique().numel() == b.n_a
+    r = (b.row.long() - 1) // 96
+    sel = b.col[r == 24].long()
+    assert int(sel.max() - sel.min()) > 0.6 * b.n_a
+    sel = a.col[((a.row.long() - 1) // 96) == 24].long()
+    assert int(sel.max() - sel.min()) < 0.1 * a.n_a
+
+
+def test_knn_map_on_the_real_cell_centres(qu240):
+    lat, lon = qu240
+    m = synthetic.knn_map(lat, lon, (90, 180), k_hi=4, seed=2)
+    assert (m.n_a, m.n_b, m.dst_dims) == (7153, 90 * 180, (90, 180))
+    row, col = m.row.long() - 1, m.col.long() - 1
+    assert 0 <= int(col.min()) and int(col.max()) < m.n_a
+    assert 0 <= int(row.min()) and int(row.max()) < m.n_b
+    per_row = torch.bincount(row, minlength=m.n_b)
+    assert int(per_row.max()) <= 4
+    empty = per_row == 0                    # land on an ocean mesh
+    assert 0.15 < float(empty.double().mean()) < 0.5
+    assert torch.equal(m.frac_b == 0, empty)
+    rowsum = torch.zeros(m.n_b, dtype=torch.float64).index_add_(0, row, m.S)
+    assert float((rowsum - m.frac_b).abs().max()) < 1e-12
+    # the columns are the mesh's own ids: one latitude row meets ids from
+    # most of the range
+    r = row // 180
+    sel = col[r == 40]
+    assert int(sel.max() - sel.min()) > 0.6 * m.n_a
