@@ -11,14 +11,22 @@ batch of 512 synthetic fields that are already resident in HBM.
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): destination
-rows are sharded over the ranks (nnz-balanced contiguous ranges), rank 0's
-source field reaches the ranks ONCE before the timed region (timed
-separately: `multi_gpu.broadcast_ms` for one RCCL broadcast; after the
-metric, under a watchdog, `multi_gpu.bands_ms` when each rank receives only
-the band of source rows its shard references, point to point), and the timed
-steps contain no collective.  The problem
-size is fixed, so this is strong scaling.  `multi_gpu.pipelined_*` is the
-whole job WITH the exchange, K-chunks pipelined behind the kernel.
+rows are sharded over the ranks (nnz-balanced contiguous ranges), every
+shard lives in the compact space of the source rows it references
+(`RemapPlan.packed`), rank 0's source field reaches the ranks ONCE before the
+timed region (one RCCL broadcast, timed separately: `multi_gpu.broadcast_ms`,
+then each rank gathers its packed rows), and the timed steps contain no
+collective.  After the metric, under a watchdog, `multi_gpu.packed_ms` times
+the exchange in which each rank receives ONLY its packed rows (one
+all_to_all_single) and `multi_gpu.pipelined_*` the whole job WITH the
+exchange, K-chunks pipelined behind the kernel.  The problem size is fixed,
+so this is strong scaling.
+
+The source cells of the synthetic conservative maps are numbered the way an
+MPAS mesh numbers its cells (`synthetic.mesh_numbering`, calibrated to the
+reference's QU240 fixture), not along the destination raster;
+`roofline.workloads.config3_raster_numbering` is the same map in the raster
+numbering round 2 measured.
 
 Prints ONE JSON line on rank 0.  `value` = destination cell-fields per second
 for the whole job; `roofline` prices the kernel against HBM bandwidth using
@@ -63,8 +71,12 @@ def parse_args():
     ap.add_argument('--layout', default='nk', choices=['nk', 'tnl', 'tn'],
                     help="'nk': field (n_a, K); 'tnl': (T=8, n_a, K/8); "
                          "'tn': (T=K, n_a)")
-    ap.add_argument('--locality', default='raster',
-                    choices=['raster', 'mesh', 'scatter', 'none'])
+    ap.add_argument('--locality', default='mesh',
+                    choices=['raster', 'mesh', 'scatter', 'none'],
+                    help="numbering of the synthetic source mesh: 'mesh' = "
+                         "as MPAS numbers its cells (default), 'raster' = "
+                         "along the destination raster (round 2), 'scatter' "
+                         "= at random")
     ap.add_argument('--shard', default='rows', choices=['rows', 'fields'])
     ap.add_argument('--sets', type=int, default=3,
                     help='distinct X/Y buffer sets rotated over the steps')
@@ -189,7 +201,7 @@ def time_steps(launch, steps, warmup, dist):
 
 
 def make_fields(n_a, K, layout, sets, seed, device, nan_frac=0.0,
-                dtype='f64'):
+                dtype='f64', times=8):
     import torch
     g = torch.Generator(device=device)
     g.manual_seed(seed)
@@ -200,7 +212,7 @@ def make_fields(n_a, K, layout, sets, seed, device, nan_frac=0.0,
         elif layout == 'tn':
             shape, cell_axis = (K, n_a), 1
         else:
-            shape, cell_axis = (8, n_a, K // 8), 1
+            shape, cell_axis = (times, n_a, K // times), 1
         x = torch.randn(shape, generator=g, device=device,
                         dtype=torch.float64)
         if dtype == 'f32':
@@ -218,7 +230,7 @@ class Workload:
 
 
 def prepare(name, args, rank, world, dist, K=None, mode=None, layout=None,
-            sets=None, dtype='f64'):
+            sets=None, dtype='f64', locality=None, times=8):
     """Build plan + fields + output buffers for one workload."""
     import torch
 
@@ -236,7 +248,8 @@ def prepare(name, args, rank, world, dist, K=None, mode=None, layout=None,
     tune = [int(t) for t in args.tune.split(',')] if args.tune else None
 
     t0 = time.perf_counter()
-    m = synthetic.make_config(name, device=device, locality=args.locality)
+    w.locality = locality or args.locality
+    m = synthetic.make_config(name, device=device, locality=w.locality)
     full = engine.RemapPlan.from_triplets(
         m.row, m.col, m.S, m.frac_b, m.n_a, m.n_b, index_base=1,
         device=device)
@@ -262,8 +275,9 @@ def prepare(name, args, rank, world, dist, K=None, mode=None, layout=None,
     w.dtype = dtype
     w.fields = make_fields(m.n_a, w.K_local, w.layout, w.sets, 1234, device,
                            nan_frac=0.25 if w.mode == 'masked' else 0.0,
-                           dtype=dtype)
+                           dtype=dtype, times=times)
     w.exchange = None
+    w.full_field = None
     if w.sharded:
         w.exchange = time_exchange(w, dist)
 
@@ -290,12 +304,17 @@ def prepare(name, args, rank, world, dist, K=None, mode=None, layout=None,
 def time_exchange(w, dist):
     """
     The ONE exchange step of the sharded path in its collective form -- one
-    RCCL broadcast of the whole field -- timed on its own; leaves every rank
-    holding rank 0's fields.  (The point-to-point form: time_bands.)
+    RCCL broadcast of the whole field, then each rank gathers the packed
+    source rows its shard references -- timed on its own; leaves every rank
+    holding ITS packed rows of rank 0's fields.  (The form that sends each
+    rank only its packed rows: time_packed.)
     """
     import torch
+
+    from pyremap_amd import engine
     out = {}
     x = w.fields[0]
+    axis = 0 if w.layout == 'nk' else 1
     times = []
     for _ in range(3):
         barrier(dist)
@@ -304,39 +323,48 @@ def time_exchange(w, dist):
         torch.cuda.synchronize()
         times.append((time.perf_counter() - t0) * 1e3)
     out['broadcast_ms'] = min(times)
-    for x in w.fields:            # every set resident everywhere
+    for x in w.fields:            # every set's packed rows resident
         dist.broadcast(x, src=0)
     torch.cuda.synchronize()
-    from pyremap_amd.parallel import band_fraction
-    out['band_fraction_of_broadcast'] = band_fraction(w.remap.src_ranges,
-                                                      w.plan.n_a)
     out['field_bytes'] = x.numel() * x.element_size()
+    out['packed_fraction_of_broadcast'] = w.remap.packed_fraction()
+    out['packed_rows_this_rank'] = int(w.remap.ucols.shape[0])
+    a = torch.cuda.Event(enable_timing=True)
+    b = torch.cuda.Event(enable_timing=True)
+    a.record()
+    packed = [engine.gather_rows(x, axis, w.remap.ucols) for x in w.fields]
+    b.record()
+    torch.cuda.synchronize()
+    out['local_gather_ms'] = a.elapsed_time(b) / len(w.fields)
+    w.full_field = w.fields[0]     # (rank 0's is the data; time_packed)
+    w.fields = packed
     return out
 
 
-def time_bands(w, dist):
+def time_packed(w, dist):
     """
-    The point-to-point form of the exchange (each rank receives only the band
-    of source rows its shard references), timed AFTER the metric: it is the
-    one part of this file that has never run on more than one GPU, and a
-    watchdog (see main) reports the metric without it should it not return.
+    The exchange that moves only what is needed: rank 0 gathers each rank's
+    packed source rows and ONE all_to_all_single delivers them.  Timed AFTER
+    the metric, under the watchdog (see main): it has run under gloo and with
+    ranks sharing one GPU, not yet across xGMI.
     """
     import torch
-    if w.layout != 'nk' or dist.get_backend() != 'nccl':
-        return {}      # (gloo moves GPU tensors point to point via the host)
-    x = w.fields[0]
+    if w.full_field is None or dist.get_backend() != 'nccl':
+        return {}      # (gloo moves GPU tensors through the host)
+    x = w.full_field
+    axis = 0 if w.layout == 'nk' else 1
     times = []
     try:
         for _ in range(3):
             barrier(dist)
             t0 = time.perf_counter()
-            w.remap.distribute(x, src=0, how='bands')
+            w.remap.distribute(x, src=0, axis=axis, how='alltoall')
             torch.cuda.synchronize()
             times.append((time.perf_counter() - t0) * 1e3)
-        return {'bands_ms': min(times)}
+        return {'packed_ms': min(times)}
     except RuntimeError as exc:
-        return {'bands_ms': None,
-                'bands_error': str(exc).splitlines()[0][:200]}
+        return {'packed_ms': None,
+                'packed_error': str(exc).splitlines()[0][:200]}
 
 
 def time_pipelined(w, args, dist, reps=5, n_batches=4):
@@ -346,17 +374,17 @@ def time_pipelined(w, args, dist, reps=5, n_batches=4):
     b is computed.  Milliseconds per K fields, max over ranks.
     """
     import torch
-    if w.remap is None or w.layout != 'nk':
+    if w.remap is None or w.layout != 'nk' or w.full_field is None:
         return None
     kb = w.K_local // n_batches
-    src = w.fields[0]
+    src = w.full_field
     batches = [src[:, b * kb:(b + 1) * kb].contiguous()
                for b in range(n_batches)]
     outs = [torch.empty((w.plan.n_b, kb), dtype=torch.float64,
                         device=src.device) for _ in range(n_batches)]
     out = {}
-    for how in ('bands', 'broadcast'):
-        if how == 'bands' and dist.get_backend() != 'nccl':
+    for how in ('alltoall', 'broadcast'):
+        if how == 'alltoall' and dist.get_backend() != 'nccl':
             continue
         try:
             w.remap.apply_pipelined(batches, w.emode, how=how,
@@ -397,7 +425,8 @@ def measure(w, args, dist, steps=None, warmup=None):
     return dict(
         name=w.name, title=w.title, n_a=m.n_a, n_b=m.n_b,
         n_s_file=m.n_s, nnz_csr=w.full.nnz, K=w.K, mode=w.mode,
-        layout=w.layout, steps=steps, warmup=warmup, wall_s=wall,
+        layout=w.layout, locality=w.locality, steps=steps, warmup=warmup,
+        wall_s=wall,
         ms_per_step=wall * 1e3 / steps,
         kernel_ms_mean=mean_ms,
         kernel_ms_median=per_launch[len(per_launch) // 2],
@@ -509,13 +538,16 @@ def pcie_inclusive(args):
     The same workload when the boundary hands over HOST buffers (numpy in,
     numpy out through Remapper.remap_array): upload of X, launch, download
     of Y and of the byte mask.  Reported for DESIGN.md; never `value`.
+    Two layouts: the (n_a, K) matrix of the metric and the layout MPAS output
+    has, (Time, nCells, nVertLevels), which pipelines batch by batch.
     """
     import numpy as np
     import torch
 
     from pyremap_amd import Remapper, synthetic
     cfg = synthetic.CONFIGS['config3']
-    m = synthetic.make_config('config3', device='cuda')
+    m = synthetic.make_config('config3', device='cuda',
+                              locality=args.locality)
 
     class Desc:
         pass
@@ -526,27 +558,43 @@ def pcie_inclusive(args):
     mm = m.numpy()
     r = Remapper.from_triplets(mm['row'], mm['col'], mm['S'], mm['frac_b'],
                                src, dst, device='cuda')
-    x = np.random.default_rng(0).standard_normal((m.n_a, cfg['K']))
-    r.remap_array(x[:, :8], [0])                     # loads the weights
-    times = []
-    y = None
-    for _ in range(4):
-        del y
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        y = r.remap_array(x, [0])
-        times.append(time.perf_counter() - t0)
-    t = min(times)
-    return dict(seconds=t, seconds_first_call=times[0],
-                cell_fields_per_s=m.n_b * cfg['K'] / t,
-                bytes_over_pcie=x.nbytes + y.data.nbytes + y.mask.nbytes,
-                note='numpy in -> numpy masked array out through '
-                     'Remapper.remap_array, best of 4')
+    rng = np.random.default_rng(0)
+    out = {}
+    for tag, shape, axes in (('n_a_K', (m.n_a, cfg['K']), [0]),
+                             ('Time8_nCells_L64', (8, m.n_a, cfg['K'] // 8),
+                              [1])):
+        x = rng.standard_normal(shape)
+        r.remap_array(x[..., :8], axes)              # loads the weights
+        times = []
+        y = None
+        for _ in range(4):
+            del y
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            y = r.remap_array(x, axes)
+            times.append(time.perf_counter() - t0)
+        t = min(times)
+        out[tag] = dict(
+            seconds=t, seconds_first_call=times[0],
+            cell_fields_per_s=m.n_b * cfg['K'] / t,
+            bytes_over_pcie=x.nbytes + y.data.nbytes + y.mask.nbytes)
+        del x, y
+    out['numbering'] = args.locality
+    out['note'] = ('numpy in -> numpy masked array out through '
+                   'Remapper.remap_array, best of 4')
+    return out
 
 
-def load_traffic(name, K, mode):
-    """PMC-measured HBM bytes per launch, from a committed rocprofv3 run."""
-    path = os.path.join(_REPO, 'profiles', f'traffic_{name}.json')
+def load_traffic(name, K, mode, locality='mesh'):
+    """PMC-measured HBM bytes per launch, from a committed rocprofv3 run
+    (`traffic_<workload>_mesh.json` for the mesh numbering, the round-2
+    files `traffic_<workload>.json` for the raster numbering)."""
+    suffix = {'raster': '', 'mesh': '_mesh'}.get(locality)
+    if suffix is None:
+        return None, None
+    if mode != 'fracb':
+        suffix += '_' + mode
+    path = os.path.join(_REPO, 'profiles', f'traffic_{name}{suffix}.json')
     if not os.path.exists(path):
         return None, None
     with open(path) as f:
@@ -557,32 +605,56 @@ def load_traffic(name, K, mode):
 
 
 EXTRA_KEYS = ('title', 'n_a', 'n_b', 'nnz_csr', 'K', 'mode', 'layout',
-              'schedule', 'touched_frac', 'ms_per_step', 'kernel_ms_mean',
-              'kernel_ms_median', 'cell_fields_per_s', 'bytes_alg',
-              'achieved_GBps')
+              'locality', 'schedule', 'touched_frac', 'ms_per_step',
+              'kernel_ms_mean', 'kernel_ms_median', 'cell_fields_per_s',
+              'bytes_alg', 'achieved_GBps')
+
+#: workloads that hold tens of GB: prepared, measured and freed one at a
+#: time, before the small ones are prepared
+BIG = ('headline', 'config4', 'config5')
 
 
 def extras_todo(args, world):
-    """The other reported workloads: (tag, prepare() keywords, steps)."""
+    """
+    The other reported workloads: (tag, prepare() keywords, steps).  Their
+    summary rows land in `roofline.workloads` (the driver's record keeps
+    `roofline`; it truncates `extra`).
+    """
     if args.no_extra or args.workload != 'config3':
         return []
     if world == 1:
         return [
-            ('headline_3.7M_to_1.0M', dict(name='headline', sets=2), 30),
+            # north_star's target workload; BASELINE configs 5 and 4
+            ('headline', dict(name='headline', sets=2), 12),
+            ('config5', dict(name='config5', sets=1), 4),
+            ('config5_masked', dict(name='config5', sets=1, mode='masked'),
+             4),
+            ('config4', dict(name='config4', sets=1), 6),
+            ('config4_f32_fields', dict(name='config4', sets=1, dtype='f32'),
+             6),
+            # the metric mapping in the raster numbering round 2 measured
+            ('config3_raster_numbering',
+             dict(name='config3', locality='raster'), 50),
             ('K1_one_2d_field', dict(name='config3', K=1), 50),
             ('K12_monthly_time_nCells', dict(name='config3', K=12,
                                              layout='tn'), 50),
+            ('Time120_nCells', dict(name='config3', K=120, layout='tn'), 30),
             ('f32_fields', dict(name='config3', dtype='f32'), 50),
             ('layout_T8_nCells_L64', dict(name='config3', layout='tnl'), 50),
-            ('masked_renormalised', dict(name='config3', mode='masked'), 50),
+            ('layout_T8_nCells_L60', dict(name='config3', layout='tnl',
+                                          K=480), 50),
+            ('masked', dict(name='config3', mode='masked'), 50),
         ]
-    return [('masked_renormalised', dict(name='config3', mode='masked'), 50)]
+    return [('masked', dict(name='config3', mode='masked'), 50)]
 
 
-def prepare_extras(args, rank, world, dist, extra):
-    """Build every extra workload (host work: the GPU idles meanwhile)."""
+def prepare_extras(args, rank, world, dist, extra, big):
+    """Build the extra workloads of one class (host work: the GPU idles)."""
     ready = []
     for tag, kw, steps in extras_todo(args, world):
+        if (kw['name'] in BIG) != big:
+            continue
+        kw = dict(kw)
         try:
             ready.append((tag, prepare(kw.pop('name'), args, rank, world,
                                        dist, **kw), steps))
@@ -591,7 +663,24 @@ def prepare_extras(args, rank, world, dist, extra):
     return ready
 
 
-def measure_extras(ready, args, dist, extra):
+def measure_big_extras(args, rank, world, dist, extra):
+    """The tens-of-GB workloads: prepare, measure, free -- one at a time."""
+    import torch
+    for tag, kw, steps in extras_todo(args, world):
+        if kw['name'] not in BIG:
+            continue
+        kw = dict(kw)
+        try:
+            w = prepare(kw.pop('name'), args, rank, world, dist, **kw)
+            measure_extras([(tag, w, steps)], args, dist, extra,
+                           long_last=False)
+            del w
+        except Exception as exc:  # noqa: BLE001
+            extra[tag] = {'error': f'{type(exc).__name__}: {exc}'}
+        torch.cuda.empty_cache()
+
+
+def measure_extras(ready, args, dist, extra, long_last=True):
     """
     Time the prepared extras back to back (no host work in between).  The
     last one -- the metric mapping in masked mode, same kernel family -- runs
@@ -602,7 +691,7 @@ def measure_extras(ready, args, dist, extra):
     import torch
     for n, (tag, w, steps) in enumerate(ready):
         try:
-            if n + 1 == len(ready):
+            if long_last and n + 1 == len(ready):
                 a = torch.cuda.Event(enable_timing=True)
                 b = torch.cuda.Event(enable_timing=True)
                 a.record()
@@ -617,16 +706,46 @@ def measure_extras(ready, args, dist, extra):
                                      dtype=torch.int64)
                     dist.all_reduce(t, op=dist.ReduceOp.MAX)
                     steps = int(t.item())
-            r = measure(w, args, dist, steps=steps, warmup=5)
+            r = measure(w, args, dist, steps=steps,
+                        warmup=2 if w.name in BIG else 5)
             extra[tag] = {k: r[k] for k in EXTRA_KEYS}
             extra[tag]['steps'] = steps
+            extra[tag]['dtype'] = w.dtype
             extra[tag]['frac_of_peak'] = r['achieved_GBps'] / HBM_PEAK_GBPS
+            extra[tag]['read_frac_of_peak'] = r['bytes_alg_read'] / (
+                r['kernel_ms_mean'] * 1e-3) / 1e9 / HBM_PEAK_GBPS
             # (the committed counter traffic is that of the (n_a, K) layout)
-            traffic, _ = load_traffic(w.name, w.K, w.mode) \
+            traffic, _ = load_traffic(w.name, w.K, w.mode, w.locality) \
                 if w.layout == 'nk' and w.dtype == 'f64' else (None, None)
             extra[tag]['traffic'] = traffic
         except Exception as exc:  # noqa: BLE001
             extra[tag] = {'error': f'{type(exc).__name__}: {exc}'}
+
+
+def workload_rows(extra):
+    """`roofline.workloads`: one short row per extra workload."""
+    rows = {}
+    for tag, e in extra.items():
+        if not isinstance(e, dict) or 'kernel_ms_mean' not in e:
+            if isinstance(e, dict) and 'error' in e:
+                rows[tag] = {'error': e['error'][:120]}
+            continue
+        sched = e.get('schedule') or {}
+        rows[tag] = {
+            'ms': round(e['kernel_ms_mean'], 5),
+            'frac': round(e['frac_of_peak'], 4),
+            'read_frac': round(e['read_frac_of_peak'], 4),
+            'traffic_ratio': (round(e['traffic'] / e['bytes_alg'], 4)
+                              if e.get('traffic') else None),
+            'GBps': round(e['achieved_GBps'], 1),
+            'bytes_alg': e['bytes_alg'],
+            'K': e['K'], 'mode': e['mode'], 'layout': e['layout'],
+            'dtype': e.get('dtype', 'f64'), 'numbering': e['locality'],
+            'kernel': KERNEL_OF_FAMILY.get(sched.get('family'),
+                                           'spmm_rowlane' if e['K'] <= 32
+                                           else 'spmm_*'),
+        }
+    return rows
 
 
 def print_line(line):
@@ -647,10 +766,12 @@ def print_line(line):
 OPTIONAL_TIMEOUT_S = int(os.environ.get('BENCH_OPTIONAL_TIMEOUT_S', 150))
 
 
-def compose_line(args, res, world, ceiling, cpu, extra, pipelined):
+def compose_line(args, res, world, ceiling, cpu, extra, pipelined,
+                 status='ok'):
     """The one JSON line, from what has been measured."""
     K = res['K']
-    traffic, traffic_src = load_traffic(args.workload, K, res['mode'])
+    traffic, traffic_src = load_traffic(args.workload, K, res['mode'],
+                                        args.locality)
     kernel_ms = res.get('kernel_ms_mean_max_rank', res['kernel_ms_mean'])
     achieved = res['bytes_alg'] / (kernel_ms * 1e-3) / 1e9
     multi = None
@@ -682,8 +803,9 @@ def compose_line(args, res, world, ceiling, cpu, extra, pipelined):
             'locality': args.locality,
             'touched_frac': res['touched_frac'],
             'sharding': 'none' if world == 1 else
-            (f'dst rows over {world} GPUs, X distributed once (RCCL) before '
-             f'the timed region' if args.shard == 'rows' else
+            (f'dst rows over {world} GPUs in packed column space, X '
+             f'distributed once (RCCL) before the timed region'
+             if args.shard == 'rows' else
              f'fields over {world} GPUs, no collective'),
             'buffer_sets_rotated': args.sets,
             'bitwise_mode': not (args.flags & 1),
@@ -716,7 +838,10 @@ def compose_line(args, res, world, ceiling, cpu, extra, pipelined):
             'read_frac_of_peak': res['bytes_alg_read'] /
             (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
             'measured_copy_ceiling_GBps': ceiling,
+            'numbering': args.locality,
+            'workloads': workload_rows(extra),
         },
+        'status': status,
         'cpu_baseline': cpu,
         'plan_build_s': res['plan_build_s'],
         'multi_gpu': multi,
@@ -734,10 +859,13 @@ def main():
     engine.require_gpu()
 
     extra = {}
-    # everything is PREPARED first (host work, GPU mostly idle), then all
-    # measurements run back to back; the metric workload last
+    # The metric workload and the small extras are PREPARED first (host
+    # work, GPU mostly idle); the tens-of-GB workloads come and go one at a
+    # time in between; then all remaining measurements run back to back, the
+    # metric workload last.
     main_w = prepare(args.workload, args, rank, world, dist)
-    ready = prepare_extras(args, rank, world, dist, extra)
+    ready = prepare_extras(args, rank, world, dist, extra, big=False)
+    measure_big_extras(args, rank, world, dist, extra)
     ceiling = copy_ceiling(device)
     pipelined = None
     res = None
@@ -763,30 +891,32 @@ def main():
         res['kernel_ms_mean_max_rank'] = float(t.item())
     watchdog = None
     if main_w.sharded:
-        # The metric is in hand.  What follows uses RCCL point to point,
-        # which no test could exercise on more than one GPU: should it not
-        # return, every rank leaves after OPTIONAL_TIMEOUT_S and rank 0
-        # prints the line without these numbers.
+        # The metric is in hand.  What follows moves packed rows with
+        # all_to_all_single over RCCL, which no test could exercise on more
+        # than one GPU: should it not return, rank 0 prints the line with
+        # "status": "exchange_hung" and every rank exits with code 3 -- a
+        # hung exchange must not look like a clean run.
         import threading
 
         def bail():
             if rank == 0:
                 late = dict(res['exchange'] or {})
                 late['optional_measurements'] = (
-                    f'timed out after {OPTIONAL_TIMEOUT_S} s: point-to-point '
-                    f'bands / pipelined exchange not measured')
+                    f'timed out after {OPTIONAL_TIMEOUT_S} s: packed / '
+                    f'pipelined exchange did not return')
                 res['exchange'] = late
                 print_line(compose_line(args, res, world, ceiling, None,
-                                        extra, None))
-            os._exit(0)
+                                        extra, None,
+                                        status='exchange_hung'))
+            os._exit(3)
         watchdog = threading.Timer(OPTIONAL_TIMEOUT_S, bail)
         watchdog.daemon = True
         watchdog.start()
         if os.environ.get('BENCH_TEST_HANG'):      # exercises the watchdog
             time.sleep(10 ** 6)
-        bands = time_bands(main_w, dist)
+        packed = time_packed(main_w, dist)
         if res['exchange'] is not None:
-            res['exchange'].update(bands)
+            res['exchange'].update(packed)
         pipelined = time_pipelined(main_w, args, dist)
         barrier(dist)
         watchdog.cancel()

@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define REMAP_ABI_VERSION 18
+#define REMAP_ABI_VERSION 19
 
 enum {
     REMAP_OK = 0,
@@ -422,8 +422,11 @@ int remap_schedule_auto(const remap_csr *A, const double *frac_b,
  * remap_plan_apply = `_remap_numpy_array` (:223-297): one fused launch over
  *   all rows, asynchronous on `stream`; field layout and modes as in
  *   remap_apply_args (same names, same meaning).
- * remap_plan_destroy frees the device memory (the caller makes sure no
- *   launch still uses it).
+ *   The calling thread's current HIP device must be the one the plan was
+ *   created on (REMAP_ERR_ARG otherwise: the launch would run against
+ *   another device's pointers).
+ * remap_plan_destroy frees the device memory on the plan's device, whatever
+ *   device is current (the caller makes sure no launch still uses it).
  */
 typedef struct remap_plan remap_plan;
 
@@ -468,11 +471,43 @@ int remap_plan_apply(const remap_plan *plan, const remap_field *field,
 
 /*
  * OR 1 into *flag (device int32, zeroed by the caller) if any of the n
- * elements of x (device, REMAP_DTYPE_*, 16-byte aligned) is a NaN.
+ * elements of x (device, REMAP_DTYPE_*, element-aligned) is a NaN.
  * Asynchronous on `stream`; the device half of remap_numpy.py:201-204.
  */
 int remap_scan_nan(const void *x, int32_t x_dtype, int64_t n, int32_t *flag,
                    void *stream);
+
+/*
+ * The two device steps of a ROW SHARD's exchange (no counterpart in the
+ * reference, which is single-process; the math is remap_numpy.py:264-268:
+ * destination row i reads only the source rows its entries name, so a shard
+ * of rows needs X[unique(col[shard])] and nothing else -- whatever the
+ * numbering of the source mesh).
+ *
+ * remap_pack_columns: one-off per shard.  ucols_out (device, capacity
+ *   min(nnz, n_cols)) receives the DISTINCT column indices of `col`
+ *   ascending, *n_ucols_out (device int64) their number, and col_out (device,
+ *   nnz; may alias col) the same entries renumbered to positions in that
+ *   list.  The renumbering is monotone: a row's entries keep their order, so
+ *   the packed shard reproduces the unsharded result bit for bit.
+ *   *bad_out (device int64) counts entries outside [0, n_cols).
+ * remap_gather_rows: per batch of fields, on the device that holds them:
+ *   dst[b][i][0:row_bytes] = src[b * batch_stride + rows[i] * row_stride ...]
+ *   for b < n_batch, i < n_rows; dst is contiguous (n_batch, n_rows,
+ *   row_bytes).  With rows = a shard's ucols this is the packed source
+ *   buffer that travels to the shard's GPU; strides in BYTES.
+ * Both asynchronous on `stream`; nothing is allocated.
+ */
+int remap_pack_columns_workspace(int64_t n_cols, size_t *bytes_out);
+int remap_pack_columns(const int32_t *col, int64_t nnz, int64_t n_cols,
+                       int32_t *col_out, int32_t *ucols_out,
+                       int64_t *n_ucols_out, int64_t *bad_out,
+                       void *workspace, size_t workspace_bytes, void *stream);
+int remap_gather_rows(const void *src, int64_t n_batch,
+                      int64_t src_batch_stride_bytes,
+                      int64_t src_row_stride_bytes, const int32_t *rows,
+                      int64_t n_rows, int64_t row_bytes, void *dst,
+                      void *stream);
 
 /*
  * Device-to-device streaming copy of `bytes` (16 B per lane, grid-stride):

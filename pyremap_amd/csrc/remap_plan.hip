@@ -290,12 +290,20 @@ void remap_plan_destroy(remap_plan *plan)
 {
     if (!plan)
         return;
+    // the memory belongs to the device the plan was created on, whatever
+    // device the calling thread has current
+    int current = -1;
+    const bool switched = hipGetDevice(&current) == hipSuccess &&
+                          current != plan->device &&
+                          hipSetDevice(plan->device) == hipSuccess;
     for (void *p : {static_cast<void *>(plan->rowptr),
                     static_cast<void *>(plan->col),
                     static_cast<void *>(plan->val),
                     static_cast<void *>(plan->frac_b), plan->arena})
         if (p)
             (void)hipFree(p);
+    if (switched)
+        (void)hipSetDevice(current);
     delete plan;
 }
 
@@ -322,6 +330,21 @@ int remap_plan_apply(const remap_plan *plan, const remap_field *f,
     if (f->mode < 0 || f->mode > 2)
         return remap::fail(REMAP_ERR_ARG, "remap_plan_apply: mode %d",
                            f->mode);
+    // A launch goes to the calling thread's current device; the plan's
+    // arrays (and the stream, X and Y the caller passes) belong to the device
+    // the plan was created on.  Refuse instead of launching against another
+    // device's pointers.
+    int current = -1;
+    if (hipGetDevice(&current) != hipSuccess) {
+        (void)hipGetLastError();
+        return remap::fail(REMAP_ERR_HIP, "remap_plan_apply: hipGetDevice");
+    }
+    if (current != plan->device)
+        return remap::fail(
+            REMAP_ERR_ARG,
+            "remap_plan_apply: the plan lives on device %d but the calling "
+            "thread's current device is %d; hipSetDevice(%d) first",
+            plan->device, current, plan->device);
     remap_apply_args a = remap_apply_args();
     a.A.n_rows = plan->n_b;
     a.A.n_cols = plan->n_a;

@@ -808,13 +808,22 @@ __global__ __launch_bounds__(kBlock) void stream_copy_kernel(
 namespace {
 template <typename T>
 __global__ __launch_bounds__(kBlock) void scan_nan_kernel(
-    const T *__restrict__ x, size_t n, int32_t *__restrict__ flag)
+    const T *__restrict__ x0, size_t n0, size_t head,
+    int32_t *__restrict__ flag)
 {
-    // 16 bytes per lane per step, blocks in dispatch order
+    // 16 bytes per lane per step, blocks in dispatch order; the `head`
+    // elements in front of the first 16-byte boundary (a view that starts
+    // inside an allocation: big[1:]) and the tail are peeled by block 0
     constexpr int PER = 16 / sizeof(T);
     typedef T vec_t __attribute__((ext_vector_type(PER)));
+    const T *__restrict__ x = x0 + head;
+    const size_t n = n0 - head;
     const size_t nvec = n / PER;
     bool found = false;
+    if (blockIdx.x == 0 && threadIdx.x < head) {
+        const T t = x0[threadIdx.x];
+        found |= (t != t);
+    }
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nvec;
          i += (size_t)gridDim.x * kBlock) {
         const vec_t v = __builtin_nontemporal_load(
@@ -842,10 +851,14 @@ int scan_nan(const void *x, int32_t dtype, int64_t n, int32_t *flag,
     if (n == 0)
         return REMAP_OK;
     const size_t elem = dtype == REMAP_DTYPE_F64 ? 8 : 4;
-    if (!aligned(x, 16))
+    if (!aligned(x, elem))
         return fail(REMAP_ERR_ARG,
-                    "remap_scan_nan: needs a 16-byte aligned buffer");
-    const size_t nvec = (size_t)n * elem / 16;
+                    "remap_scan_nan: the buffer is not element-aligned");
+    const size_t mis = reinterpret_cast<uintptr_t>(x) % 16;
+    size_t head = mis ? (16 - mis) / elem : 0;
+    if (head > (size_t)n)
+        head = (size_t)n;
+    const size_t nvec = ((size_t)n - head) * elem / 16;
     size_t grid = (nvec + kBlock - 1) / kBlock;
     if (grid < 1)
         grid = 1;
@@ -854,11 +867,13 @@ int scan_nan(const void *x, int32_t dtype, int64_t n, int32_t *flag,
     if (dtype == REMAP_DTYPE_F64)
         hipLaunchKernelGGL(scan_nan_kernel<double>, dim3((uint32_t)grid),
                            dim3(kBlock), 0, stream,
-                           static_cast<const double *>(x), (size_t)n, flag);
+                           static_cast<const double *>(x), (size_t)n, head,
+                           flag);
     else
         hipLaunchKernelGGL(scan_nan_kernel<float>, dim3((uint32_t)grid),
                            dim3(kBlock), 0, stream,
-                           static_cast<const float *>(x), (size_t)n, flag);
+                           static_cast<const float *>(x), (size_t)n, head,
+                           flag);
     REMAP_HIP_CHECK(hipGetLastError());
     return REMAP_OK;
 }

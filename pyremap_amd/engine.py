@@ -33,7 +33,7 @@ FLAG_TREE = 8
 DTYPE_F64 = 0
 DTYPE_F32 = 1
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 #: readable pad entries kept behind col/val (remap_csr.csr_pad)
 CSR_PAD = 8
@@ -47,7 +47,8 @@ EXPORTS = (
     'remap_patches_workspace', 'remap_patches_build',
     'remap_schedule_sizes', 'remap_schedule_auto',
     'remap_plan_create', 'remap_plan_destroy', 'remap_plan_query',
-    'remap_plan_apply',
+    'remap_plan_apply', 'remap_pack_columns_workspace', 'remap_pack_columns',
+    'remap_gather_rows',
 )
 
 
@@ -263,6 +264,19 @@ def load_library():
     lib.remap_plan_apply.restype = ctypes.c_int
     lib.remap_plan_apply.argtypes = [ctypes.c_void_p,
                                      ctypes.POINTER(_Field), ctypes.c_void_p]
+    lib.remap_pack_columns_workspace.restype = ctypes.c_int
+    lib.remap_pack_columns_workspace.argtypes = [
+        ctypes.c_int64, ctypes.POINTER(ctypes.c_size_t)]
+    lib.remap_pack_columns.restype = ctypes.c_int
+    lib.remap_pack_columns.argtypes = [
+        ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_size_t, ctypes.c_void_p]
+    lib.remap_gather_rows.restype = ctypes.c_int
+    lib.remap_gather_rows.argtypes = [
+        ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+        ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
+        ctypes.c_void_p]
     lib.remap_scan_nan.restype = ctypes.c_int
     lib.remap_scan_nan.argtypes = [ctypes.c_void_p, ctypes.c_int32,
                                    ctypes.c_int64, ctypes.c_void_p,
@@ -575,6 +589,58 @@ class RemapPlan:
             self.col[j0:j1].contiguous(), self.val[j0:j1].contiguous(),
             self.frac_b[r0:r1].contiguous(),
             row_offset=self.row_offset + r0, n_b_global=self.n_b_global)
+
+    def to(self, device):
+        """A copy of this plan (CSR + frac_b, no schedule) on ``device``."""
+        torch = _torch()
+        device = torch.device(device)
+        return RemapPlan(
+            self.n_a, self.n_b, self.rowptr.to(device),
+            self._col_padded.to(device), self._val_padded.to(device),
+            self.frac_b.to(device), row_offset=self.row_offset,
+            n_b_global=self.n_b_global)
+
+    def packed(self):
+        """
+        This plan over the COMPACT space of the source rows it references
+        (a row shard needs ``X[unique(col[shard])]``
+        and nothing else): returns ``(plan, ucols)`` where ``ucols`` is the
+        ascending int32 device tensor of the distinct source rows and
+        ``plan`` is the same matrix with ``n_a = len(ucols)`` and every
+        column index replaced by its position in ``ucols``
+        (``remap_pack_columns``).  The renumbering is monotone, so a row's
+        entries keep their order and the packed plan applied to
+        ``X[ucols]`` gives the same bits as this plan applied to ``X``.
+        Schedules are not carried over (they hold column indices): call
+        ``auto_schedule`` on the result.
+        """
+        torch = _torch()
+        lib = load_library()
+        dev = self.device
+        with torch.cuda.device(dev):
+            nbytes = ctypes.c_size_t(0)
+            _check(lib.remap_pack_columns_workspace(
+                self.n_a, ctypes.byref(nbytes)),
+                'remap_pack_columns_workspace')
+            ws = torch.empty(max(int(nbytes.value), 1), dtype=torch.uint8,
+                             device=dev)
+            col = torch.zeros(self.nnz + CSR_PAD, dtype=torch.int32,
+                              device=dev)
+            ucols = torch.empty(max(min(self.nnz, self.n_a), 1),
+                                dtype=torch.int32, device=dev)
+            counts = torch.zeros(2, dtype=torch.int64, device=dev)
+            _check(lib.remap_pack_columns(
+                _ptr(self.col), self.nnz, self.n_a, _ptr(col), _ptr(ucols),
+                ctypes.c_void_p(counts.data_ptr()),
+                ctypes.c_void_p(counts.data_ptr() + 8), _ptr(ws),
+                ws.numel(), _stream_ptr(dev)), 'remap_pack_columns')
+            n_u, bad = (int(v) for v in counts.cpu())
+        if bad:
+            raise EngineError(f'{bad} column indices outside [0, {self.n_a})')
+        plan = RemapPlan(n_u, self.n_b, self.rowptr, col, self._val_padded,
+                         self.frac_b, row_offset=self.row_offset,
+                         n_b_global=self.n_b_global)
+        return plan, ucols[:n_u].clone()
 
     # -- scheduling ---------------------------------------------------------
     def set_row_order(self, order):
@@ -1082,6 +1148,16 @@ def remap_tensor(plan, dst_grid_dims, field, remap_axes, mode, threshold=0.0,
     slab of rows ``[plan.row_offset, plan.row_offset + plan.n_b)``).
     """
     torch = _torch()
+    if hasattr(plan, 'shards'):
+        # a parallel.MultiDeviceRemap standing where the plan stands
+        # (Remapper(..., devices=[...])): rows sharded over several GPUs
+        if out is not None or gate is not None or mask_out is not None or \
+                tune is not None:
+            raise ValueError('out / gate / mask_out / tune address ONE '
+                             "device's launch; not with a multi-device plan")
+        return plan.remap_tensor(dst_grid_dims, field, remap_axes, mode,
+                                 threshold=threshold, want_mask=want_mask,
+                                 flags=flags)
     remap_axes = [int(a) % field.ndim for a in remap_axes]
     ndim = field.ndim
     extra_axes = [ax for ax in range(ndim) if ax not in remap_axes]
@@ -1201,6 +1277,12 @@ def remap_tensor_auto_mode(plan, dst_grid_dims, field, remap_axes, threshold,
     (the one whose gate is closed does nothing), nothing synchronises.
     """
     torch = _torch()
+    if hasattr(plan, 'shards'):
+        if out is not None or flag is not None:
+            raise ValueError("out / flag address ONE device's launch; not "
+                             'with a multi-device plan')
+        return plan.remap_tensor_auto_mode(dst_grid_dims, field, remap_axes,
+                                           threshold, flags=flags)
     if not in_place_addressable(field.shape, remap_axes):
         # permute copies either side of the launch: decide with one readback
         masked = bool(torch.isnan(field).any())
@@ -1217,6 +1299,40 @@ def remap_tensor_auto_mode(plan, dst_grid_dims, field, remap_axes, threshold,
                      gate_value=1)
     return remap_tensor(plan, dst_grid_dims, X, remap_axes, MODE_FRACB,
                         flags=flags, out=Y, gate=flag, gate_value=0)
+
+
+def gather_rows(field, axis, rows, out=None):
+    """
+    ``field.index_select(axis, rows)`` for a contiguous device tensor through
+    the library's ``remap_gather_rows``: the packed source buffer
+    ``X[ucols]`` a row shard's GPU receives.  ``rows``: int32 device tensor.
+    Asynchronous on torch's current stream.
+    """
+    torch = _torch()
+    lib = load_library()
+    if not field.is_contiguous():
+        field = field.contiguous()
+    axis = int(axis) % field.ndim
+    if rows.dtype != torch.int32 or rows.device != field.device:
+        rows = rows.to(device=field.device, dtype=torch.int32)
+    rows = rows.contiguous()
+    n_batch = _prod(field.shape[:axis])
+    inner = _prod(field.shape[axis + 1:])
+    item = field.element_size()
+    shape = list(field.shape[:axis]) + [int(rows.shape[0])] + \
+        list(field.shape[axis + 1:])
+    if out is None:
+        out = torch.empty(shape, dtype=field.dtype, device=field.device)
+    elif list(out.shape) != shape or out.dtype != field.dtype or \
+            out.device != field.device or not out.is_contiguous():
+        raise ValueError(f'out must be a contiguous {field.dtype} tensor of '
+                         f'shape {tuple(shape)} on {field.device}')
+    with torch.cuda.device(field.device):
+        _check(lib.remap_gather_rows(
+            _ptr(field), n_batch, int(field.shape[axis]) * inner * item,
+            inner * item, _ptr(rows), int(rows.shape[0]), inner * item,
+            _ptr(out), _stream_ptr(field.device)), 'remap_gather_rows')
+    return out
 
 
 def stream_copy(dst, src):

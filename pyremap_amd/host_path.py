@@ -55,6 +55,16 @@ _pinned_alive = [0]
 _pinned_lock = threading.Lock()
 
 
+_logged = set()
+
+
+def _log_once(key, message):
+    if key not in _logged:
+        _logged.add(key)
+        import logging
+        logging.getLogger('pyremap_amd').info(message)
+
+
 def _host_buffer(shape, dtype):
     """A result buffer: pinned while the budget lasts, pageable beyond."""
     torch = engine._torch()
@@ -246,10 +256,14 @@ def _enqueue(plan, dst_grid_dims, values, host, remap_axes, lead, n_batch,
     """The transfers and launches of :func:`remap_host_array`."""
     torch = engine._torch()
     device = plan.device
+    # a multi-device plan (parallel.MultiDeviceRemap) shards ROWS over its
+    # GPUs per call: one upload to its source device, one sharded remap, one
+    # download (the pipelines below drive a single device's launches)
+    multi = hasattr(plan, 'shards')
     single = not in_place or host_mask is not None or mode == 'auto' or \
-        n_batch < 2
+        n_batch < 2 or multi
     banded = in_place and host_mask is None and mode != 'auto' and \
-        n_batch == 1 and lead == 0 and \
+        n_batch == 1 and lead == 0 and not multi and \
         values.nbytes >= 4 * CHUNK_BYTES and plan.n_b == plan.n_b_global
     # (the batch pipeline below streams through chunk-sized buffers instead)
     x_d = torch.empty(values.shape, dtype=host.dtype, device=device) \
@@ -460,6 +474,19 @@ def _banded_pipeline(plan, values, host, x_d, out_h, mask_h, mode, thr,
     dns = [(r, min(r + rows_dn, n_b)) for r in range(0, n_b, rows_dn)]
     # last source row each destination block needs (one small readback)
     need = plan.block_source_extent(rows_dn)
+    if len(need) < 2 or need[len(need) // 2] > 0.9 * n_a:
+        # The band only exists when the source mesh is numbered along the
+        # destination rows.  No MPAS mesh is (one destination latitude row
+        # of the real QU240 mesh meets ids from 77-99 % of the id range), so
+        # on a real mapping half the destination blocks need (nearly) every
+        # source row: upload whole, launch once, download -- the plain form.
+        # Fields with leading batch dims -- (Time, nCells, nVertLevels), the
+        # layout MPAS output has -- overlap both directions batch by batch
+        # whatever the numbering (the ring pipeline in _enqueue).
+        _log_once('banded', 'host array (n_a, K): the source numbering does '
+                  'not follow the destination rows; upload, launch and '
+                  'download run one after the other')
+        return None
     emode = engine.MODE_MASKED if mode == 'masked' else engine.MODE_FRACB
     start = torch.cuda.Event()
     start.record(main)

@@ -145,12 +145,27 @@ def _load_mapping(remapper):
     info = _MapInfo(mapping)
     _validate_mapping(info, remapper.src_descriptor, remapper.dst_descriptor)
     # csr_matrix((S, (row - 1, col - 1)), shape=(n_b, n_a)), on the device
-    remapper._matrix = engine.RemapPlan.from_triplets(
+    plan = engine.RemapPlan.from_triplets(
         mapping.row, mapping.col, mapping.S, mapping.frac_b, info.n_a,
         info.n_b, index_base=1, device=remapper.device)
-    # pick the kernel schedule for this mapping (LDS-staged patches when
-    # neighbouring destination rows share their source rows)
-    remapper.schedule = remapper._matrix.auto_schedule(info.dst_grid_dims)
+    devices = getattr(remapper, 'devices', None)
+    group = getattr(remapper, '_process_group', None)
+    if group is not None:
+        # one process per GPU: this rank keeps its rows (packed columns)
+        from pyremap_amd.parallel import ShardedRemap
+        plan = ShardedRemap(plan, group=group[0],
+                            grid_dims=info.dst_grid_dims)
+        remapper.schedule = plan.schedule
+    elif devices and len(devices) > 1:
+        # one process, several GPUs: rows sharded over them
+        from pyremap_amd.parallel import MultiDeviceRemap
+        plan = MultiDeviceRemap(plan, devices, grid_dims=info.dst_grid_dims)
+        remapper.schedule = plan.schedule
+    else:
+        # pick the kernel schedule for this mapping (LDS-staged patches when
+        # neighbouring destination rows share their source rows)
+        remapper.schedule = plan.auto_schedule(info.dst_grid_dims)
+    remapper._matrix = plan
     remapper._ds_map = info
 
 
@@ -196,6 +211,14 @@ def _start_data_array(da, remapper, renormalization_threshold):
         if not any(dim in coord.dims for dim in src_dims):
             coords[name] = {'dims': coord.dims, 'data': coord.values}
     coords.update(remapper.dst_descriptor.coords)
+
+    if getattr(remapper, '_process_group', None) is not None:
+        data = _collective_array(remapper, da.values, remap_axes,
+                                 renormalization_threshold)
+        make = _array_class(da).from_dict
+        attrs, name = da.attrs, da.name
+        return lambda: make({'coords': coords, 'attrs': attrs, 'dims': dims,
+                             'data': data, 'name': name})
 
     # the NaN test of :201-204 and the product both run on the device; masked
     # entries come back as NaN, which is what xarray makes of the reference's
@@ -243,6 +266,31 @@ class _LookAhead:
         return self.started.pop(name)()
 
 
+def _collective_array(remapper, values, remap_axes, threshold):
+    """
+    One array through the process group (``Remapper.use_process_group``):
+    rank ``src`` uploads its array, every rank computes its rows from the
+    packed source rows it receives, every rank returns the full float64
+    result (NaN where the reference masks).
+    """
+    torch = engine.require_gpu()
+    sharded = remapper._matrix
+    src = remapper._process_group[1]
+    values = np.asarray(values)
+    if values.dtype not in (np.float64, np.float32):
+        values = values.astype(np.float64)
+    field = None
+    if sharded.rank == src:
+        field = torch.from_numpy(np.ascontiguousarray(values)).to(
+            sharded.plan.device)
+    y = sharded.remap_tensor(
+        remapper._ds_map.dst_grid_dims, field, remap_axes,
+        threshold=threshold, src=src, flags=remapper.engine_flags,
+        shape=tuple(values.shape),
+        dtype=torch.float32 if values.dtype == np.float32 else torch.float64)
+    return y.cpu().numpy()
+
+
 def _remap_numpy_array(remapper, in_field, remap_axes,
                        renormalization_threshold):
     """
@@ -264,6 +312,28 @@ def _remap_numpy_array(remapper, in_field, remap_axes,
     plan = remapper._matrix
     dst_grid_dims = remapper._ds_map.dst_grid_dims
     remap_axes = [int(a) for a in remap_axes]
+
+    if getattr(remapper, '_process_group', None) is not None:
+        # collective: rank src's data, every rank gets the full result
+        is_ma = isinstance(in_field, np.ma.MaskedArray)
+        if isinstance(in_field, torch.Tensor):
+            src = remapper._process_group[1]
+            return plan.remap_tensor(
+                dst_grid_dims,
+                in_field.to(plan.plan.device) if plan.rank == src else None,
+                remap_axes, threshold=renormalization_threshold, src=src,
+                flags=remapper.engine_flags, shape=tuple(in_field.shape),
+                dtype=in_field.dtype if in_field.dtype in (
+                    torch.float32, torch.float64) else torch.float64)
+        data = np.ma.getdata(in_field) if is_ma else np.asarray(in_field)
+        thr = renormalization_threshold if is_ma else None
+        if is_ma and thr is not None:
+            # the mask travels as NaNs (what _remap_data_array builds,
+            # :201-204); an explicit mask that hides finite values is burnt
+            # in the same way
+            data = np.where(np.ma.getmaskarray(in_field), np.nan, data)
+        out = _collective_array(remapper, data, remap_axes, thr)
+        return np.ma.masked_array(out, mask=np.isnan(out))
 
     if isinstance(in_field, torch.Tensor):
         field = in_field.to(plan.device)

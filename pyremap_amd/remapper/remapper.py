@@ -30,6 +30,11 @@ class Remapper:
 
     device : torch.device or str or None
         the GPU that holds the weights (default: the current HIP device)
+    devices : list of devices or None
+        ONE process, several GPUs: destination rows sharded over them, each
+        shard's source rows carried over by peer copies, results assembled on
+        ``devices[0]`` -- same calls, same results (bit for bit) as with one
+        device.  One process per GPU (torchrun): :meth:`use_process_group`.
     engine_flags : int
         ``pyremap_amd.engine.FLAG_*`` bits; 0 = bit-identical to scipy
     """
@@ -45,6 +50,7 @@ class Remapper:
         parallel_exec='mpirun',
         use_tmp=True,
         device=None,
+        devices=None,
     ):
         self.ntasks = ntasks
         self.src_grid_info = dict()
@@ -64,6 +70,14 @@ class Remapper:
         self.moab_path = None
         self.parallel_exec = parallel_exec
         self.device = device
+        #: several GPUs driven from this one process: the destination rows
+        #: are sharded over them (pyremap_amd.parallel.MultiDeviceRemap);
+        #: fields are handed over and results returned on devices[0]
+        self.devices = list(devices) if devices else None
+        if self.devices and device is None:
+            self.device = self.devices[0]
+        #: set by use_process_group(): remap_numpy / ncremap as collectives
+        self._process_group = None
         self.engine_flags = 0
         #: what RemapPlan.auto_schedule chose for the loaded mapping
         self.schedule = None
@@ -169,6 +183,26 @@ class Remapper:
             n_a, n_b, list(src_descriptor.dim_sizes)[::-1],
             list(dst_descriptor.dim_sizes)[::-1], row, col, S, frac_b)
         return remapper
+
+    def use_process_group(self, group=None, src=0):
+        """
+        Make ``remap_numpy`` / ``remap_array`` / ``ncremap`` COLLECTIVE calls
+        over an initialised ``torch.distributed`` process group (one process
+        per GPU; backend ``nccl`` = RCCL over xGMI): every rank makes the
+        same call, the data of rank ``src`` is remapped (the other ranks'
+        arrays only supply shapes), each rank computes its share of the
+        destination rows from the source rows it references, and every rank
+        returns the full result; ``ncremap`` writes the file on ``src`` only.
+        Call before the first remap (the mapping is sharded when loaded).
+        """
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError('use_process_group() needs an initialised '
+                               'torch.distributed process group')
+        if self._ds_map is not None:
+            raise RuntimeError('use_process_group() must precede the first '
+                               'remap: the mapping is already loaded')
+        self._process_group = (group, int(src))
 
     def load_mapping(self):
         """Read and upload the weights now instead of at the first remap."""

@@ -2,11 +2,17 @@
 The N > 1 path on CPU: several processes, gloo backend.  What is exercised is
 the distributed plumbing of pyremap_amd.parallel -- work-balanced row
 sharding (uneven shards included), the exchange of the source field (one
-broadcast, or only the band of source rows each shard references, point to
-point), pipelined batches, the row gather, and the zero-collective
-field-sharded mode -- with the CPU oracle standing in for the HIP kernel as
-the per-rank compute (the kernel itself is covered by the -m gpu tests;
-shards there are checked in test_gpu_parity.py::test_row_range_and_shards).
+broadcast, or each rank receiving only the PACKED source rows its shard
+references: one all_to_all_single), pipelined batches, the row gather, and
+the zero-collective field-sharded mode -- with the CPU oracle standing in for
+the HIP kernel as the per-rank compute (the kernel itself is covered by the
+-m gpu tests; shards there are checked in test_gpu_parity.py and
+test_gpu_multi.py).
+
+The mapping's source cells are numbered the way an MPAS mesh numbers them
+(`synthetic.mesh_numbering`), NOT along the destination raster: the packed
+exchange must move about (1/N + halo) of the field all the same, where a
+(min, max) band of source rows -- what round 2 sent -- is the whole field.
 """
 import os
 import socket
@@ -31,7 +37,8 @@ def _free_port():
 def _problem():
     from oracle import oracle
     from pyremap_amd import synthetic
-    m = synthetic.conservative_map(900, (20, 30), 1, 6, seed=5)
+    m = synthetic.conservative_map(900, (20, 30), 1, 6, seed=5,
+                                   locality='mesh')
     mm = m.numpy()
     # a solid band of land (rows 0-199 empty): shards of equal WORK then
     # hold unequal numbers of rows
@@ -89,36 +96,53 @@ def _worker(rank, world, port, tmpdir, how):
                 x = torch.from_numpy(full_x.copy())
             if how == 'broadcast':
                 parallel.broadcast_field(x, src=0)
+                x_use, shard_use = x, shard
             else:
-                lo, hi = parallel.source_row_range(
-                    torch.from_numpy(shard.indices))
-                ranges = parallel.exchange_row_ranges(lo, hi)
-                assert ranges[rank] == (lo, hi) and len(ranges) == world
-                if how == 'bands':
-                    parallel.distribute_rows(x, ranges, src=0)
-                else:   # 'bands_async': two batches, second one in flight
-                    x2 = torch.full((m.n_a, K), float('nan'),
-                                    dtype=torch.float64)
-                    if rank == 0:
-                        x2 = torch.from_numpy(2.0 * full_x)
-                    reqs1 = parallel.distribute_rows(x, ranges, src=0,
-                                                     async_op=True)
-                    reqs2 = parallel.distribute_rows(x2, ranges, src=0,
-                                                     async_op=True)
-                    for req in reqs1 + reqs2:
-                        req.wait()
+                # packed columns: the shard in the compact space of the
+                # source rows it references (monotone renumbering: the order
+                # of a row's entries -- the order of the sums -- is kept)
+                ucols = [parallel.unique_columns(torch.from_numpy(
+                    _shard(csr, bounds[r], bounds[r + 1], m.n_a).indices))
+                    for r in range(world)]
+                mine = ucols[rank]
+                packed_idx = np.searchsorted(mine.numpy(), shard.indices)
+                shard_use = oracle.OracleCSR(
+                    shard.indptr, packed_idx.astype(np.int32), shard.data,
+                    (r1 - r0, len(mine)))
+                counts = [len(u) for u in ucols]
+                notes['packed_frac'] = parallel.packed_fraction(counts,
+                                                                m.n_a)
+                notes['band_frac'] = sum(
+                    int(u.max()) + 1 - int(u.min()) for u in ucols
+                    if len(u)) / (world * m.n_a)
+
+                def pieces_of(t):
+                    return [t[u].contiguous() for u in ucols] \
+                        if rank == 0 else None
+                if how == 'packed':
+                    recv, _ = parallel.scatter_packed(
+                        pieces_of(x), len(mine) * K, torch.float64,
+                        torch.device('cpu'), src=0)
+                else:   # 'packed_async': two batches, second one in flight
+                    x2 = torch.from_numpy(2.0 * full_x) if rank == 0 \
+                        else None
+                    recv, w1 = parallel.scatter_packed(
+                        pieces_of(x), len(mine) * K, torch.float64,
+                        torch.device('cpu'), src=0, async_op=True)
+                    recv2, w2 = parallel.scatter_packed(
+                        pieces_of(x2), len(mine) * K, torch.float64,
+                        torch.device('cpu'), src=0, async_op=True)
+                    w1.wait()
+                    w2.wait()
                     y2, mask2 = oracle.remap_flat(
-                        shard, mm['frac_b'][r0:r1], x2.numpy(), False, 0.0)
+                        shard_use, mm['frac_b'][r0:r1],
+                        recv2.reshape(len(mine), K).numpy(), False, 0.0)
                     y2[mask2] = np.nan
                     notes['second'] = int(np.array_equal(
                         y2, 2.0 * ref[r0:r1], equal_nan=True))
-                notes['band_frac'] = parallel.band_fraction(ranges, m.n_a)
-                if rank != 0 and hi - lo < m.n_a:
-                    # rows outside the band were not sent
-                    outside = np.ones(m.n_a, bool)
-                    outside[lo:hi] = False
-                    notes['outside_nan'] = int(
-                        np.isnan(x.numpy()[outside]).all())
+                x_use = recv.reshape(len(mine), K)
+                notes['received_rows'] = len(mine)
+            x, shard = x_use, shard_use
             y_local, mask = oracle.remap_flat(shard, mm['frac_b'][r0:r1],
                                               x.numpy(), False, 0.0)
             y_local[mask] = np.nan
@@ -154,22 +178,25 @@ def test_row_sharded_remap_world_size_2(tmp_path):
     assert out[1]['r1'] == 600
 
 
-def test_row_sharded_world_size_4_uneven_shards_bands(tmp_path):
+def test_row_sharded_world_size_4_uneven_shards_packed(tmp_path):
     """Four ranks, shards of equal work but unequal row counts, and each rank
-    receiving only the band of source rows it references."""
-    out = _run(tmp_path, 4, 'bands')
+    receiving only the packed source rows it references -- on a source mesh
+    whose numbering has nothing to do with the destination raster."""
+    out = _run(tmp_path, 4, 'packed')
     assert all(o['balanced'] == 1 for o in out)
     assert any(o['uneven'] == 1 for o in out)
     spans = [(o['r0'], o['r1']) for o in out]
     assert spans[0][0] == 0 and spans[-1][1] == 600
     assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
-    # the bands move clearly less than four whole fields would
-    assert out[0]['band_frac'] < 0.75
-    assert all(o.get('outside_nan', 1) == 1 for o in out)
+    # the packed rows are about (1/N + halo) of the field per rank ...
+    assert out[0]['packed_frac'] < 0.55
+    assert sum(o['received_rows'] for o in out) < 0.55 * 4 * 900
+    # ... where a (min, max) band of source rows is (nearly) all of it
+    assert out[0]['band_frac'] > 0.9
 
 
 def test_row_sharded_pipelined_batches(tmp_path):
-    out = _run(tmp_path, 3, 'bands_async')
+    out = _run(tmp_path, 3, 'packed_async')
     assert all(o['second'] == 1 for o in out)
 
 

@@ -932,8 +932,13 @@ def test_sharded_remap_slabs_make_the_whole(dev):
     x = torch.randn((4, m.n_a, 96), device=dev, dtype=torch.float64)
     x[:, torch.rand(m.n_a, device=dev) < 0.1, 40:] = float('nan')
     whole = ShardedRemap(plan, grid_dims=m.dst_dims)        # no group: 1 rank
-    assert whole.world_size == 1 and whole.plan is plan
-    want = whole.apply(x, [1], engine.MODE_MASKED, threshold=0.01)
+    assert whole.world_size == 1 and whole.plan.n_b == plan.n_b
+    want = engine.remap_tensor(plan, m.dst_dims, x, [1], engine.MODE_MASKED,
+                               threshold=0.01)
+    alone = whole.apply(whole.distribute(x, axis=1), [1], engine.MODE_MASKED,
+                        threshold=0.01)
+    assert_bitwise(alone.cpu().numpy(),
+                   want.reshape(4, m.n_b, 96).cpu().numpy(), 'one rank')
     slabs, covered = [], 0
     for rank in range(3):
         part = ShardedRemap(plan, grid_dims=m.dst_dims, rank=rank,
@@ -942,7 +947,10 @@ def test_sharded_remap_slabs_make_the_whole(dev):
         assert part.plan.n_b == part.bounds[rank + 1] - part.bounds[rank]
         assert part.schedule is not None
         covered += part.plan.n_b
-        slabs.append(part.apply(x, [1], engine.MODE_MASKED, threshold=0.01))
+        # the shard lives in the compact space of the source rows it reads
+        assert part.plan.n_a == part.ucols.shape[0] < m.n_a
+        slabs.append(part.apply(engine.gather_rows(x, 1, part.ucols), [1],
+                                engine.MODE_MASKED, threshold=0.01))
     assert covered == m.n_b
     got = torch.cat(slabs, dim=1)
     assert_bitwise(got.cpu().numpy(),
@@ -1779,91 +1787,6 @@ def test_patch_plan_builder_matches_restatement(dev, case):
     if q is not None:
         ref = reference_patch_plan(plan, dims, q['tile'])
         assert torch.equal(q['lidx'], ref[3]) and q['umax'] == ref[7]
-
-
-def _sharded_worker(rank, world, port, tmpdir):
-    import sys
-
-    import torch.distributed as dist
-    sys.path.insert(0, os.path.dirname(os.path.dirname(
-        os.path.abspath(__file__))))
-    os.environ['MASTER_ADDR'] = '127.0.0.1'
-    os.environ['MASTER_PORT'] = str(port)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
-    try:
-        from oracle import oracle
-        from pyremap_amd import engine, synthetic
-        from pyremap_amd.parallel import ShardedRemap, band_fraction
-        torch.cuda.set_device(0)
-        dev = torch.device('cuda', 0)
-        m = synthetic.conservative_map(4000, (40, 60), 1, 7, seed=44)
-        mm = m.numpy()
-        full = engine.RemapPlan.from_triplets(
-            mm['row'], mm['col'], mm['S'], mm['frac_b'], m.n_a, m.n_b,
-            device=dev)
-        sharded = ShardedRemap(full, grid_dims=m.dst_dims)
-        csr = oracle.coo_to_csr(mm['row'] - 1, mm['col'] - 1, mm['S'],
-                                m.n_b, m.n_a)
-        K = 96
-        rng = np.random.default_rng(3)
-        host = [rng.standard_normal((m.n_a, K)) for _ in range(3)]
-        notes = {'band_frac': band_fraction(sharded.src_ranges, m.n_a)}
-        # one field: only rank 0 holds it; the others' buffers are poisoned
-        for how in ('bands', 'broadcast', 'auto'):
-            x = torch.from_numpy(host[0]).to(dev) if rank == 0 else \
-                torch.full((m.n_a, K), float('nan'), dtype=torch.float64,
-                           device=dev)
-            sharded.distribute(x, src=0, how=how)
-            y_rows = sharded.apply(x, [0], engine.MODE_FRACB)
-            y = sharded.gather(y_rows)
-            ref, ref_mask = oracle.remap_flat(csr, mm['frac_b'], host[0],
-                                              False, 0.0)
-            ref[ref_mask] = np.nan
-            notes[how] = int(np.array_equal(y.cpu().numpy(), ref,
-                                            equal_nan=True))
-        # three batches pipelined: batch b + 1 travels while b is computed
-        batches = [torch.from_numpy(h).to(dev) if rank == 0 else
-                   torch.full((m.n_a, K), float('nan'), dtype=torch.float64,
-                              device=dev) for h in host]
-        outs = sharded.apply_pipelined(batches, engine.MODE_FRACB,
-                                       how='bands')
-        ok = 1
-        r0, r1 = sharded.bounds[rank], sharded.bounds[rank + 1]
-        for h, o in zip(host, outs):
-            ref, ref_mask = oracle.remap_flat(csr, mm['frac_b'], h, False,
-                                              0.0)
-            ref[ref_mask] = np.nan
-            ok &= int(np.array_equal(o.cpu().numpy(), ref[r0:r1],
-                                     equal_nan=True))
-        notes['pipelined'] = ok
-        notes['schedule'] = sharded.schedule['family']
-        with open(os.path.join(tmpdir, f'rank{rank}.txt'), 'w') as f:
-            f.write(repr(notes))
-    finally:
-        dist.destroy_process_group()
-
-
-@pytest.mark.parametrize('world', [2, 3])
-def test_sharded_remap_ranks_sharing_one_gpu(world, tmp_path):
-    """
-    `ShardedRemap` end to end on the HIP kernels with `world` processes (gloo
-    rendezvous, all on this box's one GPU): per-rank schedules built by the
-    library, the field distributed as bands / one broadcast / 'auto', the
-    slabs gathered, and three batches pipelined -- every value the oracle's.
-    """
-    import socket
-
-    import torch.multiprocessing as mp
-    with socket.socket() as s:
-        s.bind(('127.0.0.1', 0))
-        port = s.getsockname()[1]
-    mp.spawn(_sharded_worker, args=(world, port, str(tmp_path)),
-             nprocs=world, join=True)
-    for rank in range(world):
-        notes = eval(open(tmp_path / f'rank{rank}.txt').read())
-        for key in ('bands', 'broadcast', 'auto', 'pipelined'):
-            assert notes[key] == 1, (rank, key, notes)
-        assert notes['band_frac'] < 1.0
 
 
 def test_bench_multi_rank_line_survives_a_hung_exchange(tmp_path):
