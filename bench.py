@@ -43,6 +43,7 @@ kernel 4-15 % slower for its first 25-30 launches (~12 ms), longer than a
 5 + 20 launch run lasts; see DESIGN.md section 5.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -674,9 +675,11 @@ def measure_big_extras(args, rank, world, dist, extra):
             w = prepare(kw.pop('name'), args, rank, world, dist, **kw)
             measure_extras([(tag, w, steps)], args, dist, extra,
                            long_last=False)
+            w.launch = w.fields = w.outs = None   # (launch closes over w)
             del w
         except Exception as exc:  # noqa: BLE001
             extra[tag] = {'error': f'{type(exc).__name__}: {exc}'}
+        gc.collect()
         torch.cuda.empty_cache()
 
 
@@ -741,9 +744,8 @@ def workload_rows(extra):
             'bytes_alg': e['bytes_alg'],
             'K': e['K'], 'mode': e['mode'], 'layout': e['layout'],
             'dtype': e.get('dtype', 'f64'), 'numbering': e['locality'],
-            'kernel': KERNEL_OF_FAMILY.get(sched.get('family'),
-                                           'spmm_rowlane' if e['K'] <= 32
-                                           else 'spmm_*'),
+            'kernel': 'spmm_rowlane' if e['K'] <= 32 else
+            KERNEL_OF_FAMILY.get(sched.get('family'), 'spmm_*'),
         }
     return rows
 

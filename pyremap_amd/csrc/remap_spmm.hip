@@ -54,6 +54,8 @@ namespace {
 #include "spmm_rowscalar.h"
 #include "spmm_rowgroup.h"
 #include "spmm_rowlane.h"
+#include "spmm_rowcell.h"
+#include "spmm_patchcell.h"
 #include "spmm_rowsub.h"
 
 // ---------------------------------------------------------------------------
@@ -120,6 +122,37 @@ kernel_fn pick_rowlane(int unr, int mode, bool fma)
                       : pick_rowlane_mode<XT, 8>(mode, fma);
 }
 
+template <typename XT, int TT, int UNR>
+kernel_fn pick_rowcell_mode(int mode, bool fma)
+{
+    switch (mode) {
+    case REMAP_MODE_RAW:
+        return fma ? spmm_rowcell<XT, REMAP_MODE_RAW, true, TT, UNR>
+                   : spmm_rowcell<XT, REMAP_MODE_RAW, false, TT, UNR>;
+    case REMAP_MODE_FRACB:
+        return fma ? spmm_rowcell<XT, REMAP_MODE_FRACB, true, TT, UNR>
+                   : spmm_rowcell<XT, REMAP_MODE_FRACB, false, TT, UNR>;
+    default:
+        return fma ? spmm_rowcell<XT, REMAP_MODE_MASKED, true, TT, UNR>
+                   : spmm_rowcell<XT, REMAP_MODE_MASKED, false, TT, UNR>;
+    }
+}
+
+// tune[1] = fields per lane (4, 8, 16), tune[2] = entries fetched together
+template <typename XT>
+kernel_fn pick_rowcell(int tt, int unr, int mode, bool fma)
+{
+    if (tt == 4)
+        return unr == 4 ? pick_rowcell_mode<XT, 4, 4>(mode, fma)
+                        : pick_rowcell_mode<XT, 4, 2>(mode, fma);
+    if (tt == 16)
+        return unr == 1 ? pick_rowcell_mode<XT, 16, 1>(mode, fma)
+                        : pick_rowcell_mode<XT, 16, 2>(mode, fma);
+    return unr == 1   ? pick_rowcell_mode<XT, 8, 1>(mode, fma)
+           : unr == 4 ? pick_rowcell_mode<XT, 8, 4>(mode, fma)
+                      : pick_rowcell_mode<XT, 8, 2>(mode, fma);
+}
+
 template <typename XT, int SUB, bool TREE>
 kernel_fn pick_rowsub_mode(int mode, bool fma)
 {
@@ -172,6 +205,35 @@ patch_fn pick_patch(int mode, bool fma, int row_bytes)
 {
     return row_bytes == 512 ? pick_patch_wc<64>(mode, fma)
                             : pick_patch_wc<128>(mode, fma);
+}
+
+typedef void (*cell_fn)(const KParams, const uint32_t, const int32_t *,
+                        const double *, const int32_t *, const int32_t *,
+                        const int32_t *, const int32_t *, const double *,
+                        const int32_t, const int32_t, const int64_t);
+
+template <typename XT, int TT>
+cell_fn pick_patchcell_mode(int mode, bool fma)
+{
+    switch (mode) {
+    case REMAP_MODE_RAW:
+        return fma ? spmm_patchcell<XT, REMAP_MODE_RAW, true, TT>
+                   : spmm_patchcell<XT, REMAP_MODE_RAW, false, TT>;
+    case REMAP_MODE_FRACB:
+        return fma ? spmm_patchcell<XT, REMAP_MODE_FRACB, true, TT>
+                   : spmm_patchcell<XT, REMAP_MODE_FRACB, false, TT>;
+    default:
+        return fma ? spmm_patchcell<XT, REMAP_MODE_MASKED, true, TT>
+                   : spmm_patchcell<XT, REMAP_MODE_MASKED, false, TT>;
+    }
+}
+
+template <typename XT>
+cell_fn pick_patchcell(int tt, int mode, bool fma)
+{
+    return tt == 4    ? pick_patchcell_mode<XT, 4>(mode, fma)
+           : tt == 16 ? pick_patchcell_mode<XT, 16>(mode, fma)
+                      : pick_patchcell_mode<XT, 8>(mode, fma);
 }
 
 // LDS a workgroup may ask for and still leave room for a second one per CU
@@ -357,6 +419,7 @@ struct Call {
     bool can_vec2;        // two elements per lane: even strides, aligned bases
     bool small_offsets;   // byte offsets inside a row fit 32 bits
     bool patch_ok;        // a usable patch plan is attached
+    bool cell_ok;         // a patch plan family 7 can use is attached
     bool group_ok;        // a usable row-group schedule is attached
 };
 
@@ -418,6 +481,12 @@ int check_args(const remap_apply_args *a, Call &c)
         ((a->n_batch - 1) * a->x_batch_stride + a->k_inner) *
             (int64_t)xelem < (int64_t(1) << 31);
     c.patch_ok = patch_usable(a, c.K, c.f32, c.can_vec2);
+    c.cell_ok = a->patch_ptr && a->patch_ucol && a->patch_lidx &&
+                a->patch_rowptr && a->patch_val && a->patch_rows > 0 &&
+                a->n_patches > 0 && a->patch_umax >= 0 &&
+                (int64_t)a->patch_umax * 4 * 8 <= (int64_t)kPatchLdsMax &&
+                c.n_rows <= a->n_patches * (int64_t)a->patch_rows &&
+                c.n_rows > (a->n_patches - 1) * (int64_t)a->patch_rows;
     c.group_ok = a->group_meta && a->group_col && a->group_w &&
                  a->group_mask && a->group_rid && a->group_frac &&
                  (a->group_rows == 8 || a->group_rows == 4) &&
@@ -460,16 +529,30 @@ KParams base_params(const remap_apply_args *a, const Call &c)
     return p;
 }
 
+// Fields whose contiguous run behind the source axes is shorter than one
+// 64-byte half line and that come in several batches -- (Time, nCells),
+// (Time, nCells, 3) -- are served by the lanes-across-rows kernel.
+bool short_runs(const remap_apply_args *a)
+{
+    return a->k_inner < 8 && a->n_batch > 1;
+}
+
 // REMAP_FLAG_TUNE_HINT: can the preferred family serve this call?
 bool hint_usable(const remap_apply_args *a, const Call &c)
 {
+    if (a->tune[0] == 7)
+        return c.cell_ok;   // LDS-staged lanes across rows: any K
     if (c.K <= 32)
         return false;  // the lane-per-(row, k) kernel owns small K
+    if (short_runs(a) && a->tune[0] != 4)
+        return false;  // (Time, nCells): lanes across rows
     switch (a->tune[0]) {
     case 10:
         return c.group_ok && c.small_offsets;
     case 5:
         return c.patch_ok;
+    case 7:
+        return c.cell_ok;
     case 6:
         return a->A.csr_pad >= 8 && c.small_offsets &&
                (a->tune[1] != 2 || c.can_vec2);
@@ -492,6 +575,8 @@ int automatic_family(const remap_apply_args *a, const Call &c)
     // bilinear map at K = 1: 10.1 vs 10.1 us -- so it stays opt-in
     if (c.K <= 32)
         return 2;
+    if (short_runs(a))
+        return 4;
     if (c.patch_ok && c.K >= 64)
         return 5;
     return a->A.csr_pad >= 8 ? 6 : 1;
@@ -665,6 +750,69 @@ int run_rowlane(const remap_apply_args *a, const Call &c, const KParams &p,
                         a, p, grid, stream);
 }
 
+// family 4: lanes across rows, TT fields per lane
+int run_rowcell(const remap_apply_args *a, const Call &c, KParams p,
+                hipStream_t stream)
+{
+    int tt = a->tune[1];
+    if (tt != 4 && tt != 8 && tt != 16)
+        tt = 8;
+    int unr = a->tune[2];
+    if (unr != 1 && unr != 2 && unr != 4)
+        unr = 2;
+    p.row_order = nullptr;   // lanes = consecutive rows: coalesced Y stores
+    int64_t grid;
+    const int rc = shape_grid(p, ceil_div(c.n_rows, kBlock),
+                              ceil_div(c.K, tt), a->tune[4] != 1, grid);
+    if (rc != REMAP_OK)
+        return rc;
+    return launch_plain(c.f32 ? pick_rowcell<float>(tt, unr, a->mode, c.fma)
+                              : pick_rowcell<double>(tt, unr, a->mode, c.fma),
+                        a, p, grid, stream);
+}
+
+// family 7: LDS-staged patches, lanes across rows, TT fields per lane.
+// tune[1] = TT (4, 8, 16; 0: the largest whose LDS image stays under 32 KB,
+// so that several workgroups share a CU and overlap staging with compute)
+int run_patchcell(const remap_apply_args *a, const Call &c, KParams p,
+                  hipStream_t stream)
+{
+    if (!c.cell_ok)
+        return fail(REMAP_ERR_ARG,
+                    "remap_apply_f64: the patchcell kernel needs a patch "
+                    "plan covering [row_begin, row_end)");
+    const int32_t upitch = (a->patch_umax + 2) & ~1;
+    int tt = a->tune[1];
+    if (tt != 4 && tt != 8 && tt != 16) {
+        tt = 16;
+        while (tt > 4 && (int64_t)upitch * tt * 8 > 32 * 1024)
+            tt >>= 1;
+    }
+    while (tt > 4 && (int64_t)upitch * tt * 8 > (int64_t)kPatchLdsMax)
+        tt >>= 1;
+    int64_t grid;
+    const int rc = shape_grid(p, a->n_patches, ceil_div(c.K, tt),
+                              a->tune[4] != 1, grid);
+    if (rc != REMAP_OK)
+        return rc;
+    uint32_t lds_bytes = static_cast<uint32_t>(upitch) * tt * 8u;
+    if (lds_bytes < 1024)
+        lds_bytes = 1024;
+    cell_fn fn = c.f32 ? pick_patchcell<float>(tt, a->mode, c.fma)
+                       : pick_patchcell<double>(tt, a->mode, c.fma);
+    if (lds_bytes > 64 * 1024)
+        REMAP_HIP_CHECK(hipFuncSetAttribute(
+            reinterpret_cast<const void *>(fn),
+            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    hipLaunchKernelGGL(fn, dim3(static_cast<uint32_t>(grid)),
+                       dim3(kCellBlock), lds_bytes, stream, p, a->flags,
+                       a->patch_rowptr, a->patch_val, a->patch_lidx,
+                       a->patch_ptr, a->patch_ucol, a->row_order, a->frac_b,
+                       a->patch_rows, upitch, a->n_patches);
+    REMAP_HIP_CHECK(hipGetLastError());
+    return REMAP_OK;
+}
+
 // family 3: a sub-group of 8 (4 for rows of at most 4 entries: bilinear
 // maps) lanes per row; tune[1] overrides the sub-group size
 int run_rowsub(const remap_apply_args *a, const Call &c, const KParams &p,
@@ -774,6 +922,10 @@ int apply(const remap_apply_args *a, hipStream_t stream)
         return run_rowlane(a, c, p, stream);
     case 3:
         return run_rowsub(a, c, p, stream);
+    case 4:
+        return run_rowcell(a, c, p, stream);
+    case 7:
+        return run_patchcell(a, c, p, stream);
     case 1:
     case 6:
         return run_rowwave(a, c, p, family, stream);

@@ -1,0 +1,136 @@
+// spmm_patchcell.h -- family 7: LDS-staged patches, lanes ACROSS destination rows.
+// Part of remap_spmm.hip: included there inside namespace remap::(anonymous),
+// in the order given there; not a stand-alone header.
+// ---------------------------------------------------------------------------
+// patchcell: the (Time, nCells) layouts of family 4 (spmm_rowcell) through
+// the LDS patch plan of family 5.  In such a field the K values of one source
+// cell lie n_a elements apart, so every X access is an 8-byte gather from a
+// 128-byte line.  Family 4 takes one such trip through the CU's L1 per
+// (entry, field) -- 3-5 x the distinct cells, and on a real mesh numbering
+// the 64 lanes of an instruction hit ~64 different lines: the L2 -> L1 fill
+// rate (one line for 8 useful bytes) is the bound, 0.21 of the roofline on
+// EC30to60 numbered as MPAS numbers its cells, 0.33 numbered along the raster,
+// 0.06 numbered at random.
+//
+// Here one workgroup owns one PATCH of destination rows (a tile of the
+// destination grid) x TT fields:
+//   1. stage    every DISTINCT source cell of the patch, for each of the TT
+//               fields, is loaded ONCE: lanes run across the patch's SORTED
+//               list of source cells, so cells with neighbouring ids -- the
+//               runs of 3-9 a mesh generator leaves -- share a line fetch
+//               inside one instruction.  LDS layout [field][cell].
+//   2. barrier
+//   3. compute  lane = destination row (slot) of the patch; its (local
+//               index, S) pairs are lane-private, X comes from LDS
+//               (ds_read_b64, 512 B per instruction instead of 64 line
+//               fills), sums in CSR order, multiply then add: same bits as
+//               every other family.  Consecutive slots of a tile row are
+//               consecutive destination rows: Y stores are coalesced.
+// f32 fields are converted while staging (LDS holds doubles).
+// ---------------------------------------------------------------------------
+constexpr int kCellBlock = 256;
+
+template <typename XT, int MODE, bool FMA, int TT>
+__global__ __launch_bounds__(kCellBlock) void spmm_patchcell(
+    const KParams p, const uint32_t flags,
+    const int32_t *__restrict__ prow, const double *__restrict__ pval,
+    const int32_t *__restrict__ plidx, const int32_t *__restrict__ pptr,
+    const int32_t *__restrict__ ucol, const int32_t *__restrict__ row_order,
+    const double *__restrict__ frac_b, const int32_t patch_rows,
+    const int32_t upitch, const int64_t n_patches)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    double *xs = reinterpret_cast<double *>(lds);   // [TT][upitch]
+    const int tid = threadIdx.x;
+    const int64_t L = logical_block(p);
+    if (L >= p.n_blocks)
+        return;
+    const int64_t chunk = L / n_patches;  // chunk-major work list
+    const int64_t patch = L - chunk * n_patches;
+
+    // wave-uniform element offsets of this chunk's TT flat columns
+    int64_t xo[TT], yo[TT];
+    bool act[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        const uint32_t kf = static_cast<uint32_t>(chunk) * TT + t;
+        act[t] = kf < p.K;
+        const uint32_t b = act[t] ? kf / p.k_inner : 0u;
+        const uint32_t k = act[t] ? kf - b * p.k_inner : 0u;
+        xo[t] = static_cast<int64_t>(b) * p.bsx + k;
+        yo[t] = static_cast<int64_t>(b) * p.bsy + k;
+    }
+    const XT *__restrict__ X = static_cast<const XT *>(p.X);
+
+    // 1. stage the patch's distinct source cells, TT fields each
+    const int u0 = pptr[patch];
+    const int U = pptr[patch + 1] - u0;
+    for (int j = tid; j < U; j += kCellBlock) {
+        const int64_t c = static_cast<int64_t>(ucol[u0 + j]) * p.ldx;
+        XT v[TT];
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+            v[t] = X[c + xo[t]];
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+            xs[t * upitch + j] = static_cast<double>(v[t]);
+    }
+    __syncthreads();
+
+    // 2. the patch's rows, one lane each
+    const int64_t slot0 = p.row_begin + patch * patch_rows;
+    const int64_t local0 = patch * patch_rows;  // index into prow
+    int nrows = patch_rows;
+    if (slot0 + nrows > p.row_end)
+        nrows = static_cast<int>(p.row_end - slot0);
+    (void)flags;
+    for (int r = tid; r < nrows; r += kCellBlock) {
+        const int64_t i = row_order ? (int64_t)row_order[slot0 + r]
+                                    : slot0 + r;
+        const int s = prow[local0 + r];
+        const int e = prow[local0 + r + 1];
+        double acc[TT], den[TT];
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            acc[t] = 0.0;
+            den[t] = 0.0;
+        }
+        for (int jj = s; jj < e; ++jj) {
+            const int32_t li = plidx[jj];
+            const double a = pval[jj];
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+                const double x = xs[t * upitch + li];
+                if constexpr (MODE == REMAP_MODE_MASKED) {
+                    const bool valid = (x == x);
+                    acc[t] = mul_add<FMA>(a, valid ? x : 0.0, acc[t]);
+                    den[t] = den_add(a, valid ? 1.0 : 0.0, den[t]);
+                } else {
+                    acc[t] = mul_add<FMA>(a, x, acc[t]);
+                }
+            }
+        }
+        double fb = 0.0;
+        if constexpr (MODE == REMAP_MODE_FRACB)
+            fb = frac_b[i];
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            if (!act[t])
+                continue;
+            bool ok = true;
+            double y = acc[t];
+            if constexpr (MODE == REMAP_MODE_FRACB) {
+                ok = fb > 0.0;
+                y = !ok ? __builtin_nan("")
+                    : (fb == 1.0) ? acc[t] : acc[t] / fb;
+            } else if constexpr (MODE == REMAP_MODE_MASKED) {
+                ok = den[t] > p.thr;
+                y = ok ? acc[t] / den[t] : __builtin_nan("");
+            }
+            const int64_t o = i * p.ldy + yo[t];
+            __builtin_nontemporal_store(y, p.Y + o);
+            if (p.mask_out)
+                p.mask_out[o] = ok ? 0 : 1;
+        }
+    }
+}

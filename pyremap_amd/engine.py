@@ -376,6 +376,11 @@ class RemapPlan:
         self._extent_cache = {}
         #: launch tuning used when a call passes none (set by auto_schedule)
         self.default_tune = None
+        #: destination grid the schedules were built for (auto_schedule)
+        self._grid_dims = None
+        #: lazily built patch plan for the lanes-across-rows kernel that
+        #: serves (Time, nCells)-like layouts (see cell_patches)
+        self._cell = None
         # schedule attributes are properties: every assignment invalidates
         # the prefilled argument block launches start from (_prefilled)
         self._sched_version = 0
@@ -402,15 +407,17 @@ class RemapPlan:
     row_order = _sched_property('row_order')
     del _sched_property
 
-    def _prefilled(self, whole):
+    def _prefilled(self, whole, cell=False):
         """
         A fresh ``remap_apply_args`` with everything that belongs to the plan
         filled in -- the CSR and, for a launch over the whole row range, the
-        row order and the schedule that goes with it -- copied from a block
+        row order and the schedule that goes with it (``cell``: the patch
+        plan of the lanes-across-rows kernel instead) -- copied from a block
         built once per schedule version (a Dataset of small variables is
         launch-overhead-bound: 2 launches per variable).
         """
-        hit = self._args_cache.get(whole)
+        key = (whole, cell)
+        hit = self._args_cache.get(key)
         if hit is not None and hit[0] == self._sched_version:
             return _ApplyArgs.from_buffer_copy(hit[1])
         args = _ApplyArgs()
@@ -423,7 +430,21 @@ class RemapPlan:
         args.A.max_row_nnz = self.max_row_nnz
         args.A.csr_pad = self.csr_pad
         order = self.row_order
-        if whole:
+        if whole and cell:
+            q = self._cell
+            args.row_order = q['order'].data_ptr() \
+                if q['order'] is not None else None
+            args.patch_ptr = q['ptr'].data_ptr()
+            args.patch_ucol = q['ucol'].data_ptr()
+            args.patch_rowptr = q['rowptr'].data_ptr()
+            args.patch_lidx = q['lidx'].data_ptr()
+            args.patch_val = q['val'].data_ptr()
+            args.patch_rows = q['rows']
+            args.patch_umax = q['umax']
+            args.patch_emax = q['emax']
+            args.patch_row_bytes = q['row_bytes']
+            args.n_patches = q['n']
+        elif whole:
             # (a stored order permutes the whole row range: partial ranges
             # run without it, and without the schedules built on it)
             args.row_order = order.data_ptr() if order is not None else None
@@ -454,7 +475,7 @@ class RemapPlan:
                 args.group_frac = groups['frac'].data_ptr()
                 args.n_groups = groups['n']
                 args.group_rows = groups['rows']
-        self._args_cache[whole] = (self._sched_version, bytes(args))
+        self._args_cache[key] = (self._sched_version, bytes(args))
         return args
 
     # -- construction -------------------------------------------------------
@@ -714,10 +735,26 @@ class RemapPlan:
         distinct / entries (small = much reuse), or ``None`` if no patch size
         fits.
         """
+        def fits(rows, umax, emax):
+            # entries staged next to the rows: 12 B each (+24 B per row)
+            return (umax + 1) * row_bytes + emax * 12 + rows * 24 + 32 <= \
+                lds_budget
+        q = self._make_patches(grid_dims, tile, fits, row_bytes)
+        if q is None:
+            self.patches = None
+            if self.nnz and self.n_b:
+                self.row_order = None
+            return None
+        self.row_order = q['order']
+        self.patches = q
+        return q['distinct'] / self.nnz
+
+    def _make_patches(self, grid_dims, tile, fits, row_bytes):
+        """``remap_patches_build`` with ``tile``, halved until ``fits(rows,
+        umax, emax)``; returns the plan's arrays as a dict, or ``None``."""
         torch = _torch()
         lib = load_library()
         if self.nnz == 0 or self.n_b == 0:
-            self.patches = None
             return None
         dev = self.device
         ty, tx = (int(t) for t in tile)
@@ -755,26 +792,46 @@ class RemapPlan:
                     _ptr(lidx), _ptr(pval), _ptr(stats), _ptr(ws),
                     ws.numel(), _stream_ptr(dev)), 'remap_patches_build')
                 distinct, umax, emax = (int(v) for v in stats.cpu())
-                # entries staged next to the rows: 12 B each (+24 B per row)
-                footprint = (umax + 1) * row_bytes + emax * 12 + \
-                    rows * 24 + 32
-                if footprint <= lds_budget:
+                if fits(rows, umax, emax):
                     break
                 if rows == 1:
-                    self.patches = None
-                    self.row_order = None
                     return None
                 if tx >= ty and tx > 1:
                     tx //= 2
                 else:
                     ty //= 2
-        self.row_order = order
-        self.patches = dict(
+        return dict(
             ptr=ptr, ucol=ucol[:max(distinct, 1)].clone(), rowptr=prow,
             lidx=lidx, val=pval, rows=rows, umax=umax, emax=emax,
             n=n_patches, order=order, tile=(ty, tx), distinct=distinct,
             row_bytes=int(row_bytes))
-        return distinct / self.nnz
+
+    #: distinct source cells a patch of the lanes-across-rows kernel may
+    #: stage: 8 fields x 8 bytes each stay under 32 KB of LDS, so several
+    #: workgroups share a CU and overlap staging with compute
+    CELL_UMAX = 512
+
+    def cell_patches(self):
+        """
+        The patch plan of kernel family 7 (``spmm_patchcell``), which serves
+        fields whose contiguous run behind the source axes is short --
+        (Time, nCells), the reference's most common input -- built on first
+        use: 16 x 16 tiles of the destination grid (256 consecutive rows of a
+        1-D destination), halved until no patch references more than
+        ``CELL_UMAX`` distinct source cells.  ``None`` when there is nothing
+        to build.
+        """
+        if self._cell is None:
+            dims = self._grid_dims
+            if dims is not None and len(dims) != 2:
+                dims = None
+            q = self._make_patches(
+                dims, (16, 16) if dims is not None else (1, 256),
+                lambda rows, umax, emax: umax <= self.CELL_UMAX or rows <= 16,
+                1024)
+            self._cell = q if q is not None else False
+            self._sched_version += 1
+        return self._cell or None
 
     GROUP = 8   # default rows per group (remap_apply_args.group_rows)
 
@@ -859,9 +916,13 @@ class RemapPlan:
         self.row_order = None
         self.default_tune = None
         self._arena = None
+        self._cell = None
+        self._grid_dims = None
         if grid_dims is None or self.nnz == 0 or self.n_b == 0:
             return {'family': 'rowscalar', 'reason': 'no destination grid'}
         dims = tuple(int(d) for d in grid_dims)
+        if len(dims) in (1, 2) and _prod(dims) == self.n_b_global:
+            self._grid_dims = dims
         if len(dims) not in (1, 2):
             return {'family': 'rowscalar',
                     'reason': f'{len(dims)}-D destination grid'}
@@ -1065,7 +1126,15 @@ def apply_strided(plan, X, Y, *, n_batch, k_inner, x_row_stride,
                                  mask_out.device != plan.device):
         raise TypeError('mask_out must be a uint8 tensor on the plan device')
     end = plan.n_b if row_end is None else row_end
-    args = plan._prefilled(row_begin == 0 and end == plan.n_b)
+    whole = row_begin == 0 and end == plan.n_b
+    # short contiguous runs in several batches -- (Time, nCells) -- go to the
+    # LDS-staged lanes-across-rows kernel on its own patch plan
+    cell = whole and not tune and k_inner < 8 and n_batch > 1 and \
+        n_batch * k_inner >= 2 and plan.cell_patches() is not None
+    args = plan._prefilled(whole, cell)
+    if cell:
+        tune = [7, 8 if n_batch * k_inner >= 64 else 4]
+        flags |= FLAG_TUNE_HINT
     args.row_begin = row_begin
     args.row_end = end
     args.X = X.data_ptr()
@@ -1119,18 +1188,17 @@ def _prod(seq):
 def in_place_addressable(shape, remap_axes):
     """
     Can a field of this shape be addressed in place (strides instead of
-    permute copies)?  The source axes must be adjacent; the wave-per-row
-    kernels want a run of >= 8 contiguous fields behind them, the few-fields
-    kernel (K <= 32) takes any strides.
+    permute copies)?  The source axes must be adjacent -- then every layout
+    has its kernel: a run of >= 8 contiguous fields behind the source axes
+    goes to the lanes-across-K kernels, shorter runs in several batches
+    ((Time, nCells), the reference's most common input) to the
+    lanes-across-rows kernel (``spmm_rowcell``), K <= 32 to the
+    lane-per-(row, k) kernel.
     """
     ndim = len(shape)
     axes = [int(a) % ndim for a in remap_axes]
     lead = min(axes)
-    if axes != list(range(lead, lead + len(axes))):
-        return False
-    n_batch = _prod(shape[:lead])
-    k_inner = _prod(shape[lead + len(axes):])
-    return k_inner >= 8 or n_batch == 1 or n_batch * k_inner <= 32
+    return axes == list(range(lead, lead + len(axes)))
 
 
 def remap_tensor(plan, dst_grid_dims, field, remap_axes, mode, threshold=0.0,

@@ -1789,13 +1789,14 @@ def test_patch_plan_builder_matches_restatement(dev, case):
         assert torch.equal(q['lidx'], ref[3]) and q['umax'] == ref[7]
 
 
-def test_bench_multi_rank_line_survives_a_hung_exchange(tmp_path):
+def test_bench_multi_rank_line_and_a_hung_exchange(tmp_path):
     """
     `bench.py --gpus 2` as the driver launches it (torch.distributed.run, one
     process per rank; here gloo, both ranks on this GPU): the JSON line
-    carries the sharded metric and the exchange timings -- and when the
-    optional point-to-point part never returns (BENCH_TEST_HANG), the
-    watchdog still gets the metric line out with exit code 0.
+    carries the sharded metric and the exchange timings.  When the optional
+    exchange measurements never return (BENCH_TEST_HANG) the watchdog still
+    gets the metric line out -- with "status": "exchange_hung" and a NON-ZERO
+    exit code: a hung exchange must not look like a clean run.
     """
     import json
     import subprocess
@@ -1812,13 +1813,19 @@ def test_bench_multi_rank_line_survives_a_hung_exchange(tmp_path):
         proc = subprocess.run(base + ['--master-port', port] + bench,
                               capture_output=True, text=True, env=env,
                               timeout=600, cwd=str(tmp_path))
-        assert proc.returncode == 0, proc.stderr[-2000:]
+        hung = bool(env_extra)
+        assert (proc.returncode != 0) == hung, proc.stderr[-2000:]
         line = json.loads(proc.stdout.strip().splitlines()[-1])
+        assert line['status'] == ('exchange_hung' if hung else 'ok')
         assert line['n_gpus'] == 2 and line['scaling'] == 'strong'
         assert line['value'] > 0 and 0 < line['roofline']['frac'] < 1
         multi = line['multi_gpu']
         assert multi['broadcast_ms'] > 0 and multi['kernel_phase_ms'] > 0
-        assert ('optional_measurements' in multi) == bool(env_extra)
+        # the source mesh is numbered as MPAS numbers its cells, and each
+        # rank still needs only about half of the source rows
+        assert line['config']['locality'] == 'mesh'
+        assert multi['packed_fraction_of_broadcast'] < 0.8
+        assert ('optional_measurements' in multi) == hung
 
 
 def test_plan_handle_device_inputs_and_strided_fields(dev):

@@ -1,0 +1,176 @@
+"""
+(Time, nCells) and the other layouts whose contiguous run behind the source
+axes is short -- the reference's most common input
+(tests/test_interpolate.py:57-59, flattened by a transpose copy at
+remap_numpy.py:254-256) -- addressed IN PLACE for any number of time slices
+(VERDICT round 2, item 7): the lanes-across-rows kernels `spmm_rowcell`
+(family 4) and `spmm_patchcell` (family 7, LDS-staged, on a patch plan the
+plan builds on first use), bitwise against the oracle.
+"""
+import numpy as np
+import pytest
+
+from helpers import assert_bitwise
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'these tests need an MI355X'
+    from pyremap_amd import engine
+    engine.load_library()
+    return torch.device('cuda', 0)
+
+
+def _problem(dev, grid, locality='mesh', n_a=6000, seed=9):
+    from oracle import oracle
+    from pyremap_amd import engine, synthetic
+    dims = grid if len(grid) == 2 else (1, grid[0])
+    m = synthetic.conservative_map(n_a, dims, 1, 7, seed=seed, device=dev,
+                                   locality=locality)
+    plan = engine.RemapPlan.from_triplets(m.row, m.col, m.S, m.frac_b,
+                                          m.n_a, m.n_b, device=dev)
+    choice = plan.auto_schedule(grid)
+    rowptr, col, val = plan.to_host_csr()
+    csr = oracle.OracleCSR(rowptr, col, val, (m.n_b, m.n_a))
+    return m, plan, csr, m.frac_b.cpu().numpy(), choice
+
+
+SHAPES = [((40, 6000), [1]), ((120, 6000), [1]), ((7, 6000, 3), [1]),
+          ((33, 6000, 1), [1]), ((5, 8, 6000), [2]), ((12, 6000), [1]),
+          ((2, 6000), [1]), ((3, 6000, 7), [1]), ((65, 6000), [1]),
+          ((2, 2, 6000, 2, 2), [2])]
+
+
+@pytest.mark.parametrize('grid', [(50, 80), (4000,)], ids=['2d', '1d'])
+@pytest.mark.parametrize('mode', ['fracb', 'masked', 'raw'])
+def test_short_run_layouts_bitwise(dev, grid, mode):
+    from oracle import oracle
+    from pyremap_amd import engine
+    m, plan, csr, frac_b, _ = _problem(dev, grid)
+    emode = {'fracb': engine.MODE_FRACB, 'masked': engine.MODE_MASKED,
+             'raw': engine.MODE_RAW}[mode]
+    rng = np.random.default_rng(5)
+    for shape, axes in SHAPES:
+        for dtype in (np.float64, np.float32):
+            x = rng.standard_normal(shape).astype(dtype)
+            if mode == 'masked':
+                dead = rng.random(m.n_a) < 0.2
+                x[(slice(None),) * axes[0] + (dead,)] = np.nan
+                x[rng.random(shape) < 0.05] = np.nan
+            X = np.moveaxis(x, axes[0], 0).reshape(m.n_a, -1)
+            # (raw = the bare product: frac_b = 1 divides by nothing)
+            ref, ref_mask = oracle.remap_flat(
+                csr, np.ones_like(frac_b) if mode == 'raw' else frac_b, X,
+                mode == 'masked', 0.05)
+            ref = ref.copy()
+            ref[ref_mask] = np.nan
+            lead = list(shape[:axes[0]])
+            tail = list(shape[axes[0] + 1:])
+            want = np.moveaxis(ref.reshape([m.n_b] + lead + tail), 0,
+                               axes[0])
+            want = want.reshape(lead + list(grid) + tail)
+            xd = torch.from_numpy(x).to(dev)
+            for tune in (None, [4], [4, 4, 4], [4, 16, 1], [7, 4], [7, 8],
+                         [7, 16], [2], [1]):
+                K = x.size // m.n_a
+                if tune == [2] and K > 32:
+                    continue
+                if tune and tune[0] == 7:
+                    assert plan.cell_patches() is not None
+                    args_tune = tune
+                    # explicit family 7: through the plan's cell patch plan
+                    y, mask = _apply_cell(plan, grid, xd, axes, emode,
+                                          args_tune)
+                else:
+                    y, mask = engine.remap_tensor(
+                        plan, grid, xd, axes, emode, threshold=0.05,
+                        want_mask=True, tune=tune)
+                assert tuple(y.shape) == want.shape
+                assert_bitwise(y.cpu().numpy(), want,
+                               f'{shape} {dtype.__name__} {mode} {tune}')
+                want_mask = np.moveaxis(
+                    ref_mask.reshape([m.n_b] + lead + tail), 0,
+                    axes[0]).reshape(want.shape)
+                assert np.array_equal(mask.cpu().numpy().astype(bool),
+                                      want_mask), (shape, mode, tune)
+
+
+def _apply_cell(plan, grid, xd, axes, emode, tune):
+    """`remap_tensor`'s own route for short runs, with an explicit TT."""
+    from pyremap_amd import engine
+    lead = axes[0]
+    n_batch = int(np.prod(xd.shape[:lead], dtype=np.int64))
+    k_inner = int(np.prod(xd.shape[lead + 1:], dtype=np.int64))
+    out_shape = list(xd.shape[:lead]) + list(grid) + list(xd.shape[lead + 1:])
+    y = torch.empty(out_shape, dtype=torch.float64, device=xd.device)
+    mask = torch.empty(out_shape, dtype=torch.uint8, device=xd.device)
+    args = plan._prefilled(True, True)
+    real = plan._prefilled
+    plan._prefilled = lambda whole, cell=False: real(whole, True)
+    try:
+        engine.apply_strided(
+            plan, xd, y, n_batch=n_batch, k_inner=k_inner,
+            x_row_stride=k_inner, x_batch_stride=plan.n_a * k_inner,
+            y_row_stride=k_inner, y_batch_stride=plan.n_b * k_inner,
+            mode=emode, threshold=0.05, mask_out=mask, tune=tune)
+    finally:
+        plan._prefilled = real
+    del args
+    return y, mask
+
+
+def test_time_ncells_takes_one_launch_no_copy(dev, monkeypatch):
+    """(Time = 120, nCells): ONE launch on the caller's tensor, no permute
+    copy, through the LDS-staged kernel; partial row ranges and plans
+    without a grid take `spmm_rowcell`."""
+    from oracle import oracle
+    from pyremap_amd import engine
+    m, plan, csr, frac_b, choice = _problem(dev, (50, 80))
+    assert choice['family'] == 'rowgroup'
+    calls = []
+    real = engine.apply_strided
+
+    def spy(plan_, X, Y, **kw):
+        calls.append((X.data_ptr(), kw['n_batch'], kw['k_inner'],
+                      kw['x_row_stride'], kw['x_batch_stride']))
+        return real(plan_, X, Y, **kw)
+    monkeypatch.setattr(engine, 'apply_strided', spy)
+    x = torch.randn((120, m.n_a), dtype=torch.float64, device=dev)
+    y = engine.remap_tensor(plan, m.dst_dims, x, [1], engine.MODE_FRACB)
+    assert calls == [(x.data_ptr(), 120, 1, 1, m.n_a)]
+    assert plan._cell and plan._cell['rows'] <= 256
+    ref, ref_mask = oracle.remap_flat(csr, frac_b, x.cpu().numpy().T.copy(),
+                                      False, 0.0)
+    ref[ref_mask] = np.nan
+    assert_bitwise(y.cpu().numpy().reshape(120, m.n_b), ref.T, 'T120')
+    # the masked / unmasked decision on the device, gated launches
+    x[:, ::7] = float('nan')
+    y = engine.remap_tensor_auto_mode(plan, m.dst_dims, x, [1], 0.05)
+    ref, ref_mask = oracle.remap_flat(csr, frac_b, x.cpu().numpy().T.copy(),
+                                      True, 0.05)
+    ref[ref_mask] = np.nan
+    assert_bitwise(y.cpu().numpy().reshape(120, m.n_b), ref.T, 'T120 auto')
+    # a row shard of the same plan: partial ranges run without patches
+    monkeypatch.setattr(engine, 'apply_strided', real)
+    sh = plan.row_slice(1000, 3000)
+    ys = engine.remap_tensor(sh, None, x, [1], engine.MODE_MASKED,
+                             threshold=0.05)
+    assert_bitwise(ys.cpu().numpy(), ref.T[:, 1000:3000], 'shard')
+
+
+@pytest.mark.parametrize('locality', ['raster', 'scatter'])
+def test_time_ncells_other_numberings(dev, locality):
+    from oracle import oracle
+    from pyremap_amd import engine
+    m, plan, csr, frac_b, _ = _problem(dev, (50, 80), locality=locality,
+                                       seed=2)
+    x = torch.randn((70, m.n_a), dtype=torch.float64, device=dev)
+    y = engine.remap_tensor(plan, m.dst_dims, x, [1], engine.MODE_FRACB)
+    ref, ref_mask = oracle.remap_flat(csr, frac_b, x.cpu().numpy().T.copy(),
+                                      False, 0.0)
+    ref[ref_mask] = np.nan
+    assert_bitwise(y.cpu().numpy().reshape(70, m.n_b), ref.T, locality)

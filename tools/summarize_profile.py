@@ -183,7 +183,15 @@ def main():
                        f'FETCH_SIZE x 1024 x 2 (gfx950 half-count correction '
                        f'for 16 B/lane reads, MI355X_MICROARCH.md) + '
                        f'WRITE_SIZE x 1024')
-            with open(os.path.join(out, f'traffic_{wl}.json'), 'w') as f:
+            # the raster-numbered files of round 2 keep their names; other
+            # numberings of the synthetic source mesh carry theirs
+            loc = cfg['config'].get('locality', 'raster') if cfg else 'raster'
+            suffix = '' if loc == 'raster' else f'_{loc}'
+            if mode not in (None, 'fracb'):
+                suffix += f'_{mode}'
+            traffic['numbering'] = loc
+            with open(os.path.join(out, f'traffic_{wl}{suffix}.json'),
+                      'w') as f:
                 json.dump(traffic, f, indent=1)
             L.append(f'Corrected fabric traffic per launch: reads '
                      f'{fetch / 1e9:.3f} GB (FETCH_SIZE x 2), writes '
