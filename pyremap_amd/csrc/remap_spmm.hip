@@ -185,26 +185,34 @@ typedef void (*patch_fn)(const KParams, const uint32_t, const int32_t *,
                          const int32_t, const int32_t, const int32_t,
                          const int64_t);
 
-template <int WC>
+template <typename XT, int WC, bool DMA>
 patch_fn pick_patch_wc(int mode, bool fma)
 {
     switch (mode) {
     case REMAP_MODE_RAW:
-        return fma ? spmm_patch<REMAP_MODE_RAW, true, WC>
-                   : spmm_patch<REMAP_MODE_RAW, false, WC>;
+        return fma ? spmm_patch<XT, REMAP_MODE_RAW, true, WC, DMA>
+                   : spmm_patch<XT, REMAP_MODE_RAW, false, WC, DMA>;
     case REMAP_MODE_FRACB:
-        return fma ? spmm_patch<REMAP_MODE_FRACB, true, WC>
-                   : spmm_patch<REMAP_MODE_FRACB, false, WC>;
+        return fma ? spmm_patch<XT, REMAP_MODE_FRACB, true, WC, DMA>
+                   : spmm_patch<XT, REMAP_MODE_FRACB, false, WC, DMA>;
     default:
-        return fma ? spmm_patch<REMAP_MODE_MASKED, true, WC>
-                   : spmm_patch<REMAP_MODE_MASKED, false, WC>;
+        return fma ? spmm_patch<XT, REMAP_MODE_MASKED, true, WC, DMA>
+                   : spmm_patch<XT, REMAP_MODE_MASKED, false, WC, DMA>;
     }
 }
 
-patch_fn pick_patch(int mode, bool fma, int row_bytes)
+// wc = columns per K-chunk (128 / 64); dma = 16-byte LDS-DMA pieces of
+// float64 rows (else through registers, converting f32 on the way)
+patch_fn pick_patch(bool f32, int mode, bool fma, int wc, bool dma)
 {
-    return row_bytes == 512 ? pick_patch_wc<64>(mode, fma)
-                            : pick_patch_wc<128>(mode, fma);
+    if (f32)
+        return wc == 64 ? pick_patch_wc<float, 64, false>(mode, fma)
+                        : pick_patch_wc<float, 128, false>(mode, fma);
+    if (!dma)
+        return wc == 64 ? pick_patch_wc<double, 64, false>(mode, fma)
+                        : pick_patch_wc<double, 128, false>(mode, fma);
+    return wc == 64 ? pick_patch_wc<double, 64, true>(mode, fma)
+                    : pick_patch_wc<double, 128, true>(mode, fma);
 }
 
 typedef void (*cell_fn)(const KParams, const uint32_t, const int32_t *,
@@ -239,14 +247,12 @@ cell_fn pick_patchcell(int tt, int mode, bool fma)
 // LDS a workgroup may ask for and still leave room for a second one per CU
 constexpr uint32_t kPatchLdsMax = 160 * 1024;
 
-bool patch_usable(const remap_apply_args *a, int64_t K64, bool f32,
-                  bool can_vec2)
+bool patch_usable(const remap_apply_args *a, int64_t K64)
 {
     return a->patch_ptr && a->patch_ucol && a->patch_lidx &&
            a->patch_rowptr && a->patch_val && a->patch_rows > 0 &&
            a->patch_rows < kPatchBlock && a->n_patches > 0 &&
-           a->patch_umax >= 0 && a->patch_emax >= 0 && !f32 && can_vec2 &&
-           K64 >= 2 &&
+           a->patch_umax >= 0 && a->patch_emax >= 0 && K64 >= 2 &&
            (a->patch_row_bytes == 1024 || a->patch_row_bytes == 512) &&
            patch_lds_bytes(a->patch_umax, a->patch_emax, a->patch_rows,
                            a->patch_row_bytes) <= kPatchLdsMax &&
@@ -417,6 +423,7 @@ struct Call {
     bool fma;
     bool f32;
     bool can_vec2;        // two elements per lane: even strides, aligned bases
+    bool dma16;           // 16-byte pieces of X rows are aligned and whole
     bool small_offsets;   // byte offsets inside a row fit 32 bits
     bool patch_ok;        // a usable patch plan is attached
     bool cell_ok;         // a patch plan family 7 can use is attached
@@ -476,11 +483,13 @@ int check_args(const remap_apply_args *a, Call &c)
         (a->x_batch_stride % 2 == 0) && (a->y_row_stride % 2 == 0) &&
         (a->y_batch_stride % 2 == 0) && aligned(a->X, 2 * xelem) &&
         aligned(a->Y, 16);
+    // LDS-DMA moves 16 bytes (2 doubles) per lane
+    c.dma16 = c.can_vec2 && !c.f32;
     // per-lane byte offset of the last flat column, from a row base
     c.small_offsets =
         ((a->n_batch - 1) * a->x_batch_stride + a->k_inner) *
             (int64_t)xelem < (int64_t(1) << 31);
-    c.patch_ok = patch_usable(a, c.K, c.f32, c.can_vec2);
+    c.patch_ok = patch_usable(a, c.K);
     c.cell_ok = a->patch_ptr && a->patch_ucol && a->patch_lidx &&
                 a->patch_rowptr && a->patch_val && a->patch_rows > 0 &&
                 a->n_patches > 0 && a->patch_umax >= 0 &&
@@ -689,15 +698,18 @@ int run_patch(const remap_apply_args *a, const Call &c, KParams p,
     if (!c.patch_ok)
         return fail(REMAP_ERR_ARG,
                     "remap_apply_f64: the patch kernel needs a patch plan "
-                    "covering [row_begin, row_end), float64 X and even "
-                    "strides");
-    // At most 64 columns: 512 bytes staged per source row whatever the plan
-    // was sized for (it fits a fortiori) -- every lane of the compute phase
-    // busy, half the DMA (config 2, K = 64: 13.7 -> 11.5 us, masked 16.0 ->
-    // 12.1; config 4's map at K = 64: 4.34 -> 3.17 ms)
-    const int row_bytes = c.K <= 64 ? 512 : a->patch_row_bytes;
+                    "covering [row_begin, row_end)");
+    // Columns per K-chunk.  At most 64 columns: 64 whatever the plan was
+    // sized for (it fits a fortiori) -- every lane of the compute phase busy,
+    // half the staging (config 2, K = 64: 13.7 -> 11.5 us, masked 16.0 ->
+    // 12.1; config 4's map at K = 64: 4.34 -> 3.17 ms).  Odd strides or
+    // level counts: 64 columns, one element per lane.  float64 rows in whole
+    // 16-byte pieces go by LDS-DMA, everything else through registers.
+    const int wc = (!c.can_vec2 || c.K <= 64) ? 64 : a->patch_row_bytes / 8;
+    const int row_bytes = wc * 8;
     int64_t grid;
-    const int rc = shape_grid(p, a->n_patches, ceil_div(c.K, row_bytes / 8),
+    const int rc = shape_grid(p, a->n_patches,
+                              shape_tiles(p, a, c.K, wc, 1),
                               a->tune[4] == 0 || a->tune[4] == 2, grid);
     if (rc != REMAP_OK)
         return rc;
@@ -705,7 +717,7 @@ int run_patch(const remap_apply_args *a, const Call &c, KParams p,
                                          a->patch_rows, row_bytes);
     if (lds_bytes < 1024)
         lds_bytes = 1024;
-    patch_fn pf = pick_patch(a->mode, c.fma, row_bytes);
+    patch_fn pf = pick_patch(c.f32, a->mode, c.fma, wc, c.dma16);
     REMAP_HIP_CHECK(diag_lds_throttle(a, reinterpret_cast<const void *>(pf),
                                       lds_bytes));
     if (lds_bytes > 64 * 1024)

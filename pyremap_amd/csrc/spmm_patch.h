@@ -32,8 +32,10 @@
 constexpr int kPatchBlock = 1024;  // 16 waves
 constexpr int kPatchWaves = kPatchBlock / kWave;
 
-// LDS image of one workgroup (row_bytes = 1024 or 512 per staged row chunk):
-//   [0, (umax + 1) * row_bytes)  the distinct source-row chunks
+// LDS image of one workgroup (row_bytes = 1024, 512 or 256 per staged row
+// chunk):
+//   [0, umax * row_bytes rounded up to a whole KiB)  the distinct source-row
+//                          chunks (a DMA instruction always lands 1 KiB)
 //   then                   hdr  16 B[rows]  per row: element offset of its
 //                                           Y row (int64), first entry, one
 //                                           past its last entry (int32 each)
@@ -44,16 +46,26 @@ constexpr int kPatchWaves = kPatchBlock / kWave;
 __host__ __device__ inline uint32_t patch_lds_bytes(int umax, int emax,
                                                     int rows, int row_bytes)
 {
-    return (static_cast<uint32_t>(umax) + 1u) * row_bytes +
+    return ((static_cast<uint32_t>(umax) * row_bytes + 1023u) & ~1023u) +
            static_cast<uint32_t>(emax) * 12u +
            static_cast<uint32_t>(rows) * 24u + 32u;
 }
 
-// WC = columns per K-chunk: 128 (two doubles per lane, 1 KiB per staged row)
-// or 64 (one double per lane, 512 B per staged row: half the LDS per row, so
-// twice the patch area fits -- for mappings whose rows reference many
-// source rows, e.g. 2nd-order conservative stencils)
-template <int MODE, bool FMA, int WC>
+// WC = columns per K-chunk: 128 (two elements per lane) or 64 (one element
+// per lane: half the LDS per row, so twice the patch area fits -- for
+// mappings whose rows reference many source rows, e.g. 2nd-order
+// conservative stencils).  The LDS image always holds float64: WC * 8 bytes
+// per staged row chunk.
+// DMA = true (float64 X only): LDS-DMA, 16 bytes per lane -- needs 16-byte
+// aligned pieces (even strides and level counts).
+// DMA = false: every lane loads its WC / 64 elements into registers, converts
+// (f32 -> f64: the reference's real lat-lon input is f32,
+// tests/test_interpolate.py:492-516; converting the few distinct rows once
+// while staging keeps the conversion out of the compute loop, which runs
+// once per ENTRY -- config 4: 44 staged rows for 2 300 entries per patch) and
+// writes them to LDS.  With WC = 64 that takes any stride and alignment:
+// (Time, nCells, 61 levels) on a bilinear map.
+template <typename XT, int MODE, bool FMA, int WC, bool DMA>
 __global__ __launch_bounds__(kPatchBlock) void spmm_patch(
     const KParams p, const uint32_t flags,
     const int32_t *__restrict__ prow, const double *__restrict__ pval,
@@ -62,11 +74,13 @@ __global__ __launch_bounds__(kPatchBlock) void spmm_patch(
     const double *__restrict__ frac_b, const int32_t patch_rows,
     const int32_t umax, const int32_t emax, const int64_t n_patches)
 {
-    constexpr int VEC = WC / kWave;           // doubles per lane
-    constexpr int kRowBytes = WC * 8;         // staged bytes per source row
+    static_assert(!DMA || sizeof(XT) == 8, "the DMA moves float64 rows");
+    constexpr int VEC = WC / kWave;           // elements per lane
+    constexpr int kRowBytes = WC * 8;         // staged bytes per row (f64)
     constexpr int kRowsPerDma = 1024 / kRowBytes;  // rows per DMA instruction
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    typedef typename XVec<double, VEC>::type xvec_t;
+    typedef typename XVec<double, VEC>::type xvec_t;   // LDS holds doubles
+    typedef typename XVec<XT, VEC>::type gvec_t;       // X as it is
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -80,17 +94,28 @@ __global__ __launch_bounds__(kPatchBlock) void spmm_patch(
     int64_t xoff[1], yoff[1];
     bool act[1];
     tile_offsets<VEC, 1>(p, chunk, lane, xoff, yoff, act);
-    // gather-phase columns: every lane moves 16 B (2 doubles); with 512-byte
-    // rows one instruction carries two source rows (lanes 0-31 / 32-63)
+    // gather-phase columns (DMA): every lane moves 16 B (2 doubles); with
+    // 512-byte rows one instruction carries two source rows (lanes 0-31 /
+    // 32-63).  Same tile shapes as the compute phase (tile_offsets): whole
+    // batches per tile (p.bpc) or the flat column list cut every WC columns.
     int64_t goff;
     {
         constexpr int kLanesPerRow = kWave / kRowsPerDma;
-        const uint32_t kf = static_cast<uint32_t>(chunk) * WC +
-                            (lane % kLanesPerRow) * 2;
-        const bool in = kf < p.K;
-        const uint32_t bb = in ? kf / p.k_inner : 0u;
-        const uint32_t kk = in ? kf - bb * p.k_inner : 0u;
-        goff = static_cast<int64_t>(bb) * p.bsx + kk;
+        const uint32_t cc = (lane % kLanesPerRow) * 2;   // column in the tile
+        if (p.bpc) {
+            const uint32_t n_batch = p.K / p.k_inner;
+            const uint32_t bi = cc / p.k_inner;
+            const uint32_t kk = cc - bi * p.k_inner;
+            const uint32_t bb = static_cast<uint32_t>(chunk) * p.bpc + bi;
+            const bool in = bi < p.bpc && bb < n_batch;
+            goff = in ? static_cast<int64_t>(bb) * p.bsx + kk : 0;
+        } else {
+            const uint32_t kf = static_cast<uint32_t>(chunk) * WC + cc;
+            const bool in = kf < p.K;
+            const uint32_t bb = in ? kf / p.k_inner : 0u;
+            const uint32_t kk = in ? kf - bb * p.k_inner : 0u;
+            goff = static_cast<int64_t>(bb) * p.bsx + kk;
+        }
     }
     const int sub = lane / (kWave / kRowsPerDma);  // which row of the pair
 
@@ -99,7 +124,8 @@ __global__ __launch_bounds__(kPatchBlock) void spmm_patch(
         int32_t s, e;         // its entries [s, e) in lds_val / lds_lidx
     };
     RowHeader *lds_hdr =
-        reinterpret_cast<RowHeader *>(lds + (umax + 1) * kRowBytes);
+        reinterpret_cast<RowHeader *>(lds +
+                                      ((umax * kRowBytes + 1023) & ~1023));
     double *lds_val = reinterpret_cast<double *>(lds_hdr + patch_rows);
     double *lds_fb = lds_val + emax;
     int32_t *lds_lidx = reinterpret_cast<int32_t *>(lds_fb + patch_rows);
@@ -145,18 +171,53 @@ __global__ __launch_bounds__(kPatchBlock) void spmm_patch(
     double my_fb = 0.0;
     if constexpr (MODE == REMAP_MODE_FRACB)
         my_fb = frac_b[my_rid];
-    const double *__restrict__ X = static_cast<const double *>(p.X);
-    for (int j = wave * kRowsPerDma; j < U; j += kPatchWaves * kRowsPerDma) {
-        // the second row of a pair may not exist: fetch the first again
-        // (lands in the spare slot behind the list)
-        const int jj = (j + sub < U) ? j + sub : j;
-        int32_t c = ucol[u0 + jj];
-        REMAP_DIAG_COL(p, c);
-        const double *g = X + static_cast<int64_t>(c) * p.ldx + goff;
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void *)g,
-            (__attribute__((address_space(3))) void *)(lds + j * kRowBytes),
-            16, 0, 0);
+    const XT *__restrict__ X = static_cast<const XT *>(p.X);
+    if constexpr (DMA) {
+        for (int j = wave * kRowsPerDma; j < U;
+             j += kPatchWaves * kRowsPerDma) {
+            // rows of the group that do not exist: fetch the first again
+            // (they land behind the list, inside its last KiB: the row
+            // region is a whole number of KiB, see patch_lds_bytes)
+            const int jj = (j + sub < U) ? j + sub : j;
+            int32_t c = ucol[u0 + jj];
+            REMAP_DIAG_COL(p, c);
+            const XT *g = X + static_cast<int64_t>(c) * p.ldx + goff;
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)g,
+                (__attribute__((address_space(3))) void *)(lds +
+                                                           j * kRowBytes),
+                16, 0, 0);
+        }
+    } else {
+        // register staging, four rows in flight per wave; a lane stages
+        // the very columns it computes (converted to float64)
+        constexpr int kAhead = 4;
+        for (int j = wave; j < U; j += kPatchWaves * kAhead) {
+            gvec_t v[kAhead];
+#pragma unroll
+            for (int q = 0; q < kAhead; ++q) {
+                const int jq = j + q * kPatchWaves;
+                int32_t c = ucol[u0 + (jq < U ? jq : j)];
+                REMAP_DIAG_COL(p, c);
+                v[q] = load_x<XT, VEC>(X + static_cast<int64_t>(c) * p.ldx +
+                                       xoff[0]);
+            }
+#pragma unroll
+            for (int q = 0; q < kAhead; ++q) {
+                const int jq = j + q * kPatchWaves;
+                if (jq < U) {
+                    xvec_t d;
+                    if constexpr (VEC == 1) {
+                        d = static_cast<double>(v[q]);
+                    } else {
+                        d[0] = static_cast<double>(v[q][0]);
+                        d[1] = static_cast<double>(v[q][1]);
+                    }
+                    *reinterpret_cast<xvec_t *>(lds + jq * kRowBytes +
+                                                lane * (VEC * 8)) = d;
+                }
+            }
+        }
     }
 #pragma unroll
     for (int k = 0; k < kPre; ++k) {

@@ -494,6 +494,55 @@ def test_patch_kernel_bitwise(dev, tile, K, row_bytes):
         assert_bitwise(y.cpu().numpy(), ref, f'tile={tile} K={K}')
 
 
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+@pytest.mark.parametrize('shape, axes', [
+    ((1500, 128), [0]), ((1500, 64), [0]), ((1500, 130), [0]),
+    ((2, 1500, 61), [1]), ((3, 1500, 64), [1]), ((2, 1500, 66), [1]),
+    ((4, 1500, 33), [1]), ((1500, 63), [0]), ((2, 1500, 100), [1])])
+def test_patch_kernel_f32_and_odd_strides(dev, shape, axes, dtype):
+    """
+    VERDICT round 2, item 6: the LDS patch kernel for f32 fields (the
+    reference's real lat-lon input, tests/test_interpolate.py:492-516) and
+    for odd strides / level counts -- (2, n, 61) -- which used to drop to
+    `spmm_rowscalar`.  Forced through family 5 (`tune=[5]` without the hint
+    flag fails loudly if the kernel cannot take the call), bitwise.
+    """
+    from oracle import oracle
+    from pyremap_amd import engine, synthetic
+    m = synthetic.bilinear_map((30, 50), (70, 90), device=dev)
+    assert m.n_a == 1500
+    plan = engine.RemapPlan.from_triplets(m.row, m.col, m.S, m.frac_b,
+                                          m.n_a, m.n_b, device=dev)
+    choice = plan.auto_schedule(m.dst_dims)
+    assert choice['family'] == 'patch', choice
+    rowptr, col, val = plan.to_host_csr()
+    csr = oracle.OracleCSR(rowptr, col, val, (m.n_b, m.n_a))
+    frac_b = m.frac_b.cpu().numpy()
+    rng = np.random.default_rng(shape[-1])
+    x = rng.standard_normal(shape).astype(dtype)
+    for masked in (False, True):
+        if masked:
+            dead = rng.random(m.n_a) < 0.2
+            x[(slice(None),) * axes[0] + (dead,)] = np.nan
+        arg = np.ma.masked_array(x, np.isnan(x)) if masked else x
+        ref = oracle.remap_numpy_array(csr, frac_b, m.dst_dims, arg, axes,
+                                       0.05 if masked else None).filled(
+            np.nan)
+        for view in ('aligned', 'offset'):
+            xd = torch.from_numpy(x).to(dev)
+            if view == 'offset':
+                # a view that starts one element into its allocation
+                big = torch.empty(xd.numel() + 1, dtype=xd.dtype, device=dev)
+                big[1:] = xd.reshape(-1)
+                xd = big[1:].reshape(shape)
+            y = engine.remap_tensor(
+                plan, m.dst_dims, xd, axes,
+                engine.MODE_MASKED if masked else engine.MODE_FRACB,
+                threshold=0.05, tune=[5])
+            assert_bitwise(y.cpu().numpy(), ref,
+                           f'{shape} {dtype.__name__} {view} {masked}')
+
+
 def test_patch_kernel_layouts_and_fallbacks(dev):
     """(T, n, L) in place through the patch family; 1-D destinations; the
     automatic choice falls back where the patch plan does not apply."""
@@ -514,7 +563,7 @@ def test_patch_kernel_layouts_and_fallbacks(dev):
     y = engine.remap_tensor(plan, m.dst_dims, torch.from_numpy(f).to(dev),
                             [1], engine.MODE_FRACB)
     assert_bitwise(y.cpu().numpy(), ref)
-    # float32 input: patch family does not apply, automatic choice still right
+    # float32 input: LDS patches too (256 / 512-byte staged rows)
     f32 = f.astype(np.float32)
     ref32 = oracle.remap_numpy_array(csr, mm['frac_b'], m.dst_dims, f32, [1],
                                      None).filled(np.nan)
