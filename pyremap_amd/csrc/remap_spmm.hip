@@ -386,15 +386,44 @@ typename GroupFn<XT>::type pick_rowgroup_shape(int unr, int tiles, int vec,
                        : pick_rowgroup_tiles<XT, G, 8>(tiles, mode, fma);
 }
 
+#ifdef REMAP_DIAG
+// the lock-step experiment (diagnostic build only; tools/lockstep.py,
+// profiles/r03_analysis/lockstep.md): float64, 2 x 2 groups, one tile
+template <int BLOCK>
+GroupFn<double>::type pick_rowgroup_lock(int mode)
+{
+    switch (mode) {
+    case REMAP_MODE_RAW:
+        return spmm_rowgroup<double, 1, REMAP_MODE_RAW, false, 4, 8, 2, true,
+                             BLOCK>;
+    case REMAP_MODE_FRACB:
+        return spmm_rowgroup<double, 1, REMAP_MODE_FRACB, false, 4, 8, 2,
+                             true, BLOCK>;
+    default:
+        return spmm_rowgroup<double, 1, REMAP_MODE_MASKED, false, 4, 8, 2,
+                             true, BLOCK>;
+    }
+}
+#endif
+
 template <typename XT>
 int launch_rowgroup(const remap_apply_args *a, const KParams &p, int tiles,
                     int unr, int vec, int wpb, bool fma, int64_t grid,
-                    hipStream_t stream)
+                    hipStream_t stream, bool lock = false)
 {
     typename GroupFn<XT>::type fn =
         a->group_rows == 8
             ? pick_rowgroup_shape<XT, 8>(unr, tiles, vec, a->mode, fma)
             : pick_rowgroup_shape<XT, 4>(unr, tiles, vec, a->mode, fma);
+#ifdef REMAP_DIAG
+    if constexpr (std::is_same<XT, double>::value) {
+        if (lock)
+            fn = wpb > 4 ? pick_rowgroup_lock<1024>(a->mode)
+                         : pick_rowgroup_lock<kBlock>(a->mode);
+    }
+#else
+    (void)lock;
+#endif
     uint32_t lds_bytes = 0;
     REMAP_HIP_CHECK(diag_lds_throttle(a, reinterpret_cast<const void *>(fn),
                                       lds_bytes));
@@ -673,12 +702,31 @@ int run_rowgroup(const remap_apply_args *a, const Call &c, KParams p,
     const int vec = (c.can_vec2 && !narrow) ? 2 : 1;
     if (vec == 1)
         tiles = c.K > 64 ? 2 : 1;
-    const int gpw = a->tune[3] > 0 ? a->tune[3] : 2;   // groups per wave
+    int gpw = a->tune[3] > 0 ? a->tune[3] : 2;   // groups per wave
     // union entries in flight
     const int unr = (a->tune[5] == 4 || a->tune[5] == 16) ? a->tune[5] : 8;
     // waves per workgroup (tune[1], unused otherwise by this family)
-    const int wpb = (a->tune[1] == 1 || a->tune[1] == 2) ? a->tune[1]
-                                                         : kWavesPerBlock;
+    int wpb = (a->tune[1] == 1 || a->tune[1] == 2) ? a->tune[1]
+                                                   : kWavesPerBlock;
+    // tune[5] >= 100 (diagnostic build): the lock-step experiment
+    // (step-aligned lists: see spmm_rowgroup.h); the workgroup is one
+    // supergroup of tune[1] groups
+    const bool lock = a->tune[5] >= 100;
+#ifndef REMAP_DIAG
+    if (lock)
+        return fail(REMAP_ERR_UNSUPPORTED,
+                    "remap_apply_f64: tune[5] >= 100 is a switch of the "
+                    "diagnostic build (-DREMAP_DIAG), absent from this one");
+#endif
+    if (lock) {
+        if (c.f32 || a->group_rows != 4 || !c.can_vec2 || tiles != 1 ||
+            c.fma || (a->tune[1] != 4 && a->tune[1] != 16))
+            return fail(REMAP_ERR_UNSUPPORTED,
+                        "remap_apply_f64: the lock-step walk serves float64, "
+                        "2 x 2 groups, supergroups of 4 or 16");
+        wpb = a->tune[1];
+        gpw = 1;
+    }
     p.rows_per_wave = gpw;
     int64_t grid;
     const int rc = shape_grid(
@@ -689,7 +737,7 @@ int run_rowgroup(const remap_apply_args *a, const Call &c, KParams p,
     return c.f32 ? launch_rowgroup<float>(a, p, tiles, unr, vec, wpb, c.fma,
                                           grid, stream)
                  : launch_rowgroup<double>(a, p, tiles, unr, vec, wpb, c.fma,
-                                           grid, stream);
+                                           grid, stream, lock);
 }
 
 int run_patch(const remap_apply_args *a, const Call &c, KParams p,

@@ -52,8 +52,18 @@ struct F64Vec<8> {
     typedef double type __attribute__((ext_vector_type(8), aligned(8)));
 };
 
-template <typename XT, int TILES, int MODE, bool FMA, int G, int UNR, int VEC>
-__global__ __launch_bounds__(kBlock) void spmm_rowgroup(
+// LOCK (diagnostic build only, tune[5] >= 100; measured and NOT adopted, see
+// profiles/r03_analysis/lockstep.md): the waves of a workgroup -- the groups
+// of one SUPERGROUP, a 4 x 4 or 8 x 8 tile of the destination grid -- walk
+// step-ALIGNED lists (every step covers the same range of source-row ids in
+// every wave; the lists carry padding entries with an empty member mask,
+// tools/lockstep.py) behind a workgroup barrier per step, so that a source
+// row two groups share is requested by both inside the same step: the
+// second request is merged with the first in L2 (or hits L1) instead of
+// arriving ~20 us later, after the line was evicted.
+template <typename XT, int TILES, int MODE, bool FMA, int G, int UNR, int VEC,
+          bool LOCK = false, int BLOCK = kBlock>
+__global__ __launch_bounds__(BLOCK) void spmm_rowgroup(
     const KParams p, const uint32_t flags,
     const int64_t *__restrict__ gmeta, const int32_t *__restrict__ gcol,
     const double *__restrict__ gw, const int32_t *__restrict__ gmask,
@@ -129,8 +139,13 @@ __global__ __launch_bounds__(kBlock) void spmm_rowgroup(
                 if (uu < n) {
                     int32_t c = cv[uu];
                     REMAP_DIAG_COL(p, c);
+                    // (padding entries of the aligned lists: a descriptor of
+                    // zero bytes -- the load returns zeros without a request)
                     const __amdgpu_buffer_rsrc_t xr =
-                        row_rsrc(X + static_cast<int64_t>(c) * p.ldx);
+                        LOCK ? row_rsrc_sized(
+                                   X + static_cast<int64_t>(c) * p.ldx,
+                                   mv[uu] ? 0x7fffffff : 0)
+                             : row_rsrc(X + static_cast<int64_t>(c) * p.ldx);
 #pragma unroll
                     for (int t = 0; t < TILES; ++t)
                         xv[uu][t] = load_x_buf<XT, VEC>(xr, xo[t]);
@@ -241,6 +256,8 @@ __global__ __launch_bounds__(kBlock) void spmm_rowgroup(
                     *reinterpret_cast<const ivec_t *>(gcol + base);
                 const ivec_t mv =
                     *reinterpret_cast<const ivec_t *>(gmask + base);
+                if constexpr (LOCK)
+                    __builtin_amdgcn_s_barrier();
                 ivec_t cv_n, mv_n;
                 step(cv, mv, n, cv_n, mv_n, base + UNR);
             }

@@ -28,6 +28,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const void *base)
                                              0x7fffffff, 0x00020000);
 }
 
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc_sized(
+    const void *base, int32_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0,
+                                             bytes, 0x00020000);
+}
+
 template <typename XT, int VEC>
 __device__ __forceinline__ typename XVec<XT, VEC>::type load_x_buf(
     __amdgpu_buffer_rsrc_t r, uint32_t byte_off)
