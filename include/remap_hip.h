@@ -122,6 +122,14 @@ typedef struct remap_csr {
 } remap_csr;
 
 /*
+ * Two levels.  The PUBLIC, frozen face for a binder is
+ * the opaque plan handle further down -- remap_plan_create / _apply /
+ * _destroy with the 15-field remap_field -- which hides every schedule
+ * internal.  remap_apply_args below is the ADVANCED level: the non-allocating
+ * entry points a host layer with its own allocator composes (this package's
+ * Python layer does); its schedule fields mirror remap_schedule one to one
+ * and are filled by remap_schedule_auto, not by hand.
+ *
  * One application of the weights to a batch of fields.
  *
  * The flattened (n_a, K) matrix of the reference (remap_numpy.py:254-256) is

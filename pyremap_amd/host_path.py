@@ -37,7 +37,19 @@ CHUNK_BYTES = 64 << 20
 #: time in pinned memory; beyond it a result lands in ordinary pageable
 #: memory (slower: first-touch page faults) rather than pinning without
 #: bound.  Environment: PYREMAP_AMD_PINNED_LIMIT (bytes).
-PINNED_LIMIT = int(os.environ.get('PYREMAP_AMD_PINNED_LIMIT', 16 << 30))
+def _default_pinned_limit():
+    """min(4 GiB, a quarter of the machine's RAM): freed result blocks go
+    back to torch's caching HOST allocator, which keeps them pinned, so the
+    budget is what a long-lived process may end up holding page-locked."""
+    try:
+        ram = os.sysconf('SC_PAGE_SIZE') * os.sysconf('SC_PHYS_PAGES')
+    except (ValueError, OSError, AttributeError):
+        ram = 16 << 30
+    return min(4 << 30, ram // 4)
+
+
+PINNED_LIMIT = int(os.environ.get('PYREMAP_AMD_PINNED_LIMIT',
+                                  _default_pinned_limit()))
 
 #: device buffers of the batch pipeline: this many chunk-sized slots each
 #: for the source and the result (bounded device memory whatever the field)
@@ -73,8 +85,20 @@ def _host_buffer(shape, dtype):
         pin = _pinned_alive[0] + nbytes <= PINNED_LIMIT
         if pin:
             _pinned_alive[0] += nbytes
-    return torch.empty(shape, dtype=dtype, pin_memory=pin), \
-        (nbytes if pin else 0)
+    if pin:
+        try:
+            return torch.empty(shape, dtype=dtype, pin_memory=True), nbytes
+        except RuntimeError:
+            # page-locking refused (ulimit -l, little RAM): hand the cached
+            # pinned blocks back and degrade to pageable memory
+            _release_pinned(nbytes)
+            try:
+                torch._C._host_emptyCache()
+            except AttributeError:
+                pass
+            _log_once('pin', 'pinned host memory refused; results land in '
+                      'pageable memory')
+    return torch.empty(shape, dtype=dtype), 0
 
 
 def _release_pinned(nbytes):

@@ -447,6 +447,71 @@ def test_dataset_level_matches_reference_golden(dev, golden_dir):
                        g[f'p_out__{v["name"]}'])
 
 
+def test_dataset_level_with_real_xarray(dev, golden_dir):
+    """
+    G3 ran the reference with this package's `xr_lite` standing in for
+    xarray on both sides (xarray is absent from the image).  The day xarray
+    imports, the same inputs go through REAL `xarray.Dataset` /
+    `DataArray` objects -- `Dataset.map(keep_attrs=True)`,
+    `DataArray.from_dict`, remap_numpy.py:42-55, 209-218 -- and must give the
+    committed outputs.  Skipped otherwise.
+    """
+    xr = pytest.importorskip('xarray')
+    import json
+    import sys
+
+    from pyremap_amd import Remapper
+    g = np.load(os.path.join(golden_dir, 'g3_dataset.npz'))
+    meta = json.loads(str(g['meta_json']))
+    rec_in = meta['input']
+    ds = xr.Dataset(
+        {v['name']: (v['dims'], g[f'in__{v["name"]}'], v['attrs'])
+         for v in rec_in['data_vars']},
+        coords={v['name']: (v['dims'], g[f'in__{v["name"]}'], v['attrs'])
+                for v in rec_in['coords']},
+        attrs=rec_in['attrs'])
+
+    class Desc:
+        pass
+    src, dst = Desc(), Desc()
+    src.dims, src.dim_sizes = ['nCells'], [int(g['n_a'])]
+    dst.dims = ['lat', 'lon']
+    dst.dim_sizes = [len(g['dst_lat']), len(g['dst_lon'])]
+    dst.coords = {k: {'dims': v['dims'], 'data': g[f'dst_{k}'],
+                      'attrs': v['attrs']}
+                  for k, v in meta['dst_coords'].items()}
+    dst.mesh_name = 'toy_6x8'
+    old = sys.argv
+    sys.argv = meta['argv']
+    try:
+        for tag, thr in (('thr', 0.01), ('nothr', None)):
+            r = Remapper.from_triplets(g['row'], g['col'], g['S'],
+                                       g['frac_b'], src, dst, device=dev)
+            out = r.remap_numpy(ds, thr)
+            assert isinstance(out, xr.Dataset)
+            rec = meta[f'dataset_{tag}']
+            assert list(out.data_vars) == [v['name']
+                                           for v in rec['data_vars']]
+            assert sorted(out.coords) == sorted(v['name']
+                                                for v in rec['coords'])
+            assert {k: str(v) for k, v in out.attrs.items()} == rec['attrs']
+            for v in rec['data_vars'] + rec['coords']:
+                var = out[v['name']]
+                assert list(var.dims) == v['dims'], v['name']
+                assert {k: str(a) for k, a in var.attrs.items()} == \
+                    v['attrs'], v['name']
+                assert_bitwise(np.asarray(var.values, dtype=np.float64),
+                               g[f'{tag}__{v["name"]}'].astype(np.float64),
+                               f'xarray {tag} {v["name"]}')
+        da = r.remap_numpy(ds['temperature'], 0.01)
+        assert isinstance(da, xr.DataArray)
+        rec = meta['dataarray_thr']
+        assert da.name == rec['name'] and list(da.dims) == rec['dims']
+        assert_bitwise(np.asarray(da.values), g['da__data'])
+    finally:
+        sys.argv = old
+
+
 # ---------------------------------------------------------------------------
 # LDS-staged patch family
 # ---------------------------------------------------------------------------
