@@ -132,9 +132,23 @@ class _Dataset:
         self.ref_slots = []       # global-heap object indices, one per axis
 
 
+def _is_deferred(data):
+    return hasattr(data, 'load') and not isinstance(data, np.ndarray)
+
+
 def write_netcdf4(filename, dimensions, variables, attrs=None,
-                  unlimited=(), nan_fill=None):
+                  unlimited=(), nan_fill=None, auto_fill=None):
     """
+    ``auto_fill``: variable name -> fill value for variables whose data is
+    PRODUCED ON DEMAND (an object with ``shape``, ``dtype``, ``load()`` and
+    optionally ``prefetch()``): each is loaded when the writer reaches it,
+    written and dropped (the next one started meanwhile), and gets that
+    value as ``_FillValue`` -- and in place of its NaNs -- iff its values
+    hold NaNs.  Their object headers are laid out with the attribute and
+    written last; where it turns out not to be needed a NIL message of the
+    same size takes its place.
+
+
     ``dimensions``: ordered name -> length; ``variables``: iterable of
     ``(name, dims, ndarray, attrs)``; ``attrs``: global attributes;
     ``nan_fill``: variable name -> value stored in place of its NaNs
@@ -144,9 +158,18 @@ def write_netcdf4(filename, dimensions, variables, attrs=None,
     storage; this writer stores contiguously).
     """
     attrs = OrderedDict(attrs or {})
+    auto_fill = dict(auto_fill or {})
+    nan_fill = dict(nan_fill or {})
     dimensions = OrderedDict((k, int(v)) for k, v in dimensions.items())
     datasets = OrderedDict()
     for name, dims, data, vattrs in variables:
+        if _is_deferred(data):
+            if tuple(data.shape) != tuple(dimensions[d] for d in dims):
+                raise ValueError(f'{name}: shape {data.shape} does not '
+                                 f'match dimensions {dims}')
+            datasets[name] = _Dataset(name, data, dims,
+                                      OrderedDict(vattrs or {}))
+            continue
         arr = np.asarray(data)
         if arr.dtype.kind == 'U':
             arr = np.char.encode(arr, 'utf-8')
@@ -186,11 +209,12 @@ def write_netcdf4(filename, dimensions, variables, attrs=None,
             heap_objects.append(d)
             ds.ref_slots.append(len(heap_objects))
 
-    def dataset_messages(ds, gheap_addr):
+    def dataset_messages(ds, gheap_addr, reserve=False):
         # fixed extents: HDF5 allows unlimited maxima only with chunked
         # storage, so record dimensions are written at their current length
         msgs = [_message(0x01, _dataspace(ds.data.shape)),
-                _message(0x03, _datatype(ds.data.dtype), flags=0x01)]
+                _message(0x03, _datatype(np.dtype(ds.data.dtype)
+                                         .newbyteorder('<')), flags=0x01)]
         nbytes = ds.data.nbytes
         addr = (ds.data_addr or 0) if (ds.allocate and nbytes) else UNDEF
         msgs.append(_message(0x08, struct.pack('<BBQQ', 3, 1, addr, nbytes)))
@@ -209,6 +233,15 @@ def write_netcdf4(filename, dimensions, variables, attrs=None,
                                    _dataspace((len(ds.ref_slots),)), data))
         for key, value in ds.attrs.items():
             msgs.append(_attr_value(key, value))
+        if _is_deferred(ds.data) and ds.name in auto_fill:
+            # the _FillValue of a variable whose values are not known yet:
+            # reserved in the layout, written iff NaNs turned up, a NIL
+            # message of the same size otherwise
+            fill = _attr_value('_FillValue', auto_fill[ds.name])
+            if reserve or ds.name in nan_fill:
+                msgs.append(fill)
+            else:
+                msgs.append(_message(0x00, b'\x00' * (len(fill) - 8)))
         return msgs
 
     # -- pass 1: sizes (addresses do not change any size) --------------------
@@ -245,7 +278,8 @@ def write_netcdf4(filename, dimensions, variables, attrs=None,
     for name in names:
         ds = datasets[name]
         ds.header_addr = pos
-        pos += _pad8(len(_object_header(dataset_messages(ds, gheap_addr))))
+        pos += _pad8(len(_object_header(dataset_messages(ds, gheap_addr,
+                                                         reserve=True))))
     for name in names:
         ds = datasets[name]
         if ds.allocate and ds.data.nbytes:
@@ -299,13 +333,32 @@ def write_netcdf4(filename, dimensions, variables, attrs=None,
         free = gheap_size - len(gh)
         gh += struct.pack('<HH4xQ', 0, 0, free)
         put(gheap_addr, gh + b'\x00' * (gheap_size - len(gh)))
+        deferred = [n for n in names if _is_deferred(datasets[n].data)]
         for name in names:
             ds = datasets[name]
-            put(ds.header_addr,
-                _object_header(dataset_messages(ds, gheap_addr)))
+            data = ds.data
+            if _is_deferred(data):
+                later = deferred[deferred.index(name) + 1:]
+                if later and hasattr(datasets[later[0]].data, 'prefetch'):
+                    datasets[later[0]].data.prefetch()
+                arr = np.asarray(data.load())
+                if tuple(arr.shape) != tuple(data.shape) or \
+                        arr.dtype.itemsize != np.dtype(data.dtype).itemsize:
+                    raise ValueError(
+                        f'{name}: produced {arr.dtype} {arr.shape}, '
+                        f'announced {data.dtype} {tuple(data.shape)}')
+                arr = np.ascontiguousarray(
+                    arr.astype(arr.dtype.newbyteorder('<'), copy=False))
+                if name in auto_fill and _parallel.any_nan(arr):
+                    nan_fill[name] = auto_fill[name]
+                data = arr
             if ds.data_addr is not None:
                 # the array's own memory goes to the file (no tobytes copy)
-                put(ds.data_addr, ds.data
-                    if ds.data.dtype.kind in 'iuf' and ds.data.size
-                    else ds.data.tobytes(), (nan_fill or {}).get(name))
+                put(ds.data_addr, data
+                    if data.dtype.kind in 'iuf' and data.size
+                    else data.tobytes(), nan_fill.get(name))
+            del data
+            # (after the data: a deferred variable's _FillValue is known now)
+            put(ds.header_addr,
+                _object_header(dataset_messages(ds, gheap_addr)))
         f.truncate(eof)

@@ -76,11 +76,45 @@ def _decode(data, attrs):
     return data, attrs, encoding
 
 
-def open_dataset(filename, mask_and_scale=True, variables=None):
+def _decoded_dtype(dtype, attrs):
+    """The dtype :func:`_decode` gives data of ``dtype`` with ``attrs``."""
+    dtype = np.dtype(dtype)
+    if dtype.kind not in 'iu':
+        return dtype
+    if any(k in attrs for k in ('_FillValue', 'missing_value',
+                                'scale_factor', 'add_offset')):
+        return np.dtype(np.float32 if dtype.itemsize <= 2 else np.float64)
+    return dtype
+
+
+def _lazy_variable(name, dims, shape, dtype, attrs, read, mask_and_scale):
+    """A DataArray whose values are read (and decoded) when asked for."""
+    if mask_and_scale:
+        # attrs / encoding as _decode leaves them, without touching the data
+        _, out_attrs, enc = _decode(np.zeros(0, dtype=dtype), attrs)
+        out_dtype = _decoded_dtype(dtype, attrs)
+    else:
+        out_attrs, enc, out_dtype = OrderedDict(attrs), {}, np.dtype(dtype)
+
+    def load():
+        data = read()
+        if mask_and_scale:
+            data = _decode(data, attrs)[0]
+        return data
+    da = xr_lite.DataArray(xr_lite.LazyValues(shape, out_dtype, load),
+                           dims=dims, name=name, attrs=out_attrs)
+    da.encoding = enc
+    return da, enc
+
+
+def open_dataset(filename, mask_and_scale=True, variables=None,
+                 lazy_bytes=None):
     """
     Read ``filename`` into a :class:`pyremap_amd.Dataset`.  ``variables``:
     read only these data variables (and the coordinate variables); the rest
-    of the file is not touched.
+    of the file is not touched.  ``lazy_bytes``: data variables of at least
+    that many bytes stay on disk until their values are asked for
+    (:class:`pyremap_amd.xr_lite.LazyValues`: every access reads again).
     """
     if not os.path.exists(filename):
         raise FileNotFoundError(filename)
@@ -90,8 +124,8 @@ def open_dataset(filename, mask_and_scale=True, variables=None):
     if variables is not None:
         variables = set(variables)
     if fmt == 'NETCDF4':
-        return _open_hdf5(filename, mask_and_scale, variables)
-    nc = netcdf3.read(filename, variables=variables)
+        return _open_hdf5(filename, mask_and_scale, variables, lazy_bytes)
+    nc = netcdf3.read(filename, variables=variables, defer_bytes=lazy_bytes)
     ds = xr_lite.Dataset(attrs=nc.attrs)
     ds.encoding = {
         'format': fmt,
@@ -100,6 +134,13 @@ def open_dataset(filename, mask_and_scale=True, variables=None):
         'dim_order': list(nc.dimensions),
     }
     for name, var in nc.variables.items():
+        if isinstance(var.data, netcdf3.Deferred):
+            da, enc = _lazy_variable(name, var.dims, var.data.shape,
+                                     var.data.dtype, var.attrs,
+                                     var.data.read, mask_and_scale)
+            ds[name] = da
+            ds.variables[name].encoding = enc
+            continue
         data, attrs, enc = (var.data, var.attrs, {})
         if mask_and_scale:
             data, attrs, enc = _decode(data, attrs)
@@ -113,7 +154,13 @@ def open_dataset(filename, mask_and_scale=True, variables=None):
     return ds
 
 
-def _open_hdf5(filename, mask_and_scale, variables=None):
+def _read_hdf5_variable(filename, name):
+    from pyremap_amd.io.netcdf4_lite import NetCDF4File
+    with NetCDF4File(filename) as nc:
+        return nc.variables[name].read()
+
+
+def _open_hdf5(filename, mask_and_scale, variables=None, lazy_bytes=None):
     """NetCDF-4 through this package's own HDF5 reader (no h5py/netCDF4)."""
     from pyremap_amd.io.netcdf4_lite import NetCDF4File
     with NetCDF4File(filename) as nc:
@@ -124,6 +171,22 @@ def _open_hdf5(filename, mask_and_scale, variables=None):
         for name, var in nc.variables.items():
             if variables is not None and name not in variables and \
                     tuple(var.dims) != (name,):
+                continue
+            try:
+                dt = np.dtype(var.dtype)
+            except TypeError:          # variable-length strings and the like
+                dt = None
+            if lazy_bytes is not None and tuple(var.dims) != (name,) and \
+                    dt is not None and dt.kind in 'fiu' and \
+                    int(np.prod(var.shape, dtype=np.int64)) * dt.itemsize \
+                    >= lazy_bytes:
+                da, enc = _lazy_variable(
+                    name, var.dims, var.shape, dt.newbyteorder('='),
+                    OrderedDict(var.attrs),
+                    lambda n=name: _read_hdf5_variable(filename, n),
+                    mask_and_scale)
+                ds[name] = da
+                ds.variables[name].encoding = enc
                 continue
             data = var.read()
             if isinstance(data, list):
@@ -166,9 +229,26 @@ def write_netcdf(ds, filename, format='NETCDF3_64BIT', fillvalues=None,
     out_vars = []
     for name in names:
         var = ds.variables[name]
-        data = np.asarray(var.values)
         attrs = OrderedDict((k, v) for k, v in var.attrs.items()
                             if k != '_FillValue')
+        if getattr(var, 'is_lazy', False) and var._data.dtype.kind == 'f':
+            # values produced when the writer reaches the variable: whether
+            # they hold NaNs -- hence whether the variable gets a _FillValue
+            # -- is found out THEN (the writers reserve the attribute's room
+            # in the header and write the header last)
+            lazy = var._data
+            key = f'{lazy.dtype.kind}{lazy.dtype.itemsize}'
+            auto = np.asarray(fillvalues[key]).astype(lazy.dtype) \
+                if lazy.dtype.kind == 'f' and key in fillvalues else None
+            for dim, size in zip(var.dims, lazy.shape):
+                if dim in unlimited_dims:
+                    dimensions.setdefault(dim, None)
+                else:
+                    dimensions.setdefault(dim, int(size))
+            out_vars.append(netcdf3.Variable(name, tuple(var.dims), lazy,
+                                             attrs, auto_fill=auto))
+            continue
+        data = np.asarray(var.values)
         nan_fill = None
         if data.dtype.kind == 'f' and _parallel.any_nan(data):
             key = f'{data.dtype.kind}{data.dtype.itemsize}'
@@ -227,7 +307,9 @@ def write_netcdf(ds, filename, format='NETCDF3_64BIT', fillvalues=None,
                       unlimited=[d for d, n in dimensions.items()
                                  if n is None],
                       nan_fill={v.name: v.nan_fill for v in out_vars
-                                if v.nan_fill is not None})
+                                if v.nan_fill is not None},
+                      auto_fill={v.name: v.auto_fill for v in out_vars
+                                 if v.auto_fill is not None})
         return
     netcdf3.write(filename, dimensions, out_vars, attrs=attrs,
                   version=version)

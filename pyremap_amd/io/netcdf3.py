@@ -51,7 +51,7 @@ class Variable:
     """A variable of a classic-format file."""
 
     def __init__(self, name, dims, data, attrs=None, is_record=False,
-                 nan_fill=None):
+                 nan_fill=None, auto_fill=None):
         self.name = name
         self.dims = tuple(dims)
         self.data = data
@@ -60,6 +60,11 @@ class Variable:
         #: when writing: the value stored in place of NaNs (the writer
         #: substitutes it chunk by chunk; ``data`` keeps its NaNs)
         self.nan_fill = nan_fill
+        #: when writing a variable whose ``data`` is produced on demand (an
+        #: object with ``shape``, ``dtype``, ``load()`` and optionally
+        #: ``prefetch()``): the fill value it gets -- as ``_FillValue`` and
+        #: in place of its NaNs -- IF its values turn out to hold NaNs
+        self.auto_fill = auto_fill
 
     @property
     def dtype(self):
@@ -140,12 +145,30 @@ class _Reader:
         return out
 
 
-def read(filename, variables=None):
+class Deferred:
+    """A variable's data not read yet: shape and dtype (native byte order)
+    are known from the header, :meth:`read` reads that variable alone."""
+
+    def __init__(self, filename, name, shape, dtype):
+        self.filename, self.name = filename, name
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * \
+            self.dtype.itemsize
+
+    def read(self):
+        return read(self.filename, variables={self.name}) \
+            .variables[self.name].data
+
+
+def read(filename, variables=None, defer_bytes=None):
     """
     Read a classic-format file into a :class:`NetCDF3File`: every variable,
     or -- ``variables`` given -- only those named plus the coordinate
     variables (a variable that is 1-D along the dimension of its own name);
-    the others are not touched on disk.
+    the others are not touched on disk.  With ``defer_bytes`` the data of
+    non-coordinate variables of at least that many bytes is left on disk:
+    their ``data`` is a :class:`Deferred`.
     """
     buf = np.memmap(filename, dtype=np.uint8, mode='r')
     if bytes(buf[:3]) != b'CDF' or buf[3] not in (1, 2, 5):
@@ -213,6 +236,14 @@ def read(filename, variables=None):
                 dims != [name]:
             continue
         dt = _TYPES[nc_type]
+        if defer_bytes is not None and dims != [name] and dt.kind != 'S':
+            shape = [nc.numrecs if nc.dimensions[d] is None
+                     else nc.dimensions[d] for d in dims]
+            later = Deferred(filename, name, shape, dt.newbyteorder('='))
+            if later.nbytes >= defer_bytes:
+                nc.variables[name] = Variable(name, dims, later, attrs,
+                                              is_rec(dimids))
+                continue
         if is_rec(dimids):
             inner = [nc.dimensions[d] for d in dims[1:]]
             count = int(np.prod(inner, dtype=np.int64))
@@ -334,6 +365,10 @@ def _write_big_endian(f, data, nan_fill=None):
                               nan_fill=nan_fill)
 
 
+def _is_deferred(data):
+    return hasattr(data, 'load') and not isinstance(data, np.ndarray)
+
+
 def write(filename, dimensions, variables, attrs=None, version=2):
     """
     Write a classic-format file.
@@ -341,6 +376,17 @@ def write(filename, dimensions, variables, attrs=None, version=2):
     dimensions : dict name -> length (``None`` for the record dimension)
     variables  : iterable of :class:`Variable`; a variable whose first
                  dimension is the record dimension becomes a record variable
+
+    A variable whose ``data`` is produced on demand (``load()``, see
+    :attr:`Variable.auto_fill`) is loaded when the writer reaches it, written
+    and dropped, the next one being started meanwhile (``prefetch()``): a
+    file of many large variables streams through with one or two of them in
+    memory.  Whether such a variable needs a ``_FillValue`` is known only
+    then, so the header is laid out WITH that attribute for each of them
+    (its largest form), the data goes to the offsets that layout gives, and
+    the header is written last, in its final form; it may end before the
+    first variable begins -- the classic format addresses data by the
+    explicit ``begin`` offsets, free space behind the header is legal.
     """
     dimensions = OrderedDict(dimensions)
     dim_ids = {name: i for i, name in enumerate(dimensions)}
@@ -349,12 +395,16 @@ def write(filename, dimensions, variables, attrs=None, version=2):
     prepared = []
     numrecs = 0
     for var in variables:
-        data = np.asarray(var.data)
-        if data.dtype.kind == 'U':
-            data = np.char.encode(data, 'utf-8')
-        if data.dtype.kind == 'S' and data.dtype.itemsize != 1:
-            raise TypeError(f'{var.name}: store strings as S1 char arrays')
-        data = _storable(data, version)
+        if _is_deferred(var.data):
+            data = var.data          # shape / dtype only, for now
+        else:
+            data = np.asarray(var.data)
+            if data.dtype.kind == 'U':
+                data = np.char.encode(data, 'utf-8')
+            if data.dtype.kind == 'S' and data.dtype.itemsize != 1:
+                raise TypeError(
+                    f'{var.name}: store strings as S1 char arrays')
+            data = _storable(data, version)
         rec = len(var.dims) > 0 and var.dims[0] == rec_dim
         if rec:
             numrecs = max(numrecs, data.shape[0])
@@ -369,7 +419,7 @@ def write(filename, dimensions, variables, attrs=None, version=2):
 
     single_rec = len(rec_list) == 1
 
-    def build(begins):
+    def build(begins, reserve):
         w = _Writer(version)
         w.parts.append(b'CDF' + bytes([version]))
         w.nonneg(numrecs)
@@ -391,7 +441,12 @@ def write(filename, dimensions, variables, attrs=None, version=2):
                 w.nonneg(len(var.dims))
                 for d in var.dims:
                     w.nonneg(dim_ids[d])
-                w.attrs(var.attrs)
+                vattrs = var.attrs
+                if reserve and _is_deferred(data) and \
+                        var.auto_fill is not None:
+                    vattrs = OrderedDict(var.attrs)
+                    vattrs['_FillValue'] = var.auto_fill
+                w.attrs(vattrs)
                 w.u32(_code(data.dtype, version))
                 w.nonneg(_pad4(vsize(data, rec)))
                 w.offset(begin)
@@ -400,8 +455,9 @@ def write(filename, dimensions, variables, attrs=None, version=2):
             w.nonneg(0)
         return w
 
-    header = build([0] * len(prepared))
-    pos = header.size()
+    header = build([0] * len(prepared), True)
+    reserved = header.size()
+    pos = reserved
     begins = [0] * len(prepared)
     for idx, (var, data, rec) in enumerate(prepared):
         if not rec:
@@ -414,23 +470,53 @@ def write(filename, dimensions, variables, attrs=None, version=2):
             begins[idx] = rec_start + recsize
             recsize += vsize(data, rec) if single_rec else \
                 _pad4(vsize(data, rec))
-    header = build(begins)
-    assert header.size() == begins[0] if prepared and not prepared[0][2] \
-        else True
+    eof = rec_start + recsize * numrecs if rec_list else pos
+
+    def materialise(idx):
+        """Load a deferred variable; decide its _FillValue; start the next."""
+        var, data, rec = prepared[idx]
+        for later in range(idx + 1, len(prepared)):
+            nxt = prepared[later][1]
+            if _is_deferred(nxt):
+                if hasattr(nxt, 'prefetch'):
+                    nxt.prefetch()
+                break
+        if not _is_deferred(data):
+            return data
+        arr = np.asarray(data.load())
+        if tuple(arr.shape) != tuple(data.shape) or \
+                arr.dtype.itemsize != data.dtype.itemsize:
+            raise ValueError(
+                f'{var.name}: produced {arr.dtype} {arr.shape}, announced '
+                f'{data.dtype} {tuple(data.shape)}')
+        if var.auto_fill is not None and _parallel.any_nan(arr):
+            var.nan_fill = var.auto_fill
+            var.attrs['_FillValue'] = var.auto_fill
+        return arr
 
     with open(filename, 'wb') as f:
-        f.write(b''.join(header.parts))
-        for var, data, rec in prepared:
+        f.truncate(eof)
+        # non-record variables, in order
+        for idx, (var, data, rec) in enumerate(prepared):
             if rec:
                 continue
-            n = _write_big_endian(f, data, var.nan_fill)
+            arr = materialise(idx)
+            f.seek(begins[idx])
+            n = _write_big_endian(f, arr, var.nan_fill)
             f.write(b'\x00' * (_pad4(n) - n))
-        for r in range(numrecs if rec_list else 0):
-            for var, data, _ in rec_list:
-                if r < data.shape[0]:
-                    n = _write_big_endian(f, data[r:r + 1], var.nan_fill)
-                else:
-                    n = vsize(data, True) if data.shape[0] else 0
-                    f.write(b'\x00' * n)
-                if not single_rec:
-                    f.write(b'\x00' * (_pad4(n) - n))
+            del arr
+        # record variables: records interleave the variables, so a
+        # variable's records go to their strided places one by one
+        for idx, (var, data, rec) in enumerate(prepared):
+            if not rec:
+                continue
+            arr = materialise(idx)
+            for r in range(arr.shape[0]):
+                f.seek(begins[idx] + r * recsize)
+                _write_big_endian(f, arr[r:r + 1], var.nan_fill)
+            del arr
+        header = build(begins, False)
+        if header.size() > reserved:
+            raise RuntimeError('NetCDF header outgrew its reserved space')
+        f.seek(0)
+        f.write(b''.join(header.parts))

@@ -22,12 +22,22 @@ from pyremap_amd.descriptor import (
     MpasMeshDescriptor,
     PointCollectionDescriptor,
 )
+from pyremap_amd.io import _parallel
 from pyremap_amd.io.netcdf import file_format, open_dataset, write_netcdf
 from pyremap_amd.io.netcdf3 import FORMATS
 from pyremap_amd.remapper.remap_numpy import _remap_numpy
+from pyremap_amd.xr_lite import LazyValues
 
 #: MPAS writes this where a field is undefined (below the sea floor, ...)
 MPAS_FILL = -9.99999979021476795361e+33
+
+#: Variables of at least this many bytes are STREAMED: read, remapped and
+#: written one at a time (the next one travelling meanwhile), as NCO does
+#: variable by variable (``pyremap/remapper/ncremap.py:117-145``) -- host
+#: memory holds two of them at most, whatever the file.  Smaller ones are
+#: handled together (their transfers overlap).  Environment:
+#: PYREMAP_AMD_STREAM_BYTES.
+STREAM_BYTES = int(os.environ.get('PYREMAP_AMD_STREAM_BYTES', 64 << 20))
 
 
 def _validate_inputs(remapper, out_filename, overwrite):
@@ -47,7 +57,8 @@ def _remap_file(remapper, in_filename, out_filename, variable_list,
         return
     # (with a variable list only those variables -- and the coordinates --
     # are read: the rest of the file is not touched)
-    ds = open_dataset(in_filename, variables=variable_list)
+    ds = open_dataset(in_filename, variables=variable_list,
+                      lazy_bytes=STREAM_BYTES)
     if variable_list is not None:
         missing = [v for v in variable_list if v not in ds]
         if missing:
@@ -60,14 +71,30 @@ def _remap_file(remapper, in_filename, out_filename, variable_list,
         # of _FillValue
         for name in list(ds.data_vars):
             var = ds.variables[name]
-            if var.values.dtype.kind == 'f':
-                fill = np.asarray(MPAS_FILL).astype(var.values.dtype)
-                hit = var.values == fill
-                if hit.any():
-                    data = np.array(var.values, copy=True)
-                    data[hit] = np.nan
-                    ds[name] = type(var)(data, dims=var.dims,
-                                         attrs=var.attrs)
+            if var.dtype.kind != 'f':
+                continue
+            fill = np.asarray(MPAS_FILL).astype(var.dtype)
+            if var.is_lazy:
+                # still on disk: the substitution joins the read
+                lazy = var._data
+
+                def load(lazy=lazy, fill=fill):
+                    data = lazy.load()
+                    if not (data.flags['WRITEABLE'] and
+                            data.flags['C_CONTIGUOUS']):
+                        data = np.array(data, copy=True, order='C')
+                    _parallel.replace_value(data, fill, np.nan)
+                    return data
+                ds[name] = type(var)(
+                    LazyValues(lazy.shape, lazy.dtype, load),
+                    dims=var.dims, attrs=var.attrs)
+                continue
+            hit = var.values == fill
+            if hit.any():
+                data = np.array(var.values, copy=True)
+                data[hit] = np.nan
+                ds[name] = type(var)(data, dims=var.dims,
+                                     attrs=var.attrs)
     encoding = getattr(ds, 'encoding', {})
     ds_out = _remap_numpy(remapper, ds, renormalize)
     fmt = encoding.get('format') or file_format(in_filename)

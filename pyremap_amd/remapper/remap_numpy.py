@@ -91,9 +91,16 @@ def _remap_numpy(remapper, ds, renormalization_threshold):
         partial = [name for name in ds.data_vars
                    if _check_drop(remapper, ds[name])]
         kept = ds.drop_vars(partial)
-        result = kept.map(
-            _LookAhead(remapper, kept, list(kept.data_vars),
-                       renormalization_threshold), keep_attrs=True)
+        if any(getattr(kept.variables[name], 'is_lazy', False)
+               for name in kept.data_vars):
+            # variables still on disk (ncremap's streaming path): the result
+            # is lazy too -- each variable is read, remapped and handed to the
+            # writer in turn, never all of them at once
+            result = _lazy_dataset(remapper, kept, renormalization_threshold)
+        else:
+            result = kept.map(
+                _LookAhead(remapper, kept, list(kept.data_vars),
+                           renormalization_threshold), keep_attrs=True)
     else:
         raise TypeError('ds not an xarray Dataset or DataArray.')
 
@@ -185,17 +192,17 @@ def _remap_data_array(da, remapper, renormalization_threshold):
     return _start_data_array(da, remapper, renormalization_threshold)()
 
 
-def _start_data_array(da, remapper, renormalization_threshold):
+def _plan_data_array(da, remapper):
     """
-    Enqueue the remap of one variable -- upload, NaN scan, launch, download,
-    none of which waits for the host -- and return the function that waits
-    for the data and assembles the result.
+    The bookkeeping of reference ``_remap_data_array`` :150-199 without
+    touching the values: ``(remap_axes, dims, coords)`` of the result, or
+    ``None`` for a variable without source dims.
     """
     src_dims = remapper.src_descriptor.dims
     remap_axes = [axis for axis, dim in enumerate(da.dims)
                   if dim in src_dims]
     if not remap_axes:
-        return lambda: da  # nothing to remap
+        return None  # nothing to remap
     if len(remap_axes) != len(src_dims):
         raise ValueError(
             'Data array with some (but not all) required source dims cannot '
@@ -211,6 +218,60 @@ def _start_data_array(da, remapper, renormalization_threshold):
         if not any(dim in coord.dims for dim in src_dims):
             coords[name] = {'dims': coord.dims, 'data': coord.values}
     coords.update(remapper.dst_descriptor.coords)
+    return remap_axes, dims, coords
+
+
+def _lazy_dataset(remapper, ds, renormalization_threshold):
+    """
+    ``ds.map(_remap_data_array, keep_attrs=True)`` for a Dataset whose
+    variables are (partly) still on disk: same variables, dims, coordinates
+    and attributes, but the values of every remapped variable are a
+    :class:`~pyremap_amd.xr_lite.LazyValues` -- read, remapped and
+    downloaded when the writer asks for them, and started one variable ahead
+    by its ``prefetch`` (upload, launch and download are enqueued without
+    waiting, so variable i + 1 travels while variable i is being written).
+    """
+    results = {}
+    for name in ds.data_vars:
+        da = ds[name]
+        plan = _plan_data_array(da, remapper)
+        if plan is None:
+            out = da
+        else:
+            remap_axes, dims, coords = plan
+            first = remap_axes[0]
+            shape = list(da.shape[:first]) + \
+                [int(s) for s in remapper._ds_map.dst_grid_dims] + \
+                [size for axis, size in enumerate(da.shape)
+                 if axis > first and axis not in remap_axes]
+
+            def start(da=da):
+                finish = _start_data_array(da, remapper,
+                                           renormalization_threshold)
+                return lambda: finish().values
+            out = xr_lite.DataArray(
+                xr_lite.LazyValues(shape, np.float64,
+                                   load=lambda start=start: start()(),
+                                   prefetch=start),
+                coords={k: xr_lite.DataArray(v['data'], dims=v['dims'],
+                                             name=k, attrs=v.get('attrs'))
+                        for k, v in coords.items()},
+                dims=dims, name=name)
+        out.attrs = type(out.attrs)(ds.variables[name].attrs)  # keep_attrs
+        results[name] = out
+    return xr_lite.Dataset(results, attrs=ds.attrs)
+
+
+def _start_data_array(da, remapper, renormalization_threshold):
+    """
+    Enqueue the remap of one variable -- upload, NaN scan, launch, download,
+    none of which waits for the host -- and return the function that waits
+    for the data and assembles the result.
+    """
+    plan = _plan_data_array(da, remapper)
+    if plan is None:
+        return lambda: da  # nothing to remap
+    remap_axes, dims, coords = plan
 
     if getattr(remapper, '_process_group', None) is not None:
         data = _collective_array(remapper, da.values, remap_axes,

@@ -22,8 +22,60 @@ from collections import OrderedDict
 import numpy as np
 
 
+class LazyValues:
+    """
+    The values of a variable that are PRODUCED ON DEMAND and not retained:
+    a variable of a file that has not been read yet, or the remapped form of
+    one that has not been computed yet.  ``shape`` / ``dtype`` are known up
+    front; :meth:`load` reads (computes) and returns the array -- every call
+    does so again, so consumers take it once.  :meth:`prefetch` (optional)
+    starts the work early without waiting for it.  This is what lets
+    ``Remapper.ncremap`` stream a file variable by variable -- as NCO does,
+    ``pyremap/remapper/ncremap.py:117-145`` -- with bounded host memory.
+    """
+
+    def __init__(self, shape, dtype, load, prefetch=None):
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self._load = load
+        self._prefetch = prefetch
+        self._started = None
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape, dtype=np.int64))
+
+    @property
+    def nbytes(self):
+        return self.size * self.dtype.itemsize
+
+    def prefetch(self):
+        """Start producing the values (no-op when there is nothing to do
+        ahead of time); the next :meth:`load` picks the work up."""
+        if self._prefetch is not None and self._started is None:
+            self._started = self._prefetch()
+
+    def load(self):
+        if self._started is not None:
+            finish, self._started = self._started, None
+            return np.asarray(finish())
+        return np.asarray(self._load())
+
+    def copy(self):
+        return self
+
+    def __array__(self, dtype=None, copy=None):
+        return np.asarray(self.load(), dtype=dtype)
+
+
 def _as_data(data):
     """xarray's ``as_compatible_data``: a masked array becomes NaN-filled."""
+    if isinstance(data, LazyValues):
+        return data
     if isinstance(data, np.ma.MaskedArray):
         mask = np.ma.getmaskarray(data)
         if mask.any():
@@ -77,11 +129,18 @@ class DataArray:
     # -- array-like members ------------------------------------------------
     @property
     def values(self):
+        if isinstance(self._data, LazyValues):
+            return self._data.load()
         return self._data
 
     @property
     def data(self):
-        return self._data
+        return self.values
+
+    @property
+    def is_lazy(self):
+        """Are the values produced on demand (:class:`LazyValues`)?"""
+        return isinstance(self._data, LazyValues)
 
     @property
     def shape(self):
@@ -122,7 +181,7 @@ class DataArray:
                        for k, v in self.coords.items()},
             'attrs': dict(self.attrs),
             'dims': self.dims,
-            'data': self._data,
+            'data': self.values,
             'name': self.name,
         }
 
@@ -286,7 +345,8 @@ class Dataset:
                     coords[cname] = cvar
         if name in self._coord_names and var.dims == (name,):
             coords[name] = var
-        da = DataArray(var.values, coords=coords, dims=var.dims, name=name)
+        # (var._data, not var.values: a lazy variable stays lazy)
+        da = DataArray(var._data, coords=coords, dims=var.dims, name=name)
         # as in xarray, the variable's attrs / encoding are shared, so
         # ``ds['lat'].attrs['units'] = ...`` sticks
         da.attrs = var.attrs

@@ -540,3 +540,132 @@ def test_examples_run(tmp_path, monkeypatch):
     assert out2['temperature'].shape == (3, 18, 36, 4)
     assert 'other' not in out2.variables
     assert np.nanmax(np.abs(out2['temperature'].values)) < 10.0   # no fills
+
+
+# ---------------------------------------------------------------------------
+# streaming: variable by variable with bounded host memory
+# ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize('fmt', ['NETCDF3_64BIT_DATA', 'NETCDF4'])
+def test_ncremap_streamed_equals_eager(setup, fmt, monkeypatch):
+    """
+    With every variable above the streaming threshold the file path reads,
+    remaps and writes one variable at a time (NCO's way,
+    ncremap.py:117-145); the output is the one the all-at-once path writes:
+    same variables, dims, attributes (`_FillValue` where NaNs turned up) and
+    values, bit for bit.
+    """
+    from pyremap_amd import Remapper
+    from pyremap_amd.io.netcdf import open_dataset
+    from pyremap_amd.remapper import remap_file
+    tmp = setup['tmp']
+    src_path = str(tmp / f'stream_in_{fmt}.nc')
+    _input_dataset(setup, fmt, src_path)
+    outs = {}
+    for tag, threshold in (('eager', 1 << 40), ('streamed', 1)):
+        monkeypatch.setattr(remap_file, 'STREAM_BYTES', threshold)
+        r = Remapper(map_filename=setup['map_path'],
+                     src_descriptor=setup['src'],
+                     dst_descriptor=setup['dst'])
+        out_path = str(tmp / f'stream_out_{tag}_{fmt}.nc')
+        r.ncremap(src_path, out_path, renormalize=0.01, overwrite=True)
+        outs[tag] = open_dataset(out_path, mask_and_scale=False)
+    a, b = outs['eager'], outs['streamed']
+    assert list(a.data_vars) == list(b.data_vars)
+    assert sorted(a.coords) == sorted(b.coords)
+    assert {k: str(v) for k, v in a.attrs.items()} == \
+        {k: str(v) for k, v in b.attrs.items()}
+    for name in a.variables:
+        va, vb = a.variables[name], b.variables[name]
+        assert va.dims == vb.dims and va.dtype == vb.dtype, name
+        assert sorted(va.attrs) == sorted(vb.attrs), name
+        assert va.values.tobytes() == vb.values.tobytes(), name
+    assert '_FillValue' in b.variables['temperature'].attrs
+    assert '_FillValue' not in b.variables['daysSinceStart'].attrs
+
+
+_STREAM_SCRIPT = r'''
+import os, resource, sys, time
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from pyremap_amd import (DataArray, Dataset, LatLonGridDescriptor,
+                         MpasCellMeshDescriptor, Remapper, synthetic)
+from pyremap_amd.io.netcdf import write_netcdf
+tmp, mode = sys.argv[2], sys.argv[3]
+n, nlat, nlon, T, L = 60000, 200, 300, 8, 24
+map_path = os.path.join(tmp, 'map.nc')
+src_path = os.path.join(tmp, 'big_in.nc')
+rng = np.random.default_rng(1)
+if not os.path.exists(src_path):
+    synthetic.conservative_map(n, (nlat, nlon), 2, 6, seed=3,
+                               locality='mesh').save(map_path)
+    ds = Dataset()
+    for v in range(4):
+        x = rng.standard_normal((T, n, L))
+        if v % 2:
+            x[:, rng.random(n) < 0.2, L // 2:] = np.nan
+        ds[f'var{v}'] = DataArray(x, dims=('Time', 'nCells', 'nVertLevels'))
+    write_netcdf(ds, src_path, format='NETCDF3_64BIT_DATA',
+                 unlimited_dims=['Time'])
+    del ds, x
+src = MpasCellMeshDescriptor(mesh_name='toy', lat=rng.random(n),
+                             lon=rng.random(n))
+dst = LatLonGridDescriptor.create(np.linspace(-90, 90, nlat + 1),
+                                  np.linspace(-180, 180, nlon + 1))
+r = Remapper(map_filename=map_path, src_descriptor=src, dst_descriptor=dst)
+r.load_mapping()
+r.remap_array(np.zeros((n, 40)), [0], 0.1)        # runtime + kernels loaded
+base = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+t0 = time.perf_counter()
+r.ncremap(src_path, os.path.join(tmp, f'big_out_{mode}.nc'), renormalize=0.05,
+          overwrite=True)
+dt = time.perf_counter() - t0
+peak = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+print('RESULT', mode, (peak - base) * 1024, dt)
+'''
+
+
+def test_ncremap_streams_with_bounded_memory(tmp_path):
+    """
+    A file of four 92 MB variables (output 4 x 92 MB): the all-at-once path
+    holds every input and every result until the write; the streaming path
+    holds about two variables.  Measured as the growth of the process's peak
+    RSS across the call, in fresh processes; both write the same bytes.
+    """
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'stream_probe.py'
+    script.write_text(_STREAM_SCRIPT)
+    grown, secs = {}, {}
+    for mode, threshold in (('eager', str(1 << 40)), ('streamed', '1')):
+        env = dict(os.environ, PYREMAP_AMD_STREAM_BYTES=threshold)
+        proc = subprocess.run(
+            [sys.executable, str(script), repo, str(tmp_path), mode],
+            capture_output=True, text=True, env=env, timeout=900)
+        assert proc.returncode == 0, proc.stderr[-3000:]
+        line = [ln for ln in proc.stdout.splitlines()
+                if ln.startswith('RESULT')][-1].split()
+        grown[mode], secs[mode] = int(line[2]), float(line[3])
+    one_in = 8 * 60000 * 24 * 8
+    one_out = 8 * 200 * 300 * 24 * 8
+    # all at once: four inputs + four results (+ their NaN-filled copies)
+    assert grown['eager'] > 3 * (one_in + one_out)
+    # streamed: two variables in flight, whatever the file holds
+    assert grown['streamed'] < 2.6 * (one_in + one_out), grown
+    assert grown['streamed'] < 0.5 * grown['eager'], grown
+    assert secs['streamed'] < 1.5 * secs['eager'] + 0.2, secs
+    a = open(tmp_path / 'big_out_eager.nc', 'rb').read()
+    b = open(tmp_path / 'big_out_streamed.nc', 'rb').read()
+    # same data bytes; the streamed header may be followed by free space
+    from pyremap_amd.io.netcdf import open_dataset
+    da = open_dataset(str(tmp_path / 'big_out_eager.nc'),
+                      mask_and_scale=False)
+    db = open_dataset(str(tmp_path / 'big_out_streamed.nc'),
+                      mask_and_scale=False)
+    assert abs(len(a) - len(b)) < 4096
+    for name in da.variables:
+        assert da.variables[name].values.tobytes() == \
+            db.variables[name].values.tobytes(), name
+        assert sorted(da.variables[name].attrs) == \
+            sorted(db.variables[name].attrs), name

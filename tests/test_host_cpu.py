@@ -698,3 +698,102 @@ def test_nan_decisions_taken_on_the_host():
     z[1, ::3, 5:] = np.nan                      # a sea floor: the sample sees it
     assert host_path._sampled_nan(z, samples=256)
     assert not _parallel.any_nan(np.arange(10))  # integers hold no NaN
+
+
+# ---------------------------------------------------------------------------
+# streaming: variables produced on demand (ncremap's bounded-memory path)
+# ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize('fmt', ['NETCDF3_CLASSIC', 'NETCDF3_64BIT',
+                                 'NETCDF3_64BIT_DATA', 'NETCDF4'])
+@pytest.mark.parametrize('unlimited', [[], ['Time']])
+def test_writers_stream_lazy_variables(tmp_path, fmt, unlimited):
+    """
+    A Dataset whose big variables are `LazyValues` is written variable by
+    variable -- each loaded when the writer reaches it, the next one
+    prefetched, none retained -- and reads back exactly as the eager write
+    of the same data does, `_FillValue` only where NaNs turned up
+    (utility.py:38-51), in every format, with and without a record
+    dimension.
+    """
+    from pyremap_amd import DataArray, Dataset
+    from pyremap_amd.io.netcdf import open_dataset, write_netcdf
+    from pyremap_amd.xr_lite import LazyValues
+    rng = np.random.default_rng(3)
+    arrays = {
+        'a': rng.standard_normal((3, 40, 7)),                 # no NaN
+        'b': np.where(rng.random((3, 40, 7)) < 0.2, np.nan,
+                      rng.standard_normal((3, 40, 7))),        # NaNs
+        'c': rng.standard_normal((40, 5)).astype(np.float32),
+        'd': np.where(rng.random((3, 40)) < 0.5, np.nan, 1.0)
+        .astype(np.float32),
+    }
+    dims = {'a': ('Time', 'n', 'z'), 'b': ('Time', 'n', 'z'),
+            'c': ('n', 'k'), 'd': ('Time', 'n')}
+    log = []
+
+    def make(lazy):
+        ds = Dataset(attrs={'title': 'stream'})
+        ds['small'] = DataArray(np.arange(7.0), dims=('z',),
+                                attrs={'units': 'm'})
+        for name, arr in arrays.items():
+            if lazy:
+                def load(name=name):
+                    log.append(('load', name))
+                    return arrays[name].copy()
+
+                def prefetch(name=name):
+                    log.append(('prefetch', name))
+                    return lambda: arrays[name].copy()
+                data = LazyValues(arr.shape, arr.dtype, load,
+                                  prefetch if name in 'bd' else None)
+            else:
+                data = arr
+            ds[name] = DataArray(data, dims=dims[name],
+                                 attrs={'long_name': name})
+        ds['ints'] = DataArray(np.arange(40, dtype=np.int32), dims=('n',))
+        return ds
+
+    eager, lazy = str(tmp_path / 'eager.nc'), str(tmp_path / 'lazy.nc')
+    write_netcdf(make(False), eager, format=fmt, unlimited_dims=unlimited)
+    write_netcdf(make(True), lazy, format=fmt, unlimited_dims=unlimited)
+    # every lazy variable was produced exactly once; prefetches came first
+    produced = [n for kind, n in log if kind == 'load'] + \
+        [n for kind, n in log if kind == 'prefetch']
+    assert sorted(produced) == ['a', 'b', 'c', 'd']
+    for raw in (False, True):
+        a = open_dataset(eager, mask_and_scale=not raw)
+        b = open_dataset(lazy, mask_and_scale=not raw)
+        assert list(a.data_vars) == list(b.data_vars)
+        assert dict(a.attrs) == dict(b.attrs)
+        for name in a.variables:
+            va, vb = a.variables[name], b.variables[name]
+            assert va.dims == vb.dims and va.dtype == vb.dtype
+            assert np.array_equal(va.values, vb.values, equal_nan=True), name
+            assert sorted(va.attrs) == sorted(vb.attrs), name
+    raw = open_dataset(lazy, mask_and_scale=False)
+    assert '_FillValue' in raw.variables['b'].attrs
+    assert '_FillValue' in raw.variables['d'].attrs
+    assert '_FillValue' not in raw.variables['a'].attrs
+    assert '_FillValue' not in raw.variables['c'].attrs
+    # and the lazy file streams back in: big variables stay on disk
+    again = open_dataset(lazy, lazy_bytes=1000)
+    assert again.variables['a'].is_lazy and again.variables['b'].is_lazy
+    assert not again.variables['small'].is_lazy
+    assert again.variables['a'].shape == (3, 40, 7)
+    assert np.array_equal(again.variables['b'].values, arrays['b'],
+                          equal_nan=True)
+    assert np.array_equal(again['b'].values, arrays['b'], equal_nan=True)
+
+
+def test_lazy_values_announced_shape_is_checked(tmp_path):
+    from pyremap_amd import DataArray, Dataset
+    from pyremap_amd.io.netcdf import write_netcdf
+    from pyremap_amd.xr_lite import LazyValues
+    ds = Dataset()
+    ds['x'] = DataArray(LazyValues((4, 3), np.float64,
+                                   lambda: np.zeros((4, 2))),
+                        dims=('a', 'b'))
+    for fmt in ('NETCDF3_64BIT', 'NETCDF4'):
+        with pytest.raises(ValueError, match='announced'):
+            write_netcdf(ds, str(tmp_path / f'bad_{fmt}.nc'), format=fmt)
