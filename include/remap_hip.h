@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define REMAP_ABI_VERSION 19
+#define REMAP_ABI_VERSION 20
 
 enum {
     REMAP_OK = 0,
@@ -472,6 +472,20 @@ int remap_plan_create(int64_t n_b, int64_t n_a, int64_t n_s,
                       int32_t index_base, const double *frac_b,
                       int32_t host_input, const int64_t *dst_grid_dims,
                       int32_t n_dims, void *stream, remap_plan **plan_out);
+/*
+ * Optional, once per plan, before fields whose contiguous run behind the
+ * source axes is short and that come in several batches -- (Time, nCells),
+ * MPAS's 2-D time series, the reference's most common input
+ * (tests/test_interpolate.py:57-59; k_inner < 8 and n_batch > 1): builds the
+ * patch plan of the LDS-staged lanes-across-rows kernel (16 x 16 tiles of the
+ * destination grid, halved until no patch references more than 512 distinct
+ * source cells), which remap_plan_apply then uses for such fields.  Without
+ * it they take the unstaged lanes-across-rows kernel (2.5 x slower on
+ * EC30to60 -> 0.5 degree at Time = 120).  Allocates device memory
+ * (remap_plan_apply never does) and synchronises `stream`; a second call
+ * does nothing.
+ */
+int remap_plan_prepare_short_runs(remap_plan *plan, void *stream);
 void remap_plan_destroy(remap_plan *plan);
 int remap_plan_query(const remap_plan *plan, remap_plan_info *info_out);
 int remap_plan_apply(const remap_plan *plan, const remap_field *field,

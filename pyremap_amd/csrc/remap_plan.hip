@@ -32,6 +32,17 @@ struct remap_plan {
     void *arena = nullptr;      // the schedule's arrays
     size_t device_bytes = 0;
     remap_schedule sched;
+    // destination grid (remap_plan_create) and, once
+    // remap_plan_prepare_short_runs has run, the patch plan of the
+    // lanes-across-rows kernel that serves (Time, nCells)-like fields
+    int64_t grid_dims[2] = {0, 0};
+    int32_t n_dims = 0;
+    void *cell_arena = nullptr;
+    int32_t *cell_order = nullptr, *cell_ptr = nullptr, *cell_ucol = nullptr,
+            *cell_rowptr = nullptr, *cell_lidx = nullptr;
+    double *cell_val = nullptr;
+    int32_t cell_rows = 0, cell_umax = 0, cell_emax = 0;
+    int64_t cell_patches = 0;
 };
 
 namespace remap {
@@ -131,6 +142,9 @@ int create(int64_t n_b, int64_t n_a, int64_t n_s, const int32_t *row,
     REMAP_HIP_CHECK(hipGetDevice(&plan->device));
     plan->n_a = n_a;
     plan->n_b = n_b;
+    plan->n_dims = n_dims;
+    for (int d = 0; d < n_dims; ++d)
+        plan->grid_dims[d] = grid_dims[d];
 
     // 1. inputs on the device
     const int32_t *d_row = nullptr, *d_col = nullptr;
@@ -270,10 +284,105 @@ int create(int64_t n_b, int64_t n_a, int64_t n_s, const int32_t *row,
     return REMAP_OK;
 }
 
+// distinct source cells a patch of the lanes-across-rows kernel may stage
+// (8 fields x 8 bytes each stay under 32 KB of LDS)
+constexpr int64_t kCellUmax = 512;
+
+size_t align256(size_t n) { return (n + 255) / 256 * 256; }
+
+int prepare_short_runs(remap_plan *plan, hipStream_t stream)
+{
+    if (plan->cell_arena || plan->nnz == 0 || plan->n_b == 0)
+        return REMAP_OK;
+    const int64_t n_b = plan->n_b, nnz = plan->nnz;
+    Owned own;
+    size_t ws_bytes = 0;
+    int rc = remap_patches_workspace(n_b, nnz, &ws_bytes);
+    if (rc != REMAP_OK)
+        return rc;
+    const size_t o_order = 0;
+    const size_t o_ptr = o_order + align256(static_cast<size_t>(n_b) * 4);
+    const size_t o_ucol = o_ptr + align256(static_cast<size_t>(n_b + 1) * 4);
+    const size_t o_rowptr = o_ucol + align256(static_cast<size_t>(nnz) * 4);
+    const size_t o_lidx =
+        o_rowptr + align256(static_cast<size_t>(n_b + 1) * 4);
+    const size_t o_val = o_lidx + align256(static_cast<size_t>(nnz) * 4);
+    const size_t total = o_val + align256(static_cast<size_t>(nnz) * 8);
+    void *arena = nullptr, *ws = nullptr, *stats = nullptr;
+    if ((rc = own.alloc(&arena, total)) != REMAP_OK ||
+        (rc = own.alloc(&ws, ws_bytes)) != REMAP_OK ||
+        (rc = own.alloc(&stats, 24)) != REMAP_OK)
+        return rc;
+    char *base = static_cast<char *>(arena);
+    remap_csr A;
+    A.n_rows = n_b;
+    A.n_cols = plan->n_a;
+    A.nnz = nnz;
+    A.rowptr = plan->rowptr;
+    A.col = plan->col;
+    A.val = plan->val;
+    A.max_row_nnz = plan->max_row_nnz;
+    A.csr_pad = kCsrPad;
+    const bool two_d = plan->n_dims == 2;
+    int32_t ty = two_d ? 16 : 1, tx = two_d ? 16 : 256;
+    int64_t h[3] = {0, 0, 0};
+    for (;;) {
+        rc = remap_patches_build(
+            &A, two_d ? plan->grid_dims : nullptr, 0, ty, tx,
+            two_d ? reinterpret_cast<int32_t *>(base + o_order) : nullptr,
+            reinterpret_cast<int32_t *>(base + o_ptr),
+            reinterpret_cast<int32_t *>(base + o_ucol),
+            reinterpret_cast<int32_t *>(base + o_rowptr),
+            reinterpret_cast<int32_t *>(base + o_lidx),
+            reinterpret_cast<double *>(base + o_val),
+            static_cast<int64_t *>(stats), ws, ws_bytes, stream);
+        if (rc != REMAP_OK)
+            return rc;
+        REMAP_HIP_CHECK(hipMemcpyAsync(h, stats, 24, hipMemcpyDeviceToHost,
+                                       stream));
+        REMAP_HIP_CHECK(hipStreamSynchronize(stream));
+        if (h[1] <= kCellUmax || ty * tx <= 16)
+            break;
+        if (tx >= ty && tx > 1)
+            tx /= 2;
+        else
+            ty /= 2;
+    }
+    plan->cell_arena = arena;
+    own.release(arena);
+    plan->cell_order =
+        two_d ? reinterpret_cast<int32_t *>(base + o_order) : nullptr;
+    plan->cell_ptr = reinterpret_cast<int32_t *>(base + o_ptr);
+    plan->cell_ucol = reinterpret_cast<int32_t *>(base + o_ucol);
+    plan->cell_rowptr = reinterpret_cast<int32_t *>(base + o_rowptr);
+    plan->cell_lidx = reinterpret_cast<int32_t *>(base + o_lidx);
+    plan->cell_val = reinterpret_cast<double *>(base + o_val);
+    plan->cell_rows = ty * tx;
+    plan->cell_umax = static_cast<int32_t>(h[1]);
+    plan->cell_emax = static_cast<int32_t>(h[2]);
+    plan->cell_patches = (n_b + plan->cell_rows - 1) / plan->cell_rows;
+    plan->device_bytes += total;
+    return REMAP_OK;
+}
+
 }  // namespace
 }  // namespace remap
 
 extern "C" {
+
+int remap_plan_prepare_short_runs(remap_plan *plan, void *stream)
+{
+    if (!plan)
+        return remap::fail(REMAP_ERR_ARG,
+                           "remap_plan_prepare_short_runs: NULL plan");
+    int current = -1;
+    if (hipGetDevice(&current) != hipSuccess || current != plan->device)
+        return remap::fail(REMAP_ERR_ARG,
+                           "remap_plan_prepare_short_runs: the plan lives on "
+                           "device %d, the current device is %d",
+                           plan->device, current);
+    return remap::prepare_short_runs(plan, static_cast<hipStream_t>(stream));
+}
 
 int remap_plan_create(int64_t n_b, int64_t n_a, int64_t n_s,
                       const int32_t *row, const int32_t *col, const double *S,
@@ -299,7 +408,8 @@ void remap_plan_destroy(remap_plan *plan)
     for (void *p : {static_cast<void *>(plan->rowptr),
                     static_cast<void *>(plan->col),
                     static_cast<void *>(plan->val),
-                    static_cast<void *>(plan->frac_b), plan->arena})
+                    static_cast<void *>(plan->frac_b), plan->arena,
+                    plan->cell_arena})
         if (p)
             (void)hipFree(p);
     if (switched)
@@ -373,6 +483,27 @@ int remap_plan_apply(const remap_plan *plan, const remap_field *f,
     a.gate_value = f->gate_value;
     a.flags = f->flags;
     const remap_schedule &s = plan->sched;
+    // fields whose contiguous run behind the source axes is short, in
+    // several batches -- (Time, nCells) -- take the LDS-staged
+    // lanes-across-rows kernel when its patch plan has been prepared
+    if (plan->cell_arena && f->k_inner < 8 && f->n_batch > 1 &&
+        f->n_batch * f->k_inner >= 2) {
+        a.row_order = plan->cell_order;
+        a.patch_ptr = plan->cell_ptr;
+        a.patch_ucol = plan->cell_ucol;
+        a.patch_rowptr = plan->cell_rowptr;
+        a.patch_lidx = plan->cell_lidx;
+        a.patch_val = plan->cell_val;
+        a.patch_rows = plan->cell_rows;
+        a.patch_umax = plan->cell_umax;
+        a.patch_emax = plan->cell_emax;
+        a.patch_row_bytes = 1024;
+        a.n_patches = plan->cell_patches;
+        a.tune[0] = 7;
+        a.tune[1] = f->n_batch * f->k_inner >= 64 ? 8 : 4;
+        a.flags |= REMAP_FLAG_TUNE_HINT;
+        return remap_apply_f64(&a, stream);
+    }
     if (s.family != 0) {
         a.row_order = s.row_order;
         a.patch_ptr = s.patch_ptr;

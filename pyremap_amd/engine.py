@@ -33,7 +33,7 @@ FLAG_TREE = 8
 DTYPE_F64 = 0
 DTYPE_F32 = 1
 
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 #: readable pad entries kept behind col/val (remap_csr.csr_pad)
 CSR_PAD = 8
@@ -48,7 +48,7 @@ EXPORTS = (
     'remap_schedule_sizes', 'remap_schedule_auto',
     'remap_plan_create', 'remap_plan_destroy', 'remap_plan_query',
     'remap_plan_apply', 'remap_pack_columns_workspace', 'remap_pack_columns',
-    'remap_gather_rows',
+    'remap_gather_rows', 'remap_plan_prepare_short_runs',
 )
 
 
@@ -261,6 +261,9 @@ def load_library():
     lib.remap_plan_query.restype = ctypes.c_int
     lib.remap_plan_query.argtypes = [ctypes.c_void_p,
                                      ctypes.POINTER(_PlanInfo)]
+    lib.remap_plan_prepare_short_runs.restype = ctypes.c_int
+    lib.remap_plan_prepare_short_runs.argtypes = [ctypes.c_void_p,
+                                                  ctypes.c_void_p]
     lib.remap_plan_apply.restype = ctypes.c_int
     lib.remap_plan_apply.argtypes = [ctypes.c_void_p,
                                      ctypes.POINTER(_Field), ctypes.c_void_p]

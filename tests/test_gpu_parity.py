@@ -2011,6 +2011,71 @@ def test_plan_handle_device_inputs_and_strided_fields(dev):
         lib.remap_plan_destroy(handle)
 
 
+def test_plan_handle_time_ncells(dev):
+    """
+    The opaque handle on the reference's most common layout, (Time, nCells):
+    in place (n_batch = Time, k_inner = 1) through `spmm_rowcell` as created,
+    through the LDS-staged `spmm_patchcell` once
+    remap_plan_prepare_short_runs has built its patch plan (a second call is
+    a no-op; the plan's device_bytes grows once) -- same bits either way.
+    """
+    import ctypes
+    from oracle import oracle
+    from pyremap_amd import engine, synthetic
+    lib = engine.load_library()
+    m = synthetic.conservative_map(5000, (40, 60), 1, 7, seed=45,
+                                   locality='mesh')
+    mm = m.numpy()
+    dims = (ctypes.c_int64 * 2)(*m.dst_dims)
+    handle = ctypes.c_void_p()
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def ptr(a):
+        return a.ctypes.data_as(ctypes.c_void_p)
+    row = np.ascontiguousarray(mm['row'], dtype=np.int32)
+    col = np.ascontiguousarray(mm['col'], dtype=np.int32)
+    S = np.ascontiguousarray(mm['S'])
+    fb = np.ascontiguousarray(mm['frac_b'])
+    rc = lib.remap_plan_create(m.n_b, m.n_a, S.size, ptr(row), ptr(col),
+                               ptr(S), 1, ptr(fb), 1, dims, 2, stream,
+                               ctypes.byref(handle))
+    assert rc == 0, lib.remap_last_error()
+    try:
+        csr = oracle.coo_to_csr(mm['row'] - 1, mm['col'] - 1, mm['S'], m.n_b,
+                                m.n_a)
+        rng = np.random.default_rng(8)
+        T = 90
+        field = rng.standard_normal((T, m.n_a))
+        field[:, rng.random(m.n_a) < 0.2] = np.nan
+        ref = np.ma.filled(oracle.remap_numpy_array(
+            csr, mm['frac_b'], m.dst_dims,
+            np.ma.masked_array(field, np.isnan(field)), [1], 0.1), np.nan)
+        X = torch.from_numpy(field).to(dev)
+        info = engine._PlanInfo()
+        sizes = []
+        for prepared in (False, True, True):
+            if prepared:
+                rc = lib.remap_plan_prepare_short_runs(handle, stream)
+                assert rc == 0, lib.remap_last_error()
+            assert lib.remap_plan_query(handle, ctypes.byref(info)) == 0
+            sizes.append(int(info.device_bytes))
+            Y = torch.full((T, m.n_b), 5.0, dtype=torch.float64, device=dev)
+            f = engine._Field()
+            f.X, f.Y = X.data_ptr(), Y.data_ptr()
+            f.x_dtype, f.mode = engine.DTYPE_F64, engine.MODE_MASKED
+            f.n_batch, f.k_inner = T, 1
+            f.x_row_stride, f.x_batch_stride = 1, m.n_a
+            f.y_row_stride, f.y_batch_stride = 1, m.n_b
+            f.threshold = 0.1
+            rc = lib.remap_plan_apply(handle, ctypes.byref(f), stream)
+            assert rc == 0, lib.remap_last_error()
+            assert_bitwise(Y.cpu().numpy().reshape((T,) + m.dst_dims), ref,
+                           f'handle (Time, nCells) prepared={prepared}')
+        assert sizes[1] > sizes[0] and sizes[2] == sizes[1]
+    finally:
+        lib.remap_plan_destroy(handle)
+
+
 def test_c_abi_from_plain_c(tmp_path):
     """examples/c_abi_plan.c -- gcc, no Python, no C++: the plan handle from
     C, every value compared in C with a sequential multiply-then-add."""
