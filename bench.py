@@ -744,7 +744,8 @@ def workload_rows(extra):
             'bytes_alg': e['bytes_alg'],
             'K': e['K'], 'mode': e['mode'], 'layout': e['layout'],
             'dtype': e.get('dtype', 'f64'), 'numbering': e['locality'],
-            'kernel': 'spmm_rowlane' if e['K'] <= 32 else
+            'kernel': 'spmm_patchcell' if e['layout'] == 'tn' else
+            'spmm_rowlane' if e['K'] <= 32 else
             KERNEL_OF_FAMILY.get(sched.get('family'), 'spmm_*'),
         }
     return rows
