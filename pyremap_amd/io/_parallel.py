@@ -87,6 +87,55 @@ def replace_value(data, old, new):
             list(pool.map(task, spans))
 
 
+def pread_convert(fd, runs, file_dtype, count):
+    """
+    ``count`` elements of ``file_dtype`` (any byte order) from a file into a
+    fresh NATIVE-order array: ``runs`` = ``(file offset, first element,
+    elements)`` triples -- one for a contiguous variable, one per record for
+    a record variable.  Every run is cut into pieces of a few MB; each task
+    ``preadv``s its piece into a small buffer of its own and casts it into
+    place (both release the GIL: several cores).  Unlike a memory map of the
+    file -- whose touched pages stay resident beside the converted copy --
+    nothing but the result remains, which is what a streaming remap of a
+    large file needs.
+    """
+    file_dtype = np.dtype(file_dtype)
+    native = file_dtype.newbyteorder('=')
+    out = np.empty(count, dtype=native)
+    item = file_dtype.itemsize
+    step = max(1, (8 << 20) // item)
+    pieces = []
+    for off, first, n in runs:
+        for i in range(0, n, step):
+            pieces.append((off + i * item, first + i, min(step, n - i)))
+    same = file_dtype.byteorder in '=|' or file_dtype == native or \
+        item == 1
+
+    def task(piece):
+        off, first, n = piece
+        if same:
+            mv = memoryview(out[first:first + n].view(np.uint8))
+        else:
+            buf = np.empty(n, dtype=file_dtype)
+            mv = memoryview(buf.view(np.uint8))
+        done, want = 0, n * item
+        while done < want:
+            got = os.preadv(fd, [mv[done:]], off + done)
+            if got <= 0:
+                raise OSError('short read')
+            done += got
+        if not same:
+            out[first:first + n] = buf
+
+    if len(pieces) <= 1 or _workers() == 1:
+        for piece in pieces:
+            task(piece)
+    else:
+        with ThreadPoolExecutor(_workers()) as pool:
+            list(pool.map(task, pieces))
+    return out
+
+
 def write_at(f, data, dtype=None, nan_fill=None):
     """
     Write the C-order bytes of ``data`` (converted to ``dtype`` first if

@@ -788,10 +788,11 @@ class Dataset(_Object):
                 # a large contiguous dataset: one pass, on several cores,
                 # straight from the mapping (slicing an mmap copies it once
                 # and decode() once more)
-                view = np.frombuffer(mm, dtype=np.uint8, count=nbytes,
-                                     offset=address).view(typ.dtype)
-                out = _parallel.convert(view, typ.dtype)
-                del view
+                # (pread into the final array, not a view of the mapping:
+                # the mapping's touched pages would stay resident beside the
+                # copy -- what a streaming remap of a large file must avoid)
+                out = _parallel.pread_convert(
+                    f._fh.fileno(), [(address, 0, count)], typ.dtype, count)
                 return out.reshape(shape)
             return self._finish(mm[address:address + nbytes], count)
         if cls != 2:

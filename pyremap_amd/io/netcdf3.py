@@ -14,6 +14,7 @@ Format reference: the NetCDF classic format specification (header =
 magic, numrecs, dim_list, gatt_list, var_list; big-endian; values padded to
 4 bytes; record variables interleaved per record).
 """
+import os
 import struct
 from collections import OrderedDict
 
@@ -157,8 +158,32 @@ class Deferred:
             self.dtype.itemsize
 
     def read(self):
+        if self.layout is not None:
+            return _read_direct(self.filename, self.shape, self.dtype,
+                                *self.layout)
         return read(self.filename, variables={self.name}) \
             .variables[self.name].data
+
+    #: (begin, record stride or 0): where the bytes lie, for the direct read
+    layout = None
+
+
+def _read_direct(filename, shape, dtype, begin, recsize):
+    """One variable's bytes straight into its final, native-order array
+    (``_parallel.pread_convert``), not through a memory map of the file."""
+    count = int(np.prod(shape, dtype=np.int64))
+    if recsize:
+        per = count // shape[0] if shape[0] else 0
+        runs = [(begin + r * recsize, r * per, per) for r in range(shape[0])]
+    else:
+        runs = [(begin, 0, count)]
+    fd = os.open(filename, os.O_RDONLY)
+    try:
+        out = _parallel.pread_convert(fd, runs, dtype.newbyteorder('>'),
+                                      count)
+    finally:
+        os.close(fd)
+    return out.reshape(shape)
 
 
 def read(filename, variables=None, defer_bytes=None):
@@ -240,6 +265,7 @@ def read(filename, variables=None, defer_bytes=None):
             shape = [nc.numrecs if nc.dimensions[d] is None
                      else nc.dimensions[d] for d in dims]
             later = Deferred(filename, name, shape, dt.newbyteorder('='))
+            later.layout = (int(begin), int(recsize) if is_rec(dimids) else 0)
             if later.nbytes >= defer_bytes:
                 nc.variables[name] = Variable(name, dims, later, attrs,
                                               is_rec(dimids))
