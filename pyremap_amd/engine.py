@@ -196,6 +196,14 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # torch brings its own HIP runtime (torch/lib/libamdhip64.so); the
+    # library's RUNPATH names the system one.  Whichever is loaded first
+    # serves the whole process, and a process with BOTH initialised sees "no
+    # ROCm-capable device" from the second: torch first, always.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     path = _build.LIB_PATH
     if not os.path.exists(path):
         if _build.find_hipcc() is None:
