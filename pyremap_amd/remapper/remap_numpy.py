@@ -18,6 +18,7 @@ reference (remap_numpy.py)      here
                                 transpose copies, one fused HIP launch
 ==============================  ============================================
 """
+import os
 import sys
 
 import numpy as np
@@ -138,13 +139,48 @@ def _validate_mapping(info, src_descriptor, dst_descriptor):
                     f'{have} != {want}')
 
 
+#: device plans of mapping FILES already loaded by this process, most
+#: recent last: (path, mtime, size, device, devices) -> (info, plan,
+#: schedule).  MPAS-Analysis builds one short-lived Remapper per variable
+#: group over the same few mapping files; the second one finds its weights
+#: on the device (the reference re-reads and re-sorts per Remapper,
+#: remap_numpy.py:87-137).  Environment: PYREMAP_AMD_PLAN_CACHE = number of
+#: plans kept (default 4; 0 disables).
+_PLAN_CACHE = {}
+_PLAN_CACHE_SIZE = int(os.environ.get('PYREMAP_AMD_PLAN_CACHE', 4))
+
+
+def _plan_cache_key(remapper):
+    if remapper._mapping_override is not None or _PLAN_CACHE_SIZE <= 0 or \
+            getattr(remapper, '_process_group', None) is not None:
+        return None
+    try:
+        st = os.stat(remapper.map_filename)
+    except OSError:
+        return None
+    devices = getattr(remapper, 'devices', None)
+    return (os.path.abspath(remapper.map_filename), st.st_mtime_ns,
+            st.st_size, str(remapper.device),
+            tuple(str(d) for d in devices) if devices else None)
+
+
 def _load_mapping(remapper):
     """
     Read the mapping file once, validate it against the descriptors and sort
     its triplets into a device-resident CSR (reference ``_load_mapping``
-    :72-139; the plan is cached where the reference caches ``_matrix``).
+    :72-139; the plan is cached where the reference caches ``_matrix``, and
+    -- per process -- by mapping file, see ``_PLAN_CACHE``).
     """
     if remapper._ds_map is not None:
+        return
+    key = _plan_cache_key(remapper)
+    if key is not None and key in _PLAN_CACHE:
+        info, plan, schedule = _PLAN_CACHE.pop(key)
+        _PLAN_CACHE[key] = (info, plan, schedule)       # most recent last
+        _validate_mapping(info, remapper.src_descriptor,
+                          remapper.dst_descriptor)
+        remapper._matrix, remapper.schedule = plan, schedule
+        remapper._ds_map = info
         return
     mapping = remapper._mapping_override
     if mapping is None:
@@ -174,6 +210,10 @@ def _load_mapping(remapper):
         remapper.schedule = plan.auto_schedule(info.dst_grid_dims)
     remapper._matrix = plan
     remapper._ds_map = info
+    if key is not None:
+        _PLAN_CACHE[key] = (info, plan, remapper.schedule)
+        while len(_PLAN_CACHE) > _PLAN_CACHE_SIZE:
+            _PLAN_CACHE.pop(next(iter(_PLAN_CACHE)))
 
 
 def _check_drop(remapper, da):

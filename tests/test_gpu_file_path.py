@@ -669,3 +669,39 @@ def test_ncremap_streams_with_bounded_memory(tmp_path):
             db.variables[name].values.tobytes(), name
         assert sorted(da.variables[name].attrs) == \
             sorted(db.variables[name].attrs), name
+
+
+def test_mapping_files_are_loaded_once_per_process(setup, tmp_path):
+    """Short-lived Remappers over one mapping file (MPAS-Analysis builds one
+    per variable group) find the device plan of the first; a rewritten file
+    is loaded afresh; descriptors are validated per Remapper all the same."""
+    import shutil
+    import time
+
+    from pyremap_amd import LatLonGridDescriptor, Remapper
+    from pyremap_amd.remapper import remap_numpy
+    path = str(tmp_path / 'map_cached.nc')
+    shutil.copy(setup['map_path'], path)
+
+    def make(dst=None):
+        return Remapper(map_filename=path, src_descriptor=setup['src'],
+                        dst_descriptor=dst or setup['dst'])
+    a, b = make(), make()
+    plan = a.load_mapping()
+    assert b.load_mapping() is plan and b.schedule == a.schedule
+    x = np.random.default_rng(0).standard_normal((setup['n_cells'], 40))
+    assert_bitwise(np.ma.filled(b.remap_array(x, [0]), np.nan),
+                   np.ma.filled(a.remap_array(x, [0]), np.nan))
+    # a descriptor that does not fit the file still raises
+    wrong = LatLonGridDescriptor.create(np.linspace(-90, 90, 10),
+                                        np.linspace(-180, 180, 37))
+    with pytest.raises(ValueError, match="don't have the same size"):
+        make(wrong).load_mapping()
+    # the file changes: a new plan
+    time.sleep(0.01)
+    m2 = setup['map']
+    m2.save(path)
+    os.utime(path, ns=(time.time_ns(), time.time_ns()))
+    assert make().load_mapping() is not plan
+    # PYREMAP_AMD_PLAN_CACHE bounds the cache
+    assert len(remap_numpy._PLAN_CACHE) <= remap_numpy._PLAN_CACHE_SIZE

@@ -5,7 +5,11 @@ source cells onto 100-300 x 100-400 grids -- hundreds of workgroups per
 launch, every K tile rule (flat, whole batches per tile, one batch per
 chunk, one or two elements per lane) -- as `(n, K)` and `(Time, n, levels)`
 fields, float32 / float64, frac_b / masked, whole plan and a row shard, bit
-for bit against the oracle.
+for bit against the oracle.  Round 3: the source cells numbered along the
+raster, as an MPAS mesh, or at random; `(Time, n)` and `(Time, n, 1..7)`
+fields (the lanes-across-rows kernels); the shard also in its PACKED column
+space on `X[ucols]`; every third seed through a 2- or 3-"device"
+MultiDeviceRemap.
 
     python tools/fuzz_medium.py [seconds=480] [first_seed=0]
 """
@@ -37,18 +41,30 @@ def one(seed, dev):
                                    seed=seed, device=dev)
     else:
         lo, hi = (1, 7) if kind == 'conservative' else (10, 24)
-        m = synthetic.conservative_map(int(rng.integers(5000, 80000)),
-                                       (my, mx), lo, hi, seed=seed,
-                                       device=dev, signed=kind == 'rich')
+        m = synthetic.conservative_map(
+            int(rng.integers(5000, 80000)), (my, mx), lo, hi, seed=seed,
+            device=dev, signed=kind == 'rich',
+            locality=str(rng.choice(['raster', 'mesh', 'scatter'])))
     plan = engine.RemapPlan.from_triplets(m.row, m.col, m.S, m.frac_b, m.n_a,
                                           m.n_b, device=dev)
     sched = plan.auto_schedule(m.dst_dims) if rng.random() < 0.85 else None
     rowptr, col, val = plan.to_host_csr()
     csr = oracle.OracleCSR(rowptr, col, val, (m.n_b, m.n_a))
     frac_b = m.frac_b.cpu().numpy()
-    for case in range(3):
-        if rng.random() < 0.4:
+    multi = None
+    if seed % 3 == 0:
+        from pyremap_amd.parallel import MultiDeviceRemap
+        multi = MultiDeviceRemap(plan, [dev] * int(rng.integers(2, 4)),
+                                 grid_dims=m.dst_dims)
+    for case in range(4):
+        pick = rng.random()
+        if pick < 0.3:
             shape, axis = [m.n_a, int(rng.choice([40, 61, 128, 200, 257]))], 0
+        elif pick < 0.5:
+            shape, axis = [int(rng.integers(2, 200)), m.n_a], 1
+        elif pick < 0.6:
+            shape = [int(rng.integers(2, 40)), m.n_a, int(rng.integers(1, 8))]
+            axis = 1
         else:
             shape = [int(rng.integers(1, 6)), m.n_a, int(rng.choice(LEVELS))]
             axis = 1
@@ -60,6 +76,8 @@ def one(seed, dev):
             cells = rng.random(m.n_a) < 0.2
             if axis == 0:
                 field[cells, shape[1] // 2:] = np.nan
+            elif len(shape) == 2:
+                field[shape[0] // 2:, cells] = np.nan
             else:
                 field[:, cells, shape[2] // 2:] = np.nan
             thr = float(rng.choice([0.0, 0.05, 0.5]))
@@ -87,6 +105,16 @@ def one(seed, dev):
         lo = shard.row_offset
         want = np.take(flat, np.arange(lo, lo + shard.n_b), axis=axis)
         assert_bitwise(ys.cpu().numpy(), want, what + f' shard {r}/3')
+        packed, ucols = shard.packed()
+        packed.auto_schedule(m.dst_dims)
+        yp = engine.remap_tensor(packed, None,
+                                 engine.gather_rows(x, axis, ucols), [axis],
+                                 emode, threshold=thr or 0.0)
+        assert_bitwise(yp.cpu().numpy(), want, what + f' packed {r}/3')
+        if multi is not None:
+            ym = engine.remap_tensor(multi, m.dst_dims, x, [axis], emode,
+                                     threshold=thr or 0.0)
+            assert_bitwise(ym.cpu().numpy(), ref, what + ' multi-device')
 
 
 def main():

@@ -38,6 +38,9 @@ def main():
     ap.add_argument('--mode', default='fracb')
     ap.add_argument('--tiles', default='16x16,8x16,8x32,16x32')
     ap.add_argument('--quick', action='store_true')
+    ap.add_argument('--only', default='',
+                    help="'patch': only the LDS-staged variants, TT = 8, "
+                         "shape (120, n_a) (for counter passes)")
     ap.add_argument('--sets', type=int, default=1,
                     help='distinct X buffers rotated over the launches '
                          '(>= 3 x 200 MB: Infinity-Cache-cold)')
@@ -55,6 +58,9 @@ def main():
               (60, m.n_a, 4), (40, m.n_a, 3), (120, m.n_a, 1)]
     if args.quick:
         shapes = [(12, m.n_a), (120, m.n_a), (60, m.n_a, 4)]
+    if args.only == 'patch':
+        shapes = [(120, m.n_a)]
+        variants = []
     variants = [('auto', None)] + [
         (f'rowcell tt={tt} unr={u}', [4, tt, u])
         for tt in (4, 8, 16) for u in (1, 2, 4)
@@ -80,9 +86,10 @@ def main():
         want = engine.remap_tensor(plan, m.dst_dims, x, [1], mode,
                                    threshold=0.01, tune=[1])
         print(f'{shape}: K = {K}, {bytes_alg / 1e6:.0f} MB algorithmic')
-        t = timed(permuted, args.reps)
-        print(f'   permute copies + (n_a, K) kernel   {t * 1e3:8.1f} us  '
-              f'{bytes_alg / t / 1e6 / 8000:.3f}')
+        if args.only != 'patch':
+            t = timed(permuted, args.reps)
+            print(f'   permute copies + (n_a, K) kernel   {t * 1e3:8.1f} us  '
+                  f'{bytes_alg / t / 1e6 / 8000:.3f}')
         for name, tune in variants:
             if name == 'rowlane' and K > 32:
                 continue
@@ -110,7 +117,7 @@ def main():
             ratio = plan.build_patches(m.dst_dims, tile=(ty, tx),
                                        lds_budget=10 ** 9)
             plan.default_tune = None
-            for tt in (4, 8, 16):
+            for tt in ((8,) if args.only == 'patch' else (4, 8, 16)):
                 if plan.patches['umax'] * tt * 8 > 150 * 1024:
                     continue
 
