@@ -55,10 +55,15 @@ def _remap_file(remapper, in_filename, out_filename, variable_list,
                 overwrite, renormalize, logger, replace_mpas_fill):
     if not _validate_inputs(remapper, out_filename, overwrite):
         return
+    group = getattr(remapper, '_process_group', None)
     # (with a variable list only those variables -- and the coordinates --
-    # are read: the rest of the file is not touched)
+    # are read: the rest of the file is not touched.  Under
+    # Remapper.use_process_group the call is a collective: every rank reads
+    # the file and takes part in every variable's remap in the same order,
+    # rank `src` alone writes -- no streaming there, the ranks must agree on
+    # the order of the collectives)
     ds = open_dataset(in_filename, variables=variable_list,
-                      lazy_bytes=STREAM_BYTES)
+                      lazy_bytes=None if group is not None else STREAM_BYTES)
     if variable_list is not None:
         missing = [v for v in variable_list if v not in ds]
         if missing:
@@ -100,6 +105,8 @@ def _remap_file(remapper, in_filename, out_filename, variable_list,
     fmt = encoding.get('format') or file_format(in_filename)
     if fmt not in FORMATS and fmt != 'NETCDF4':
         fmt = 'NETCDF3_64BIT_DATA'
+    if group is not None and remapper._matrix.rank != group[1]:
+        return                       # rank `src` writes
     write_netcdf(ds_out, out_filename, format=fmt,
                  unlimited_dims=encoding.get('unlimited_dims', []))
     if logger is not None:

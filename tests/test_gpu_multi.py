@@ -349,6 +349,26 @@ def _sharded_worker(rank, world, port, tmpdir, backend):
             csr, mm['frac_b'], m.dst_dims, field, [1], None), np.nan)
         notes['collective_array'] = int(np.array_equal(
             np.ma.filled(got, np.nan), want, equal_nan=True))
+        # ncremap as a collective: every rank reads, rank 0 alone writes
+        from pyremap_amd.io.netcdf import open_dataset, write_netcdf
+        src_path = os.path.join(tmpdir, 'collective_in.nc')
+        out_path = os.path.join(tmpdir, 'collective_out.nc')
+        if rank == 0:
+            write_netcdf(Dataset({'t': DataArray(
+                field, dims=('Time', 'nCells', 'z'))}), src_path,
+                format='NETCDF3_64BIT_DATA')
+        dist.barrier()
+        r.ncremap(src_path, out_path, renormalize=0.01)
+        dist.barrier()
+        if rank == 0:
+            back = open_dataset(out_path)
+            arg = np.ma.masked_array(field, np.isnan(field))
+            want = np.ma.filled(oracle.remap_numpy_array(
+                csr, mm['frac_b'], m.dst_dims, arg, [1], 0.01), np.nan)
+            notes['collective_file'] = int(np.array_equal(
+                back['t'].values, want, equal_nan=True))
+        else:
+            notes['collective_file'] = 1
         with open(os.path.join(tmpdir, f'rank{rank}.txt'), 'w') as f:
             f.write(repr(notes))
     finally:
@@ -364,7 +384,7 @@ def _run_ranks(world, tmp_path, backend):
         notes = eval(open(tmp_path / f'rank{rank}.txt').read())
         for key in ('alltoall', 'broadcast', 'pipelined_alltoall',
                     'pipelined_broadcast', 'collective_dataset',
-                    'collective_array'):
+                    'collective_array', 'collective_file'):
             assert notes[key] == 1, (rank, key, notes)
         # mesh-numbered source: the packed rows still are ~(1/N + halo)
         assert notes['packed_frac'] < (0.8 if world == 2 else 0.65)
@@ -389,3 +409,40 @@ def test_sharded_remap_over_rccl(tmp_path):
     """The same through RCCL, one rank per GPU -- the run the advisor asked
     for before the all-to-all exchange becomes the nccl default."""
     _run_ranks(2, tmp_path, 'nccl')
+
+
+def test_shards_without_entries(dev):
+    """A shard that holds nothing but empty destination rows (land): its
+    packed column space is empty, its slab all masked -- and the assembled
+    result still is the one-device result."""
+    from pyremap_amd import engine, synthetic
+    from pyremap_amd.parallel import MultiDeviceRemap
+    m = synthetic.conservative_map(3000, (40, 50), 1, 5, seed=12, device=dev,
+                                   locality='mesh')
+    keep = m.row > 1200                      # rows 0..1199: no entries
+    frac_b = m.frac_b.clone()
+    frac_b[:1200] = 0.0
+    plan = engine.RemapPlan.from_triplets(m.row[keep], m.col[keep],
+                                          m.S[keep], frac_b, m.n_a, m.n_b,
+                                          device=dev)
+    empty, ucols = plan.row_slice(0, 1000).packed()
+    assert empty.nnz == 0 and empty.n_a == 0 and ucols.numel() == 0
+    multi = MultiDeviceRemap(plan, [dev] * 4, grid_dims=m.dst_dims)
+    assert any(s.plan.nnz == 0 for s in multi.shards) or \
+        multi.bounds[1] <= 1200
+    plan.auto_schedule(m.dst_dims)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    for shape, axes in (((m.n_a, 70), [0]), ((3, m.n_a, 9), [1]),
+                        ((50, m.n_a), [1])):
+        x = torch.randn(shape, generator=g, device=dev, dtype=torch.float64)
+        x.index_fill_(axes[0], torch.arange(0, m.n_a, 7, device=dev),
+                      float('nan'))
+        for mode, thr in ((engine.MODE_FRACB, 0.0),
+                          (engine.MODE_MASKED, 0.05)):
+            want = engine.remap_tensor(plan, m.dst_dims, x, axes, mode,
+                                       threshold=thr)
+            got = engine.remap_tensor(multi, m.dst_dims, x, axes, mode,
+                                      threshold=thr)
+            assert_bitwise(got.cpu().numpy(), want.cpu().numpy(),
+                           f'{shape} {mode}')
