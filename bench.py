@@ -640,6 +640,10 @@ def extras_todo(args, world):
             ('K12_monthly_time_nCells', dict(name='config3', K=12,
                                              layout='tn'), 50),
             ('Time120_nCells', dict(name='config3', K=120, layout='tn'), 30),
+            # lat-lon model output on BASELINE config 1's bilinear map:
+            # (time = 120, lat x lon) float32, the reference's real input
+            ('config1_time120_latlon_f32',
+             dict(name='config1', K=120, layout='tn', dtype='f32'), 30),
             ('f32_fields', dict(name='config3', dtype='f32'), 50),
             ('layout_T8_nCells_L64', dict(name='config3', layout='tnl'), 50),
             ('layout_T8_nCells_L60', dict(name='config3', layout='tnl',

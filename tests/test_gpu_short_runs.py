@@ -174,3 +174,45 @@ def test_time_ncells_other_numberings(dev, locality):
                                       False, 0.0)
     ref[ref_mask] = np.nan
     assert_bitwise(y.cpu().numpy().reshape(70, m.n_b), ref.T, locality)
+
+
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+def test_time_level_lat_lon_on_a_bilinear_map(dev, dtype):
+    """
+    Lat-lon model output, `(time, lev, lat, lon)` remapped over its last two
+    axes (the reference's real lat-lon input is f32 `(time, lat, lon)`,
+    tests/test_interpolate.py:492-516): time x lev batches of ONE field each
+    -- the lanes-across-rows kernel on its own patch plan, beside the LDS
+    patch schedule the bilinear map itself gets (family 5).
+    """
+    from oracle import oracle
+    from pyremap_amd import engine, synthetic
+    m = synthetic.bilinear_map((30, 40), (70, 90), device=dev)
+    plan = engine.RemapPlan.from_triplets(m.row, m.col, m.S, m.frac_b,
+                                          m.n_a, m.n_b, device=dev)
+    assert plan.auto_schedule(m.dst_dims)['family'] == 'patch'
+    rowptr, col, val = plan.to_host_csr()
+    csr = oracle.OracleCSR(rowptr, col, val, (m.n_b, m.n_a))
+    frac_b = m.frac_b.cpu().numpy()
+    rng = np.random.default_rng(31)
+    for shape, axes in (((6, 5, 30, 40), [2, 3]), ((40, 30, 40), [1, 2]),
+                        ((2, 30, 40), [1, 2])):
+        x = rng.standard_normal(shape).astype(dtype)
+        x[..., 3:9, 10:20] = np.nan            # land
+        for thr in (None, 0.3):
+            arg = x if thr is None else np.ma.masked_array(x, np.isnan(x))
+            ref = np.ma.filled(oracle.remap_numpy_array(
+                csr, frac_b, m.dst_dims, arg, axes, thr), np.nan)
+            y = engine.remap_tensor(
+                plan, m.dst_dims, torch.from_numpy(x).to(dev), axes,
+                engine.MODE_FRACB if thr is None else engine.MODE_MASKED,
+                threshold=thr or 0.0)
+            assert_bitwise(y.cpu().numpy(), ref, f'{shape} {thr}')
+    assert plan._cell and plan.patches is not None   # both plans live
+    # ... and the (n, K) layout still takes the map's own LDS patches
+    xk = rng.standard_normal((m.n_a, 96)).astype(dtype)
+    ref = np.ma.filled(oracle.remap_numpy_array(
+        csr, frac_b, m.dst_dims, xk, [0], None), np.nan)
+    y = engine.remap_tensor(plan, m.dst_dims, torch.from_numpy(xk).to(dev),
+                            [0], engine.MODE_FRACB)
+    assert_bitwise(y.cpu().numpy(), ref, 'nk after the cell plan')
