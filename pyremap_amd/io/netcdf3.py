@@ -537,9 +537,28 @@ def write(filename, dimensions, variables, attrs=None, version=2):
             if not rec:
                 continue
             arr = materialise(idx)
-            for r in range(arr.shape[0]):
-                f.seek(begins[idx] + r * recsize)
-                _write_big_endian(f, arr[r:r + 1], var.nan_fill)
+            per = vsize(arr, True)
+            if arr.shape[0] and per < (1 << 20):
+                # many short records (time stamps, scalars per step): one
+                # strided assignment through a mapping of the file instead
+                # of a seek and a write per record
+                f.flush()
+                raw = np.ascontiguousarray(arr)
+                if var.nan_fill is not None:
+                    raw = np.where(np.isnan(raw), var.nan_fill, raw)
+                if raw.dtype.kind != 'S' and raw.dtype.itemsize > 1:
+                    raw = raw.astype(raw.dtype.newbyteorder('>'))
+                rows = raw.reshape(arr.shape[0], -1).view(np.uint8)
+                mm = np.memmap(filename, dtype=np.uint8, mode='r+')
+                np.lib.stride_tricks.as_strided(
+                    mm[begins[idx]:], shape=rows.shape,
+                    strides=(recsize, 1))[:] = rows
+                mm.flush()
+                del mm
+            else:
+                for r in range(arr.shape[0]):
+                    f.seek(begins[idx] + r * recsize)
+                    _write_big_endian(f, arr[r:r + 1], var.nan_fill)
             del arr
         header = build(begins, False)
         if header.size() > reserved:
