@@ -1105,6 +1105,12 @@ def apply_strided(plan, X, Y, *, n_batch, k_inner, x_row_stride,
     """
     One asynchronous ``remap_apply_f64`` launch on torch's current stream.
     ``X``/``Y``/``mask_out`` are device tensors; strides are in elements.
+
+    The first ``(Time, nCells)``-like call on a plan (short contiguous runs
+    in several batches) builds the patch plan of ``spmm_patchcell``
+    (:meth:`RemapPlan.cell_patches`: allocations and one readback): make it
+    -- or call ``plan.cell_patches()`` -- before capturing launches in a
+    hipGraph.
     """
     torch = _torch()
     lib = load_library()

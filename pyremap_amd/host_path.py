@@ -205,11 +205,47 @@ class Pending:
         return self._done
 
 
+class OnDevice:
+    """
+    A remap whose result STAYS ON THE DEVICE until asked for
+    (``remap_host_array(..., keep_on_device=True)``): :meth:`result`
+    allocates the (pinned) host buffer, downloads and returns the data.  The
+    streaming file path starts the next variable this way while the current
+    one is being written: the host holds one result and, briefly, one input
+    -- HBM holds what is in flight (288 GB of it).
+    """
+
+    def __init__(self, y_d, out_shape):
+        self._y_d = y_d
+        self._out_shape = out_shape
+        self._done = None
+
+    def result(self):
+        if self._done is not None:
+            return self._done
+        torch = engine._torch()
+        y_d, self._y_d = self._y_d, None
+        with torch.cuda.device(y_d.device):
+            out_h, pinned = _host_buffer(self._out_shape, torch.float64)
+            try:
+                out_h.copy_(y_d, non_blocking=True)
+                torch.cuda.current_stream(y_d.device).synchronize()
+            except BaseException:
+                _release_pinned(pinned)
+                raise
+        data = out_h.numpy()
+        weakref.finalize(data, _release_pinned, pinned)
+        self._done = data
+        return data
+
+
 def remap_host_array(plan, dst_grid_dims, values, remap_axes, *, mode,
                      threshold=None, want_mask=False, flags=0,
-                     host_mask=None):
+                     host_mask=None, keep_on_device=False):
     """
-    Enqueue the remap of one host array and return a :class:`Pending`.
+    Enqueue the remap of one host array and return a :class:`Pending`
+    (``keep_on_device``: an :class:`OnDevice` -- upload and launch are
+    enqueued, the download waits for ``result()``).
 
     ``mode``: ``'fracb'`` (unmasked branch), ``'masked'`` (NaN-as-mask with
     renormalisation; ``threshold`` required) or ``'auto'`` -- masked iff the
@@ -259,6 +295,24 @@ def remap_host_array(plan, dst_grid_dims, values, remap_axes, *, mode,
         free, _ = torch.cuda.mem_get_info(device)
         if need > DEVICE_FRACTION * free:
             mode = 'masked' if _any_nan(values) else 'fracb'
+    if keep_on_device:
+        if want_mask or host_mask is not None:
+            raise ValueError('keep_on_device answers with NaN-filled data '
+                             'of plain arrays only')
+        with torch.cuda.device(device):
+            x_d = torch.empty(values.shape, dtype=host.dtype, device=device)
+            x_d.copy_(host, non_blocking=True)
+            if mode == 'auto':
+                y_d = engine.remap_tensor_auto_mode(
+                    plan, dst_grid_dims, x_d, remap_axes, thr, flags=flags)
+            else:
+                emode = engine.MODE_MASKED if mode == 'masked' else \
+                    engine.MODE_FRACB
+                y_d = engine.remap_tensor(
+                    plan, dst_grid_dims, x_d, remap_axes, emode,
+                    threshold=thr if emode == engine.MODE_MASKED else 0.0,
+                    flags=flags)
+        return OnDevice(y_d, out_shape)
     with torch.cuda.device(device):
         out_h, pin_o = _host_buffer(out_shape, torch.float64)
         mask_h, pin_m = _host_buffer(out_shape, torch.uint8) \

@@ -268,8 +268,9 @@ def _lazy_dataset(remapper, ds, renormalization_threshold):
     and attributes, but the values of every remapped variable are a
     :class:`~pyremap_amd.xr_lite.LazyValues` -- read, remapped and
     downloaded when the writer asks for them, and started one variable ahead
-    by its ``prefetch`` (upload, launch and download are enqueued without
-    waiting, so variable i + 1 travels while variable i is being written).
+    by its ``prefetch`` (read, upload and launch: variable i + 1 is computed
+    while variable i is being written; its result waits on the DEVICE and
+    comes down when asked for, so the host holds one result at a time).
     """
     results = {}
     for name in ds.data_vars:
@@ -287,7 +288,8 @@ def _lazy_dataset(remapper, ds, renormalization_threshold):
 
             def start(da=da):
                 finish = _start_data_array(da, remapper,
-                                           renormalization_threshold)
+                                           renormalization_threshold,
+                                           keep_on_device=True)
                 return lambda: finish().values
             out = xr_lite.DataArray(
                 xr_lite.LazyValues(shape, np.float64,
@@ -302,11 +304,14 @@ def _lazy_dataset(remapper, ds, renormalization_threshold):
     return xr_lite.Dataset(results, attrs=ds.attrs)
 
 
-def _start_data_array(da, remapper, renormalization_threshold):
+def _start_data_array(da, remapper, renormalization_threshold,
+                      keep_on_device=False):
     """
     Enqueue the remap of one variable -- upload, NaN scan, launch, download,
     none of which waits for the host -- and return the function that waits
-    for the data and assembles the result.
+    for the data and assembles the result.  ``keep_on_device``: the download
+    waits too, until the result is asked for (the streaming file path: the
+    host then holds one result at a time).
     """
     plan = _plan_data_array(da, remapper)
     if plan is None:
@@ -328,7 +333,8 @@ def _start_data_array(da, remapper, renormalization_threshold):
         remapper._matrix, remapper._ds_map.dst_grid_dims, da.values,
         remap_axes,
         mode='fracb' if renormalization_threshold is None else 'auto',
-        threshold=renormalization_threshold, flags=remapper.engine_flags)
+        threshold=renormalization_threshold, flags=remapper.engine_flags,
+        keep_on_device=keep_on_device)
     make = _array_class(da).from_dict
     attrs, name = da.attrs, da.name
 
