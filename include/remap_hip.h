@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define REMAP_ABI_VERSION 20
+#define REMAP_ABI_VERSION 21
 
 enum {
     REMAP_OK = 0,
@@ -240,6 +240,11 @@ typedef struct remap_apply_args {
      *                              columns (needs the row-group schedule),
      *                         6 = 1 with row metadata through the scalar
      *                             cache (needs csr_pad >= 8; the default)
+     *                         4 = lanes across destination rows, TT fields
+     *                             per lane (short contiguous runs in
+     *                             several batches: (Time, nCells)),
+     *                         7 = 4 with the distinct source cells of a
+     *                             patch staged in LDS (needs a patch plan)
      * tune[1] doubles per lane per tile (1 or 2); family 10: waves per
      *         workgroup (1, 2; else 4); family 2: entries of a row fetched
      *         together (1, 4 or 8)
@@ -251,6 +256,16 @@ typedef struct remap_apply_args {
      *         tools/build_diag.py, reads bottleneck-analysis switches from
      *         them; this build rejects them) */
     int32_t tune[8];
+    /* Two source axes that are NOT adjacent in memory -- a field (lat, M,
+     * lon[, T]) remapped over (lat, lon): source cell a = y * x_src_fold + x
+     * lives at y * x_outer_stride + x * x_row_stride (+ the column's offset
+     * b * x_batch_stride + k, where the dims BETWEEN the two axes are the
+     * batches: n_batch = M, x_batch_stride = their stride, k_inner = T).
+     * x_src_fold = 0 (the default): one stride, a * x_row_stride.  Served in
+     * place by the lanes-across-rows kernels (families 4 and 7); the
+     * reference takes a transpose copy (remap_numpy.py:254-256). */
+    int64_t x_src_fold;
+    int64_t x_outer_stride;
 } remap_apply_args;
 
 /* ABI / build information */

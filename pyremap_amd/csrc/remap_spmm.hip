@@ -494,6 +494,18 @@ int check_args(const remap_apply_args *a, Call &c)
     if (a->mode == REMAP_MODE_FRACB && !a->frac_b)
         return fail(REMAP_ERR_ARG,
                     "remap_apply_f64: REMAP_MODE_FRACB needs frac_b");
+    if (a->x_src_fold < 0 || a->x_src_fold >= (int64_t(1) << 31) ||
+        (a->x_src_fold != 0 &&
+         (a->x_outer_stride < 0 || A.n_cols % a->x_src_fold != 0)))
+        return fail(REMAP_ERR_ARG,
+                    "remap_apply_f64: x_src_fold = %lld does not divide the "
+                    "%lld source cells", (long long)a->x_src_fold,
+                    (long long)A.n_cols);
+    if (a->x_src_fold != 0 && a->tune[0] != 0 && a->tune[0] != 4 &&
+        a->tune[0] != 7 && !(a->flags & REMAP_FLAG_TUNE_HINT))
+        return fail(REMAP_ERR_UNSUPPORTED,
+                    "remap_apply_f64: two non-adjacent source axes "
+                    "(x_src_fold) are served by kernel families 4 and 7");
     if (c.K >= (int64_t(1) << 31))
         return fail(REMAP_ERR_UNSUPPORTED,
                     "remap_apply_f64: K = %lld fields per call exceeds 2^31",
@@ -555,6 +567,8 @@ KParams base_params(const remap_apply_args *a, const Call &c)
     p.row_end = a->row_end;
     p.ldx = a->x_row_stride;
     p.bsx = a->x_batch_stride;
+    p.src_fold = static_cast<uint32_t>(a->x_src_fold);
+    p.src_outer = a->x_outer_stride;
     p.ldy = a->y_row_stride;
     p.bsy = a->y_batch_stride;
     p.thr = a->threshold;
@@ -572,7 +586,9 @@ KParams base_params(const remap_apply_args *a, const Call &c)
 // (Time, nCells, 3) -- are served by the lanes-across-rows kernel.
 bool short_runs(const remap_apply_args *a)
 {
-    return a->k_inner < 8 && a->n_batch > 1;
+    // (two non-adjacent source axes: only the lanes-across-rows kernels
+    // address a cell through two strides)
+    return (a->k_inner < 8 && a->n_batch > 1) || a->x_src_fold != 0;
 }
 
 // REMAP_FLAG_TUNE_HINT: can the preferred family serve this call?
@@ -611,6 +627,8 @@ int automatic_family(const remap_apply_args *a, const Call &c)
     // this and measured slower on every case -- config 3's map: K = 1 17.7
     // vs 9.7 us, K = 12 77 vs 27 us, K = 32 268 vs 57 us; config 1's
     // bilinear map at K = 1: 10.1 vs 10.1 us -- so it stays opt-in
+    if (a->x_src_fold != 0)
+        return 4;
     if (c.K <= 32)
         return 2;
     if (short_runs(a))

@@ -29,6 +29,9 @@ struct KParams {
     int32_t xcd_map;
     uint32_t x_range;      // bytes addressable from a source row base
     uint32_t y_range;      // bytes addressable from a destination row base
+    int64_t src_outer;     // two non-adjacent source axes (src_fold != 0):
+    uint32_t src_fold;     // cell a lives at (a / fold) * src_outer +
+                           // (a % fold) * ldx; else at a * ldx
     const int32_t *__restrict__ gate;  // optional device-side switch: the
     int32_t gate_value;                // launch is a no-op unless *gate ==
                                        // gate_value (remap_apply_args.gate)
@@ -298,6 +301,17 @@ __device__ __forceinline__ int64_t logical_block(const KParams &p)
         L = xcd * p.blocks_per_xcd + slot;
     }
     return L;
+}
+
+// element offset of source cell a (remap_apply_args.x_src_fold)
+__device__ __forceinline__ int64_t cell_base(const KParams &p, int32_t a)
+{
+    if (p.src_fold == 0)
+        return static_cast<int64_t>(a) * p.ldx;
+    const uint32_t y = static_cast<uint32_t>(a) / p.src_fold;
+    const uint32_t x = static_cast<uint32_t>(a) - y * p.src_fold;
+    return static_cast<int64_t>(y) * p.src_outer +
+           static_cast<int64_t>(x) * p.ldx;
 }
 
 __device__ __forceinline__ int64_t readlane_i64(int64_t v, int src_lane)

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(kCellBlock) void spmm_patchcell(
     const int u0 = pptr[patch];
     const int U = pptr[patch + 1] - u0;
     for (int j = tid; j < U; j += kCellBlock) {
-        const int64_t c = static_cast<int64_t>(ucol[u0 + j]) * p.ldx;
+        const int64_t c = cell_base(p, ucol[u0 + j]);
         XT v[TT];
 #pragma unroll
         for (int t = 0; t < TT; ++t)

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(kBlock) void spmm_rowcell(const KParams p,
         for (int u = 0; u < UNR; ++u) {
             // clamped to the row's last entry: no load sits behind a branch
             const int64_t jj = base + u < e ? base + u : e - 1;
-            c[u] = static_cast<int64_t>(p.col[jj]) * p.ldx;
+            c[u] = cell_base(p, p.col[jj]);
             a[u] = p.val[jj];
         }
 #pragma unroll

@@ -33,7 +33,7 @@ FLAG_TREE = 8
 DTYPE_F64 = 0
 DTYPE_F32 = 1
 
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 #: readable pad entries kept behind col/val (remap_csr.csr_pad)
 CSR_PAD = 8
@@ -107,6 +107,8 @@ class _ApplyArgs(ctypes.Structure):
         ('gate_value', ctypes.c_int32),
         ('flags', ctypes.c_uint32),
         ('tune', ctypes.c_int32 * 8),
+        ('x_src_fold', ctypes.c_int64),
+        ('x_outer_stride', ctypes.c_int64),
     ]
 
 
@@ -1101,7 +1103,8 @@ class RemapPlan:
 def apply_strided(plan, X, Y, *, n_batch, k_inner, x_row_stride,
                   x_batch_stride, y_row_stride, y_batch_stride, mode,
                   threshold=0.0, mask_out=None, flags=0, tune=None,
-                  row_begin=0, row_end=None, gate=None, gate_value=0):
+                  row_begin=0, row_end=None, gate=None, gate_value=0,
+                  x_src_fold=0, x_outer_stride=0):
     """
     One asynchronous ``remap_apply_f64`` launch on torch's current stream.
     ``X``/``Y``/``mask_out`` are device tensors; strides are in elements.
@@ -1135,6 +1138,15 @@ def apply_strided(plan, X, Y, *, n_batch, k_inner, x_row_stride,
         if t is None or n_batch <= 0 or k_inner <= 0 or rows <= 0:
             continue
         reach = (n_batch - 1) * bs + (rows - 1) * rs + k_inner
+        if name == 'X' and x_src_fold:
+            # two source axes: the last cell is (n_a / fold - 1, fold - 1)
+            if x_src_fold < 0 or plan.n_a % x_src_fold or \
+                    x_outer_stride < 0:
+                raise ValueError(f'x_src_fold {x_src_fold} does not divide '
+                                 f'n_a = {plan.n_a}')
+            reach = (n_batch - 1) * bs + \
+                (plan.n_a // x_src_fold - 1) * x_outer_stride + \
+                (x_src_fold - 1) * rs + k_inner
         if min(rs, bs) < 0 or reach > t.numel():
             raise ValueError(
                 f'{name} holds {t.numel()} elements; the strides (row {rs}, '
@@ -1146,7 +1158,8 @@ def apply_strided(plan, X, Y, *, n_batch, k_inner, x_row_stride,
     whole = row_begin == 0 and end == plan.n_b
     # short contiguous runs in several batches -- (Time, nCells) -- go to the
     # LDS-staged lanes-across-rows kernel on its own patch plan
-    cell = whole and not tune and k_inner < 8 and n_batch > 1 and \
+    cell = whole and not tune and \
+        ((k_inner < 8 and n_batch > 1) or x_src_fold) and \
         n_batch * k_inner >= 2 and plan.cell_patches() is not None
     args = plan._prefilled(whole, cell)
     if cell:
@@ -1173,6 +1186,8 @@ def apply_strided(plan, X, Y, *, n_batch, k_inner, x_row_stride,
         args.gate = gate.data_ptr()
         args.gate_value = int(gate_value)
     args.flags = flags
+    args.x_src_fold = int(x_src_fold)
+    args.x_outer_stride = int(x_outer_stride)
     if not tune:
         # the plan's preference (auto_schedule); the library falls back to
         # its own choice where the preferred family cannot serve the call
@@ -1306,6 +1321,38 @@ def remap_tensor(plan, dst_grid_dims, field, remap_axes, mode, threshold=0.0,
             y_row_stride=k_inner, y_batch_stride=plan.n_b * k_inner,
             mode=mode, threshold=threshold, mask_out=mask, flags=flags,
             tune=tune, gate=gate, gate_value=gate_value)
+        return (Y, mask) if want_mask else Y
+    if len(remap_axes) == 2 and remap_axes[0] < remap_axes[1] and \
+            out is None and gate is None and mask_out is None:
+        # Two source axes with other dims BETWEEN them -- (lat, M, lon[, T])
+        # -- in place too: the dims between are the batches of the launch,
+        # a source cell is addressed through two strides (x_src_fold), and
+        # the lanes-across-rows kernels do the rest; one launch per index of
+        # the dims in front.  (remap_numpy.py:254-256 transposes.)
+        a0, a1 = remap_axes
+        X = field.contiguous()
+        lead_n = _prod(X.shape[:a0])
+        ny, nx = int(X.shape[a0]), int(X.shape[a1])
+        M = _prod(X.shape[a0 + 1:a1])
+        T = _prod(X.shape[a1 + 1:])
+        between = [int(s) for s in X.shape[a0 + 1:a1]]
+        trailing = [int(s) for s in X.shape[a1 + 1:]]
+        full_shape = [int(s) for s in X.shape[:a0]] + dst_shape + \
+            between + trailing
+        Y = torch.empty(full_shape, dtype=torch.float64, device=X.device)
+        mask = torch.empty(full_shape, dtype=torch.uint8,
+                           device=X.device) if want_mask else None
+        Xl = X.reshape(lead_n, -1)
+        Yl = Y.reshape(lead_n, -1)
+        Ml = mask.reshape(lead_n, -1) if want_mask else None
+        for li in range(lead_n):
+            apply_strided(
+                plan, Xl[li], Yl[li], n_batch=M, k_inner=T,
+                x_row_stride=T, x_batch_stride=nx * T,
+                y_row_stride=M * T, y_batch_stride=T, mode=mode,
+                threshold=threshold,
+                mask_out=Ml[li] if want_mask else None, flags=flags,
+                tune=tune, x_src_fold=nx, x_outer_stride=M * nx * T)
         return (Y, mask) if want_mask else Y
     if gate is not None or mask_out is not None:
         raise ValueError('gated launches and caller-supplied masks need the '

@@ -216,3 +216,57 @@ def test_time_level_lat_lon_on_a_bilinear_map(dev, dtype):
     y = engine.remap_tensor(plan, m.dst_dims, torch.from_numpy(xk).to(dev),
                             [0], engine.MODE_FRACB)
     assert_bitwise(y.cpu().numpy(), ref, 'nk after the cell plan')
+
+
+def test_non_adjacent_source_axes_in_place(dev, monkeypatch):
+    """
+    Two source axes with other dims between them -- `(lat, M, lon[, T])`,
+    the last layout the reference's transpose copy (remap_numpy.py:254-256)
+    was still needed for: addressed in place through two source strides
+    (`remap_apply_args.x_src_fold`) by the lanes-across-rows kernels, one
+    launch per index of the dims in front, no permute copy; bitwise.
+    """
+    from oracle import oracle
+    from pyremap_amd import engine, synthetic
+    m = synthetic.bilinear_map((30, 40), (70, 90), device=dev)
+    plan = engine.RemapPlan.from_triplets(m.row, m.col, m.S, m.frac_b,
+                                          m.n_a, m.n_b, device=dev)
+    plan.auto_schedule(m.dst_dims)
+    rowptr, col, val = plan.to_host_csr()
+    csr = oracle.OracleCSR(rowptr, col, val, (m.n_b, m.n_a))
+    frac_b = m.frac_b.cpu().numpy()
+    calls = []
+    real = engine.apply_strided
+
+    def spy(plan_, X, Y, **kw):
+        calls.append((kw['n_batch'], kw['k_inner'], kw.get('x_src_fold', 0)))
+        return real(plan_, X, Y, **kw)
+    monkeypatch.setattr(engine, 'apply_strided', spy)
+    monkeypatch.setattr(torch.Tensor, 'permute',
+                        lambda *a, **k: (_ for _ in ()).throw(
+                            AssertionError('permute copy taken')))
+    rng = np.random.default_rng(77)
+    for shape, axes in (((30, 7, 40), [0, 2]), ((3, 30, 5, 40, 2), [1, 3]),
+                        ((30, 2, 3, 40), [0, 3]), ((2, 30, 50, 40, 9), [1, 3]),
+                        ((30, 1, 40), [0, 2])):
+        for dtype in (np.float64, np.float32):
+            x = rng.standard_normal(shape).astype(dtype)
+            x[rng.random(shape) < 0.1] = np.nan
+            for thr in (None, 0.2):
+                arg = x if thr is None else np.ma.masked_array(x, np.isnan(x))
+                ref = oracle.remap_numpy_array(csr, frac_b, m.dst_dims, arg,
+                                               axes, thr)
+                want_mask = np.ma.getmaskarray(ref)
+                ref = np.ma.filled(ref, np.nan)
+                calls.clear()
+                y, mask = engine.remap_tensor(
+                    plan, m.dst_dims, torch.from_numpy(x).to(dev), axes,
+                    engine.MODE_FRACB if thr is None else engine.MODE_MASKED,
+                    threshold=thr or 0.0, want_mask=True)
+                assert tuple(y.shape) == ref.shape, (shape, axes)
+                assert_bitwise(y.cpu().numpy(), ref,
+                               f'{shape} {axes} {dtype.__name__} {thr}')
+                assert np.array_equal(mask.cpu().numpy().astype(bool),
+                                      want_mask)
+                lead = int(np.prod(shape[:axes[0]], dtype=np.int64))
+                assert len(calls) == lead and all(c[2] == 40 for c in calls)
