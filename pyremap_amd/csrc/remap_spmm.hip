@@ -26,6 +26,11 @@
 //    each destination patch's distinct source rows by LDS-DMA.
 //  * rowlane family (K <= 32): one lane per (row, k); lanes of a wave cover
 //    64 / K consecutive rows, X accesses are contiguous over k.
+//  * rowcell / patchcell families: lanes ACROSS destination rows, a few
+//    fields per lane -- for fields whose K values of one source cell are not
+//    contiguous: (Time, nCells), (time, lev, lat, lon), two source axes with
+//    other dims between them.  patchcell stages each distinct source cell of
+//    a destination patch once in LDS.
 //  * Fused epilogue: division by frac_b / by the remapped mask, threshold
 //    test, NaN fill and the optional byte mask are applied in registers; the
 //    reference's four (n, K) temporaries and its second SpMM never exist.
