@@ -500,7 +500,7 @@ int remap_plan_apply(const remap_plan *plan, const remap_field *f,
         a.patch_row_bytes = 1024;
         a.n_patches = plan->cell_patches;
         a.tune[0] = 7;
-        a.tune[1] = f->n_batch * f->k_inner >= 64 ? 8 : 4;
+        a.tune[1] = f->n_batch * f->k_inner >= 16 ? 8 : 4;
         a.flags |= REMAP_FLAG_TUNE_HINT;
         return remap_apply_f64(&a, stream);
     }

@@ -41,6 +41,10 @@ def main():
     ap.add_argument('--only', default='',
                     help="'patch': only the LDS-staged variants, TT = 8, "
                          "shape (120, n_a) (for counter passes)")
+    ap.add_argument('--tts', default='',
+                    help='fields per lane to try (default 4,8,16; 8 with '
+                         '--only patch)')
+    ap.add_argument('--time', type=int, default=120, dest='n_time')
     ap.add_argument('--sets', type=int, default=1,
                     help='distinct X buffers rotated over the launches '
                          '(>= 3 x 200 MB: Infinity-Cache-cold)')
@@ -59,7 +63,7 @@ def main():
     if args.quick:
         shapes = [(12, m.n_a), (120, m.n_a), (60, m.n_a, 4)]
     if args.only == 'patch':
-        shapes = [(120, m.n_a)]
+        shapes = [(args.n_time, m.n_a)]
         variants = []
     variants = [('auto', None)] + [
         (f'rowcell tt={tt} unr={u}', [4, tt, u])
@@ -117,7 +121,8 @@ def main():
             ratio = plan.build_patches(m.dst_dims, tile=(ty, tx),
                                        lds_budget=10 ** 9)
             plan.default_tune = None
-            for tt in ((8,) if args.only == 'patch' else (4, 8, 16)):
+            for tt in (tuple(int(v) for v in args.tts.split(',')) if args.tts
+                       else (8,) if args.only == 'patch' else (4, 8, 16)):
                 if plan.patches['umax'] * tt * 8 > 150 * 1024:
                     continue
 
