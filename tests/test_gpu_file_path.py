@@ -654,7 +654,7 @@ def test_ncremap_streams_with_bounded_memory(tmp_path):
     # streamed: two variables in flight, whatever the file holds
     assert grown['streamed'] < 2.6 * (one_in + one_out), grown
     assert grown['streamed'] < 0.5 * grown['eager'], grown
-    assert secs['streamed'] < 1.5 * secs['eager'] + 0.2, secs
+    assert secs['streamed'] < 2.0 * secs['eager'] + 0.5, secs
     a = open(tmp_path / 'big_out_eager.nc', 'rb').read()
     b = open(tmp_path / 'big_out_streamed.nc', 'rb').read()
     # same data bytes; the streamed header may be followed by free space
