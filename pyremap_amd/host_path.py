@@ -216,9 +216,14 @@ class OnDevice:
     """
 
     def __init__(self, y_d, out_shape):
+        torch = engine._torch()
         self._y_d = y_d
         self._out_shape = out_shape
         self._done = None
+        # the launch that produces y_d sits on the stream that is current
+        # NOW; result() may be called under another one
+        self._ready = torch.cuda.Event()
+        self._ready.record(torch.cuda.current_stream(y_d.device))
 
     def result(self):
         if self._done is not None:
@@ -228,8 +233,11 @@ class OnDevice:
         with torch.cuda.device(y_d.device):
             out_h, pinned = _host_buffer(self._out_shape, torch.float64)
             try:
+                stream = torch.cuda.current_stream(y_d.device)
+                stream.wait_event(self._ready)
                 out_h.copy_(y_d, non_blocking=True)
-                torch.cuda.current_stream(y_d.device).synchronize()
+                y_d.record_stream(stream)
+                stream.synchronize()
             except BaseException:
                 _release_pinned(pinned)
                 raise
@@ -312,7 +320,7 @@ def remap_host_array(plan, dst_grid_dims, values, remap_axes, *, mode,
                     plan, dst_grid_dims, x_d, remap_axes, emode,
                     threshold=thr if emode == engine.MODE_MASKED else 0.0,
                     flags=flags)
-        return OnDevice(y_d, out_shape)
+            return OnDevice(y_d, out_shape)
     with torch.cuda.device(device):
         out_h, pin_o = _host_buffer(out_shape, torch.float64)
         mask_h, pin_m = _host_buffer(out_shape, torch.uint8) \

@@ -145,9 +145,12 @@ def _validate_mapping(info, src_descriptor, dst_descriptor):
 #: group over the same few mapping files; the second one finds its weights
 #: on the device (the reference re-reads and re-sorts per Remapper,
 #: remap_numpy.py:87-137).  Environment: PYREMAP_AMD_PLAN_CACHE = number of
-#: plans kept (default 4; 0 disables).
+#: plans kept (default 4; 0 disables).  Mappings of more than
+#: ``_PLAN_CACHE_MAX_NNZ`` entries (their plans hold GBs of HBM) are not kept
+#: alive behind the Remapper's back.
 _PLAN_CACHE = {}
 _PLAN_CACHE_SIZE = int(os.environ.get('PYREMAP_AMD_PLAN_CACHE', 4))
+_PLAN_CACHE_MAX_NNZ = 20_000_000
 
 
 def _plan_cache_key(remapper):
@@ -210,7 +213,7 @@ def _load_mapping(remapper):
         remapper.schedule = plan.auto_schedule(info.dst_grid_dims)
     remapper._matrix = plan
     remapper._ds_map = info
-    if key is not None:
+    if key is not None and getattr(plan, 'nnz', 0) <= _PLAN_CACHE_MAX_NNZ:
         _PLAN_CACHE[key] = (info, plan, remapper.schedule)
         while len(_PLAN_CACHE) > _PLAN_CACHE_SIZE:
             _PLAN_CACHE.pop(next(iter(_PLAN_CACHE)))
