@@ -1345,9 +1345,10 @@ def remap_tensor(plan, dst_grid_dims, field, remap_axes, mode, threshold=0.0,
         Y = torch.empty(full_shape, dtype=torch.float64, device=X.device)
         mask = torch.empty(full_shape, dtype=torch.uint8,
                            device=X.device) if want_mask else None
-        Xl = X.reshape(lead_n, -1)
-        Yl = Y.reshape(lead_n, -1)
-        Ml = mask.reshape(lead_n, -1) if want_mask else None
+        per_x, per_y = ny * M * nx * T, _prod(dst_shape) * M * T
+        Xl = X.reshape(lead_n, per_x)
+        Yl = Y.reshape(lead_n, per_y)
+        Ml = mask.reshape(lead_n, per_y) if want_mask else None
         for li in range(lead_n):
             apply_strided(
                 plan, Xl[li], Yl[li], n_batch=M, k_inner=T,

@@ -270,3 +270,51 @@ def test_non_adjacent_source_axes_in_place(dev, monkeypatch):
                                       want_mask)
                 lead = int(np.prod(shape[:axes[0]], dtype=np.int64))
                 assert len(calls) == lead and all(c[2] == 40 for c in calls)
+
+
+def test_empty_shapes_through_every_layout(dev):
+    """Empty inputs (the reference's edge cases: no time slices, no levels,
+    nothing between two source axes) give empty outputs of the right shape
+    on every layout path, without a launch and without an error."""
+    from pyremap_amd import DataArray, Dataset, Remapper, engine, synthetic
+    m = synthetic.conservative_map(3000, (30, 40), 1, 6, seed=3, device=dev,
+                                   locality='mesh')
+    plan = engine.RemapPlan.from_triplets(m.row, m.col, m.S, m.frac_b,
+                                          m.n_a, m.n_b, device=dev)
+    plan.auto_schedule(m.dst_dims)
+    for shape, axes, want in (((0, 3000), [1], (0, 30, 40)),
+                              ((2, 3000, 0), [1], (2, 30, 40, 0)),
+                              ((0, 3000, 5), [1], (0, 30, 40, 5)),
+                              ((3000, 0), [0], (30, 40, 0)),
+                              ((5, 0, 3000), [2], (5, 0, 30, 40))):
+        x = torch.randn(shape, device=dev, dtype=torch.float64)
+        for mode in (engine.MODE_FRACB, engine.MODE_MASKED):
+            y, mask = engine.remap_tensor(plan, m.dst_dims, x, axes, mode,
+                                          threshold=0.1, want_mask=True)
+            assert tuple(y.shape) == tuple(mask.shape) == want
+    mb = synthetic.bilinear_map((10, 12), (20, 24), device=dev)
+    pb = engine.RemapPlan.from_triplets(mb.row, mb.col, mb.S, mb.frac_b,
+                                        mb.n_a, mb.n_b, device=dev)
+    pb.auto_schedule(mb.dst_dims)
+    for shape, axes, want in (((10, 0, 12), [0, 2], (20, 24, 0)),
+                              ((0, 10, 3, 12), [1, 3], (0, 20, 24, 3)),
+                              ((2, 10, 3, 12, 0), [1, 3], (2, 20, 24, 3, 0))):
+        x = torch.randn(shape, device=dev, dtype=torch.float64)
+        y = engine.remap_tensor(pb, mb.dst_dims, x, axes, engine.MODE_FRACB)
+        assert tuple(y.shape) == want
+    torch.cuda.synchronize()
+
+    class Desc:
+        pass
+    s, d = Desc(), Desc()
+    s.dims, s.dim_sizes = ['nCells'], [m.n_a]
+    d.dims, d.dim_sizes = ['lat', 'lon'], list(m.dst_dims)
+    d.coords, d.mesh_name = {}, 'g'
+    mm = m.numpy()
+    r = Remapper.from_triplets(mm['row'], mm['col'], mm['S'], mm['frac_b'],
+                               s, d, device=dev)
+    out = r.remap_numpy(Dataset({'a': DataArray(
+        np.zeros((0, m.n_a)), dims=('Time', 'nCells'))}), 0.1)
+    assert out['a'].shape == (0, 30, 40)
+    got = r.remap_array(np.zeros((0, m.n_a)), [1], 0.1)
+    assert got.shape == (0, 30, 40)
