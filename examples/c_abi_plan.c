@@ -133,6 +133,34 @@ int main(void)
     printf("%s (ABI %d): %lld triplets -> %lld entries, schedule family %d, "
            "%d x %d values, %d differ\n", remap_arch(), remap_abi_version(),
            (long long)n_s, (long long)info.nnz, info.family, NB, K, bad);
+
+    /* the same fields laid out (Time, nCells) -- MPAS's 2-D time series, the
+     * reference's most common input, which it flattens with a transpose copy
+     * (remap_numpy.py:254-256).  Here: addressed in place, n_batch = Time,
+     * k_inner = 1, through the LDS-staged lanes-across-rows kernel once its
+     * patch plan has been prepared; the output is (Time, lat, lon). */
+    static double Xt[K * NA], Yt[K * NB];
+    for (int a = 0; a < NA; ++a)
+        for (int k = 0; k < K; ++k)
+            Xt[k * NA + a] = X[a * K + k];
+    CHECK_REMAP(remap_plan_prepare_short_runs(plan, NULL));
+    CHECK_HIP(hipMemcpy(dX, Xt, sizeof(Xt), hipMemcpyHostToDevice));
+    f.n_batch = K;
+    f.k_inner = 1;
+    f.x_row_stride = f.y_row_stride = 1;
+    f.x_batch_stride = NA;
+    f.y_batch_stride = NB;
+    CHECK_REMAP(remap_plan_apply(plan, &f, NULL));
+    CHECK_HIP(hipMemcpy(Yt, dY, sizeof(Yt), hipMemcpyDeviceToHost));
+    int bad_t = 0;
+    for (int i = 0; i < NB; ++i)
+        for (int k = 0; k < K; ++k) {
+            const double y = Yt[k * NB + i], r = ref[i * K + k];
+            if (!(isnan(y) && isnan(r)) && memcmp(&y, &r, 8) != 0)
+                ++bad_t;
+        }
+    printf("(Time = %d, nCells) in place: %d differ\n", K, bad_t);
+    bad += bad_t;
     remap_plan_destroy(plan);
     hipFree(dX);
     hipFree(dY);

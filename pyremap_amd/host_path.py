@@ -282,8 +282,12 @@ def remap_host_array(plan, dst_grid_dims, values, remap_axes, *, mode,
     dst_shape = [int(d) for d in dst_grid_dims] \
         if dst_grid_dims is not None and plan.n_b == plan.n_b_global \
         else [plan.n_b]
+    # (remap_numpy.py:280-295: the destination dims take the place of the
+    # first source axis, every other non-source dim keeps its order -- also
+    # the ones BETWEEN two source axes)
     out_shape = list(values.shape[:lead]) + dst_shape + \
-        list(values.shape[lead + len(remap_axes):])
+        [int(values.shape[ax]) for ax in range(lead, values.ndim)
+         if ax not in remap_axes]
 
     if mode == 'auto' and host_mask is None and values.dtype.kind == 'f' \
             and values.nbytes >= 4 * CHUNK_BYTES and _sampled_nan(values):

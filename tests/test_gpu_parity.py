@@ -2152,3 +2152,4 @@ def test_c_abi_from_plain_c(tmp_path):
     proc = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert proc.returncode == 0, proc.stdout + proc.stderr
     assert ' 0 differ' in proc.stdout and 'gfx950' in proc.stdout
+    assert 'nCells) in place: 0 differ' in proc.stdout

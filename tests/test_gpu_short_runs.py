@@ -270,6 +270,15 @@ def test_non_adjacent_source_axes_in_place(dev, monkeypatch):
                                       want_mask)
                 lead = int(np.prod(shape[:axes[0]], dtype=np.int64))
                 assert len(calls) == lead and all(c[2] == 40 for c in calls)
+                # numpy in -> numpy out (the dims BETWEEN the source axes
+                # keep their place behind the destination dims)
+                from pyremap_amd import host_path
+                got, gmask = host_path.remap_host_array(
+                    plan, m.dst_dims, x, axes,
+                    mode='fracb' if thr is None else 'masked',
+                    threshold=thr, want_mask=True).result()
+                assert_bitwise(got, ref, f'host {shape} {axes}')
+                assert np.array_equal(gmask, want_mask)
 
 
 def test_empty_shapes_through_every_layout(dev):

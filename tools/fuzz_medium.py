@@ -51,6 +51,9 @@ def one(seed, dev):
     rowptr, col, val = plan.to_host_csr()
     csr = oracle.OracleCSR(rowptr, col, val, (m.n_b, m.n_a))
     frac_b = m.frac_b.cpu().numpy()
+    src2d = None
+    if kind == 'bilinear':
+        src2d = m.src_dims
     multi = None
     if seed % 3 == 0:
         from pyremap_amd.parallel import MultiDeviceRemap
@@ -58,6 +61,41 @@ def one(seed, dev):
                                  grid_dims=m.dst_dims)
     for case in range(4):
         pick = rng.random()
+        if src2d is not None and case == 3:
+            # two source axes with other dims BETWEEN them, in place
+            ny, nx = src2d
+            lead = [int(rng.integers(1, 3))] if rng.random() < 0.5 else []
+            between = [int(rng.integers(1, 9))]
+            tail = [int(rng.integers(1, 5))] if rng.random() < 0.5 else []
+            shape = lead + [ny] + between + [nx] + tail
+            axes2 = [len(lead), len(lead) + 2]
+            dtype = rng.choice([np.float64, np.float32])
+            field = rng.standard_normal(shape).astype(dtype)
+            masked = bool(rng.random() < 0.5)
+            thr = None
+            arg = field
+            if masked:
+                field[rng.random(shape) < 0.1] = np.nan
+                thr = float(rng.choice([0.0, 0.05, 0.5]))
+                arg = np.ma.masked_array(field, mask=np.isnan(field))
+            ref = oracle.remap_numpy_array(csr, frac_b, m.dst_dims, arg,
+                                           axes2, thr)
+            ref = np.ma.filled(ref.astype(np.float64), np.nan) \
+                if np.ma.isMaskedArray(ref) else np.asarray(ref)
+            what = (f'seed {seed} case {case}: non-adjacent {shape} '
+                    f'{np.dtype(dtype).name} masked={masked}')
+            y = engine.remap_tensor(
+                plan, m.dst_dims, torch.from_numpy(field).to(dev), axes2,
+                engine.MODE_MASKED if masked else engine.MODE_FRACB,
+                threshold=thr or 0.0)
+            assert_bitwise(y.cpu().numpy(), ref, what)
+            # ... and from / to host arrays
+            from pyremap_amd import host_path
+            got = host_path.remap_host_array(
+                plan, m.dst_dims, field, axes2,
+                mode='masked' if masked else 'fracb', threshold=thr).result()
+            assert_bitwise(got, ref, what + ' host')
+            continue
         if pick < 0.3:
             shape, axis = [m.n_a, int(rng.choice([40, 61, 128, 200, 257]))], 0
         elif pick < 0.5:
@@ -95,6 +133,13 @@ def one(seed, dev):
                 f'{np.dtype(dtype).name} masked={masked} thr {thr}')
         assert tuple(y.shape) == ref.shape, what
         assert_bitwise(y.cpu().numpy(), ref, what)
+        if case == 1:
+            # the same through the host-array path (numpy in, numpy out)
+            from pyremap_amd import host_path
+            got = host_path.remap_host_array(
+                plan, m.dst_dims, field, [axis],
+                mode='masked' if masked else 'fracb', threshold=thr).result()
+            assert_bitwise(got, ref, what + ' host')
         r = int(rng.integers(0, 3))
         shard = plan.shard(r, 3)
         shard.auto_schedule(m.dst_dims)
