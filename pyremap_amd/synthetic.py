@@ -248,7 +248,7 @@ def conservative_map(n_a, dst_dims, k_lo, k_hi, seed=0, device='cpu',
             col = torch.cat([col, orphan])
             S = torch.cat([S, w])
 
-    if locality == 'mesh':
+    if locality == 'mesh' and int(ocean.sum()) > 0:
         # same overlaps, the source cells numbered as a mesh generator
         # numbers them: a column permutation of the 'raster' matrix
         ocean_rows = ocean.nonzero().squeeze(1)

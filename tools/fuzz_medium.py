@@ -162,6 +162,76 @@ def one(seed, dev):
             assert_bitwise(ym.cpu().numpy(), ref, what + ' multi-device')
 
 
+def dataarray_level(seed, dev):
+    """`Remapper.remap_numpy(DataArray)` on random dims orders and dtypes --
+    the xarray-level bookkeeping of remap_numpy.py:150-220 (which dims the
+    result has, where the destination dims go, float64 out, masked iff a NaN
+    and a threshold) -- against the oracle's array-level result."""
+    from pyremap_amd import DataArray, Remapper
+    rng = np.random.default_rng(77_000 + seed)
+    two_d = bool(rng.random() < 0.5)
+    if two_d:
+        m = synthetic.bilinear_map((int(rng.integers(8, 30)),
+                                    int(rng.integers(8, 30))),
+                                   (int(rng.integers(10, 60)),
+                                    int(rng.integers(10, 60))), seed=seed,
+                                   device=dev)
+        src_dims = ['y', 'x']
+    else:
+        m = synthetic.conservative_map(
+            int(rng.integers(500, 5000)),
+            (int(rng.integers(10, 60)), int(rng.integers(10, 60))), 1, 6,
+            seed=seed, device=dev,
+            locality=str(rng.choice(['raster', 'mesh'])))
+        src_dims = ['nCells']
+
+    class Desc:
+        pass
+    src, dst = Desc(), Desc()
+    src.dims, src.dim_sizes = src_dims, list(m.src_dims)
+    dst.dims, dst.dim_sizes = ['lat', 'lon'], list(m.dst_dims)
+    dst.coords, dst.mesh_name = {}, 'fuzz'
+    mm = m.numpy()
+    r = Remapper.from_triplets(mm['row'], mm['col'], mm['S'], mm['frac_b'],
+                               src, dst, device=dev)
+    csr = oracle.coo_to_csr(mm['row'] - 1, mm['col'] - 1, mm['S'], m.n_b,
+                            m.n_a)
+    for case in range(4):
+        n_extra = int(rng.integers(0, 4))
+        extras = [(f'e{i}', int(rng.integers(1, 7))) for i in range(n_extra)]
+        # the source dims keep their relative order; extras go anywhere
+        dims = list(zip(src_dims, m.src_dims))
+        for e in extras:
+            dims.insert(int(rng.integers(0, len(dims) + 1)), e)
+        names = [d[0] for d in dims]
+        shape = [int(d[1]) for d in dims]
+        kind = rng.choice(['f8', 'f4', 'i4'])
+        if kind == 'i4':
+            data = rng.integers(-50, 50, size=shape).astype(np.int32)
+        else:
+            data = rng.standard_normal(shape).astype(kind)
+            if rng.random() < 0.5:
+                data[rng.random(shape) < 0.1] = np.nan
+        thr = None if rng.random() < 0.4 else \
+            float(rng.choice([0.0, 0.1, 0.6]))
+        out = r.remap_numpy(DataArray(data, dims=names, name='v'), thr)
+        axes = [names.index(d) for d in src_dims]
+        has_nan = data.dtype.kind == 'f' and bool(np.isnan(data).any())
+        arg = np.ma.masked_array(data, np.isnan(data)) if has_nan else data
+        ref = oracle.remap_numpy_array(csr, mm['frac_b'], m.dst_dims, arg,
+                                       axes, thr)
+        ref = np.ma.filled(np.ma.masked_array(ref).astype(np.float64),
+                           np.nan)
+        first = axes[0]
+        want_dims = names[:first] + ['lat', 'lon'] + \
+            [d for d in names[first:] if d not in src_dims]
+        what = (f'seed {seed} DataArray {list(zip(names, shape))} {kind} '
+                f'thr {thr} nan {has_nan}')
+        assert list(out.dims) == want_dims, what
+        assert out.values.dtype == np.float64, what
+        assert_bitwise(out.values, ref, what)
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 480.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
@@ -170,6 +240,7 @@ def main():
     while time.time() - t0 < budget and len(bad) < 4:
         try:
             one(seed, dev)
+            dataarray_level(seed, dev)
             n += 1
         except Exception as exc:   # noqa: BLE001 - reported
             print('SEED', seed, 'FAILED', type(exc).__name__, str(exc)[:400])
