@@ -491,7 +491,7 @@ int remap_plan_create(int64_t n_b, int64_t n_a, int64_t n_s,
  * Optional, once per plan, before fields whose contiguous run behind the
  * source axes is short and that come in several batches -- (Time, nCells),
  * MPAS's 2-D time series, the reference's most common input
- * (tests/test_interpolate.py:57-59; k_inner < 8 and n_batch > 1): builds the
+ * (tests/test_interpolate.py:57-59; k_inner < 4 and n_batch > 1): builds the
  * patch plan of the LDS-staged lanes-across-rows kernel (16 x 16 tiles of the
  * destination grid, halved until no patch references more than 512 distinct
  * source cells), which remap_plan_apply then uses for such fields.  Without

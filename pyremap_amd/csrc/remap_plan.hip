@@ -486,7 +486,7 @@ int remap_plan_apply(const remap_plan *plan, const remap_field *f,
     // fields whose contiguous run behind the source axes is short, in
     // several batches -- (Time, nCells) -- take the LDS-staged
     // lanes-across-rows kernel when its patch plan has been prepared
-    if (plan->cell_arena && f->k_inner < 8 && f->n_batch > 1 &&
+    if (plan->cell_arena && f->k_inner < 4 && f->n_batch > 1 &&
         f->n_batch * f->k_inner >= 2) {
         a.row_order = plan->cell_order;
         a.patch_ptr = plan->cell_ptr;

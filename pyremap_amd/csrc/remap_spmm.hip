@@ -586,14 +586,19 @@ KParams base_params(const remap_apply_args *a, const Call &c)
     return p;
 }
 
-// Fields whose contiguous run behind the source axes is shorter than one
-// 64-byte half line and that come in several batches -- (Time, nCells),
-// (Time, nCells, 3) -- are served by the lanes-across-rows kernel.
+// Fields whose contiguous run behind the source axes is at most 3 elements
+// and that come in several batches -- (Time, nCells), (Time, nCells, 3) --
+// are served by the lanes-across-rows kernels.  Measured on config 3's map,
+// (T, nCells, L) with T * L = 512, fraction of 8 TB/s, patchcell / rowgroup:
+// L = 2 0.351 / 0.070, 3 0.230 / 0.096, 4 0.171 / 0.186, 6 0.096 / 0.192,
+// 7 0.079 / 0.176, 8 - / 0.387: from 4 elements on the lanes-across-K
+// kernels win (the 8 fields a lane of patchcell owns then straddle batches
+// and its 8-byte Y stores lie 8 * L bytes apart).
 bool short_runs(const remap_apply_args *a)
 {
     // (two non-adjacent source axes: only the lanes-across-rows kernels
     // address a cell through two strides)
-    return (a->k_inner < 8 && a->n_batch > 1) || a->x_src_fold != 0;
+    return (a->k_inner < 4 && a->n_batch > 1) || a->x_src_fold != 0;
 }
 
 // REMAP_FLAG_TUNE_HINT: can the preferred family serve this call?

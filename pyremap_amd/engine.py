@@ -1159,7 +1159,7 @@ def apply_strided(plan, X, Y, *, n_batch, k_inner, x_row_stride,
     # short contiguous runs in several batches -- (Time, nCells) -- go to the
     # LDS-staged lanes-across-rows kernel on its own patch plan
     cell = whole and not tune and \
-        ((k_inner < 8 and n_batch > 1) or x_src_fold) and \
+        ((k_inner < 4 and n_batch > 1) or x_src_fold) and \
         n_batch * k_inner >= 2 and plan.cell_patches() is not None
     args = plan._prefilled(whole, cell)
     if cell:

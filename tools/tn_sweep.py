@@ -45,6 +45,9 @@ def main():
                     help='fields per lane to try (default 4,8,16; 8 with '
                          '--only patch)')
     ap.add_argument('--time', type=int, default=120, dest='n_time')
+    ap.add_argument('--levels', default='',
+                    help="'T:L,T:L': (T, n_a, L) shapes instead of the "
+                         "default list")
     ap.add_argument('--sets', type=int, default=1,
                     help='distinct X buffers rotated over the launches '
                          '(>= 3 x 200 MB: Infinity-Cache-cold)')
@@ -65,10 +68,14 @@ def main():
     if args.only == 'patch':
         shapes = [(args.n_time, m.n_a)]
         variants = []
+    if args.levels:
+        shapes = [(int(t), m.n_a, int(lv)) for t, lv in
+                  (v.split(':') for v in args.levels.split(','))]
     variants = [('auto', None)] + [
         (f'rowcell tt={tt} unr={u}', [4, tt, u])
         for tt in (4, 8, 16) for u in (1, 2, 4)
-        if (tt, u) not in ((4, 1), (16, 4))] + [('rowlane', [2])]
+        if (tt, u) not in ((4, 1), (16, 4))] + [('rowlane', [2]),
+                                                ('rowgroup', [10])]
     for shape in shapes:
         x = torch.randn(shape, generator=g, device=dev, dtype=torch.float64)
         if args.mode == 'masked':
