@@ -274,6 +274,7 @@ def prepare(name, args, rank, world, dist, K=None, mode=None, layout=None,
     torch.cuda.synchronize()
     w.plan_s = time.perf_counter() - t0
     w.dtype = dtype
+    w.times = times
     w.fields = make_fields(m.n_a, w.K_local, w.layout, w.sets, 1234, device,
                            nan_frac=0.25 if w.mode == 'masked' else 0.0,
                            dtype=dtype, times=times)
@@ -648,6 +649,9 @@ def extras_todo(args, world):
             ('layout_T8_nCells_L64', dict(name='config3', layout='tnl'), 50),
             ('layout_T8_nCells_L60', dict(name='config3', layout='tnl',
                                           K=480), 50),
+            # short level runs (10 soil / ice layers): small LDS patches
+            ('layout_T48_nCells_L10', dict(name='config3', layout='tnl',
+                                           K=480, times=48), 30),
             ('masked', dict(name='config3', mode='masked'), 50),
         ]
     return [('masked', dict(name='config3', mode='masked'), 50)]
@@ -718,6 +722,7 @@ def measure_extras(ready, args, dist, extra, long_last=True):
             extra[tag] = {k: r[k] for k in EXTRA_KEYS}
             extra[tag]['steps'] = steps
             extra[tag]['dtype'] = w.dtype
+            extra[tag]['times'] = getattr(w, 'times', 8)
             extra[tag]['frac_of_peak'] = r['achieved_GBps'] / HBM_PEAK_GBPS
             extra[tag]['read_frac_of_peak'] = r['bytes_alg_read'] / (
                 r['kernel_ms_mean'] * 1e-3) / 1e9 / HBM_PEAK_GBPS
@@ -749,6 +754,8 @@ def workload_rows(extra):
             'K': e['K'], 'mode': e['mode'], 'layout': e['layout'],
             'dtype': e.get('dtype', 'f64'), 'numbering': e['locality'],
             'kernel': 'spmm_patchcell' if e['layout'] == 'tn' else
+            'spmm_patch' if e['layout'] == 'tnl' and
+            4 <= e['K'] // e.get('times', 8) < 16 else
             'spmm_rowlane' if e['K'] <= 32 else
             KERNEL_OF_FAMILY.get(sched.get('family'), 'spmm_*'),
         }

@@ -394,6 +394,9 @@ class RemapPlan:
         #: lazily built patch plan for the lanes-across-rows kernel that
         #: serves (Time, nCells)-like layouts (see cell_patches)
         self._cell = None
+        #: lazily built small LDS patches for fields with short level runs
+        #: (see run_patches)
+        self._runs = None
         # schedule attributes are properties: every assignment invalidates
         # the prefilled argument block launches start from (_prefilled)
         self._sched_version = 0
@@ -444,7 +447,7 @@ class RemapPlan:
         args.A.csr_pad = self.csr_pad
         order = self.row_order
         if whole and cell:
-            q = self._cell
+            q = self._runs if cell == 'runs' else self._cell
             args.row_order = q['order'].data_ptr() \
                 if q['order'] is not None else None
             args.patch_ptr = q['ptr'].data_ptr()
@@ -824,6 +827,33 @@ class RemapPlan:
     #: workgroups share a CU and overlap staging with compute
     CELL_UMAX = 512
 
+    def run_patches(self):
+        """
+        Small LDS patches (4 x 8 tiles of the destination grid, 32
+        consecutive rows of a 1-D one) for ``(Time, nCells, L)`` fields with
+        SHORT level runs, 4 <= L < 16, on mappings whose own schedule is the
+        row groups: there every (source row, batch) is a separate 32-120 byte
+        run, the row-group kernel pays a line fetch per run and ENTRY, the
+        LDS patch kernel (family 5) one per run and DISTINCT source row
+        (config 3's map, fraction of 8 TB/s, groups / patches: L = 4 0.19 /
+        0.27, 6 0.19 / 0.27, 8 0.39 / 0.45, 10 0.28 / 0.38, 12 0.34 / 0.41;
+        from L = 16 the groups win, 0.60 / 0.55).  Built on first use;
+        ``None`` when there is nothing to build.
+        """
+        if self._runs is None:
+            dims = self._grid_dims
+            if dims is not None and len(dims) != 2:
+                dims = None
+
+            def fits(rows, umax, emax):
+                return (umax + 1) * 1024 + emax * 12 + rows * 24 + 32 <= \
+                    100 * 1024 or rows <= 4
+            q = self._make_patches(dims, (4, 8) if dims is not None
+                                   else (1, 32), fits, 1024)
+            self._runs = q if q is not None else False
+            self._sched_version += 1
+        return self._runs or None
+
     def cell_patches(self):
         """
         The patch plan of kernel family 7 (``spmm_patchcell``), which serves
@@ -930,6 +960,7 @@ class RemapPlan:
         self.default_tune = None
         self._arena = None
         self._cell = None
+        self._runs = None
         self._grid_dims = None
         if grid_dims is None or self.nnz == 0 or self.n_b == 0:
             return {'family': 'rowscalar', 'reason': 'no destination grid'}
@@ -1161,8 +1192,17 @@ def apply_strided(plan, X, Y, *, n_batch, k_inner, x_row_stride,
     cell = whole and not tune and \
         ((k_inner < 4 and n_batch > 1) or x_src_fold) and \
         n_batch * k_inner >= 2 and plan.cell_patches() is not None
+    # short level runs in several batches -- (Time, nCells, 4 ... 15) -- on
+    # a row-group mapping: small LDS patches (RemapPlan.run_patches)
+    if not cell and whole and not tune and n_batch > 1 and \
+            4 <= k_inner < 16 and n_batch * k_inner >= 64 and \
+            plan.patches is None and plan.run_patches() is not None:
+        cell = 'runs'
     args = plan._prefilled(whole, cell)
-    if cell:
+    if cell == 'runs':
+        tune = [5]
+        flags |= FLAG_TUNE_HINT
+    elif cell:
         # fields per lane: 8 (4 for a handful of fields: more workgroups);
         # (12, nCells): 22.1 / 22.4 us with 4 / 8, (60, 3.7 M cells): 1.36 /
         # 1.16 ms

@@ -128,6 +128,24 @@ def main():
             ratio = plan.build_patches(m.dst_dims, tile=(ty, tx),
                                        lds_budget=10 ** 9)
             plan.default_tune = None
+            if plan.patches['umax'] * 1024 + plan.patches['emax'] * 12 \
+                    < 150 * 1024:
+                # the LDS patch kernel of family 5 (lanes across K)
+                def run5():
+                    i = turn[0] = (turn[0] + 1) % args.sets
+                    outs[i] = engine.remap_tensor(
+                        plan, m.dst_dims, xs[i], [1], mode, threshold=0.01,
+                        tune=[5], out=outs[i])
+                    return outs[i]
+                y = run5()
+                same = bool(((y == want) |
+                             (y.isnan() & want.isnan())).all())
+                t = timed(run5, args.reps)
+                print(f'   patch (family 5) {tile} umax='
+                      f'{plan.patches["umax"]:5d}          '
+                      f'{t * 1e3:8.1f} us  '
+                      f'{bytes_alg / t / 1e6 / 8000:.3f}  '
+                      f'{"bitwise" if same else "DIFFERS"}')
             for tt in (tuple(int(v) for v in args.tts.split(',')) if args.tts
                        else (8,) if args.only == 'patch' else (4, 8, 16)):
                 if plan.patches['umax'] * tt * 8 > 150 * 1024:
