@@ -48,6 +48,8 @@ def main():
     ap.add_argument('--levels', default='',
                     help="'T:L,T:L': (T, n_a, L) shapes instead of the "
                          "default list")
+    ap.add_argument('--no-cell', action='store_true',
+                    help='skip the lanes-across-rows variants (long runs)')
     ap.add_argument('--sets', type=int, default=1,
                     help='distinct X buffers rotated over the launches '
                          '(>= 3 x 200 MB: Infinity-Cache-cold)')
@@ -76,6 +78,8 @@ def main():
         for tt in (4, 8, 16) for u in (1, 2, 4)
         if (tt, u) not in ((4, 1), (16, 4))] + [('rowlane', [2]),
                                                 ('rowgroup', [10])]
+    if args.no_cell:
+        variants = [('auto', None), ('rowgroup', [10])]
     for shape in shapes:
         x = torch.randn(shape, generator=g, device=dev, dtype=torch.float64)
         if args.mode == 'masked':
@@ -146,8 +150,9 @@ def main():
                       f'{t * 1e3:8.1f} us  '
                       f'{bytes_alg / t / 1e6 / 8000:.3f}  '
                       f'{"bitwise" if same else "DIFFERS"}')
-            for tt in (tuple(int(v) for v in args.tts.split(',')) if args.tts
-                       else (8,) if args.only == 'patch' else (4, 8, 16)):
+            for tt in () if args.no_cell else (
+                    tuple(int(v) for v in args.tts.split(',')) if args.tts
+                    else (8,) if args.only == 'patch' else (4, 8, 16)):
                 if plan.patches['umax'] * tt * 8 > 150 * 1024:
                     continue
 
