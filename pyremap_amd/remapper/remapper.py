@@ -137,8 +137,9 @@ class Remapper:
         weight generation for unstructured meshes is outside this engine's
         scope.  ``map_tool='analytic'`` (an addition) covers what has a closed
         form: ``conserve`` / ``bilinear`` / ``neareststod`` between two
-        lat-lon grids, or two grids of one projection
-        (:mod:`pyremap_amd.weights`).  The file is written to
+        lat-lon grids, or two grids of one projection, and ``bilinear`` from
+        an MPAS mesh (cells, edges or vertices, given by its mesh file) to
+        anything -- ESMF's weights, reproduced (:mod:`pyremap_amd.weights`).  The file is written to
         ``map_filename`` (default name as in ``setup.py:29-42``).
         """
         from pyremap_amd.remapper.setup import _setup_remapper
@@ -147,7 +148,8 @@ class Remapper:
                 'pyremap_amd applies existing mapping files on the GPU; '
                 'build the mapping file with ESMF_RegridWeightGen / mbtempest '
                 '(e.g. through pyremap) and pass it as map_filename, or use '
-                "map_tool='analytic' for lat-lon / projection grid pairs")
+                "map_tool='analytic' for lat-lon / projection grid pairs and "
+                "bilinear maps from an MPAS mesh")
         _setup_remapper(self)
         from pyremap_amd.weights import write_weights
         if logger is not None:

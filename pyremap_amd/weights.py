@@ -1,6 +1,7 @@
 """
-Analytic mapping weights for logically rectangular grids (SURVEY.md section 8
-f-4): users without ESMF / MOAB can build the simple maps themselves.
+Mapping weights without ESMF / MOAB: closed forms
+for logically rectangular grids, and ESMF's ``bilinear`` on the dual mesh
+when an MPAS mesh is the source.
 
 The reference generates weights only by shelling out to
 ``ESMF_RegridWeightGen`` or ``mbtempest`` (``pyremap/remapper/build_map.py``),
@@ -18,6 +19,14 @@ axes the common methods have closed forms:
   points beyond the first / last centre of a non-periodic axis (e.g. poleward
   of the last latitude row) take the nearest row.
 * ``neareststod`` -- nearest source centre per axis.
+
+* ``bilinear`` FROM an MPAS mesh (its cells, edges or vertices) -- linear
+  interpolation on the triangles of the dual mesh, located and weighted along
+  straight lines in 3-D, polygons cut into triangles by ESMF's ear-clipping
+  rule (:func:`clip_ears`): reproduces the outputs the reference's tests store
+  for ``test_mpas_{cell,edge,vertex}_to_latlon`` and
+  ``test_mpas_cell_to_stereographic`` to rounding, the unmapped cells
+  included.
 
 The result is a :class:`pyremap_amd.io.mapfile.MappingFile` with exactly the
 schema ESMF writes (1-based ``row``/``col``, Fortran-ordered grid dims), so it
@@ -263,6 +272,242 @@ def _to_points(src_descriptor, plat, plon, dst_dims, method):
         S[order], frac_b)
 
 
+# ---------------------------------------------------------------------------
+# an MPAS mesh as the SOURCE: linear interpolation on the dual mesh
+# ---------------------------------------------------------------------------
+
+def _unit(lat, lon):
+    return np.stack([np.cos(lat) * np.cos(lon), np.cos(lat) * np.sin(lon),
+                     np.sin(lat)], axis=-1)
+
+
+def clip_ears(xyz, poly, count):
+    """
+    Triangulate convex polygons the way ESMF does before it interpolates on
+    elements with more than four corners: repeatedly cut off the corner whose
+    two edge vectors have the LARGEST dot product (3-D Cartesian, not
+    normalised) until a triangle is left.  (Inferred from the outputs the
+    reference's tests store for `test_mpas_vertex_to_latlon` and
+    `test_mpas_edge_to_latlon`: of the 14 triangulations of each of the 7 088
+    hexagons that the stored values pin down, this rule picks the one ESMF
+    used, every time; fans and the other greedy measures -- angle, area,
+    diagonal -- do not.)
+
+    ``poly``: (n_poly, max_corners) node ids, the first ``count[i]`` of row i
+    valid, in order around the polygon (either orientation).  Returns the
+    triangles, (nt, 3) node ids.
+    """
+    poly = np.array(poly, dtype=np.int64)
+    count = np.array(count, dtype=np.int64)
+    keep = count >= 3
+    poly, count = poly[keep], count[keep]
+    out = []
+    width = poly.shape[1] if len(poly) else 0
+    slots = np.arange(width)
+    while len(poly):
+        done = count == 3
+        if done.any():
+            out.append(poly[done][:, :3])
+            poly, count = poly[~done], count[~done]
+            if not len(poly):
+                break
+        valid = slots[None, :] < count[:, None]
+        rows = np.arange(len(poly))[:, None]
+        prev = poly[rows, (slots[None, :] - 1) % count[:, None]]
+        nxt = poly[rows, (slots[None, :] + 1) % count[:, None]]
+        here = xyz[np.where(valid, poly, 0)]
+        dot = ((xyz[np.where(valid, prev, 0)] - here) *
+               (xyz[np.where(valid, nxt, 0)] - here)).sum(axis=-1)
+        dot[~valid] = -np.inf
+        ear = dot.argmax(axis=1)
+        r = np.arange(len(poly))
+        out.append(np.stack([prev[r, ear], poly[r, ear], nxt[r, ear]],
+                            axis=1))
+        # delete the ear: shift the corners behind it one slot left
+        shift = slots[None, :] >= ear[:, None]
+        poly = np.where(shift, poly[rows, np.minimum(slots + 1,
+                                                     width - 1)[None, :]],
+                        poly)
+        count = count - 1
+    return np.concatenate(out) if out else np.zeros((0, 3), dtype=np.int64)
+
+
+def _dual_triangles(descriptor):
+    """
+    The mesh ESMF interpolates on when an MPAS mesh is the source of a
+    ``bilinear`` map: the DUAL of the SCRIP cells the reference writes for it
+    -- nodes at the cells' centres, one element around every corner three or
+    more SCRIP cells share -- with elements of more than three corners cut
+    into triangles (:func:`clip_ears`):
+
+    * cells (``mpas_cell_mesh_descriptor.py:84-167``: corners = vertices):
+      the triangle of the three cell centres around every vertex;
+    * vertices (``mpas_vertex_mesh_descriptor.py:107-180``: corners = cell
+      centres and edge midpoints): the polygon of the vertices around every
+      cell;
+    * edges (``mpas_edge_mesh_descriptor.py:106-190``: corners = the two
+      vertices and the two cell centres): the triangle of the three edge
+      midpoints around every vertex and the polygon of the edge midpoints
+      around every cell.
+
+    Elements at the boundary of the mesh that lack a member (a land cell)
+    do not exist: destination points there stay unmapped.  Returns ``(xyz of
+    the nodes (n, 3), triangles (nt, 3) of 0-based node ids)``.
+    """
+    if getattr(descriptor, 'filename', None) is None:
+        raise ValueError(
+            'weights FROM an MPAS mesh need its mesh file (connectivity): '
+            'construct the descriptor with filename=')
+    from pyremap_amd.io.netcdf import open_dataset
+    kind = descriptor._dim
+    wanted = {'nCells': ['latCell', 'lonCell', 'cellsOnVertex'],
+              'nVertices': ['latVertex', 'lonVertex', 'verticesOnCell',
+                            'nEdgesOnCell'],
+              'nEdges': ['latEdge', 'lonEdge', 'edgesOnVertex',
+                         'cellsOnEdge', 'latCell', 'lonCell']}[kind]
+    ds = open_dataset(descriptor.filename, variables=wanted)
+    xyz = _unit(np.asarray(ds[wanted[0]].values, dtype=np.float64),
+                np.asarray(ds[wanted[1]].values, dtype=np.float64))
+    n = len(xyz)
+
+    def triples(name):
+        t = np.asarray(ds[name].values, dtype=np.int64)
+        if t.ndim != 2 or t.shape[1] != 3:
+            raise ValueError(f'{name}: a vertexDegree of 3 is needed')
+        return t[((t > 0) & (t <= n)).all(axis=1)] - 1
+
+    def polygons(name):
+        poly = np.asarray(ds[name].values, dtype=np.int64) - 1
+        count = np.asarray(ds['nEdgesOnCell'].values, dtype=np.int64)
+        whole = ((poly >= 0) & (poly < n)) | \
+            (np.arange(poly.shape[1])[None, :] >= count[:, None])
+        ok = whole.all(axis=1)
+        return clip_ears(xyz, poly[ok], count[ok])
+
+    def edges_around_cells():
+        # (the reference's edge descriptor needs cellsOnEdge only, and mesh
+        # files cut down to what it reads carry no edgesOnCell: the edges of
+        # a cell in order of their bearing from the cell centre)
+        coe = np.asarray(ds['cellsOnEdge'].values, dtype=np.int64) - 1
+        lat = np.asarray(ds['latCell'].values, dtype=np.float64)
+        lon = np.asarray(ds['lonCell'].values, dtype=np.float64)
+        edge = np.repeat(np.arange(len(coe)), 2)
+        cell = coe.reshape(-1)
+        keep = (cell >= 0) & (cell < len(lat))
+        edge, cell = edge[keep], cell[keep]
+        east = np.stack([-np.sin(lon), np.cos(lon), np.zeros_like(lon)], -1)
+        north = np.stack([-np.sin(lat) * np.cos(lon),
+                          -np.sin(lat) * np.sin(lon), np.cos(lat)], -1)
+        off = xyz[edge] - _unit(lat, lon)[cell]
+        bearing = np.arctan2((off * north[cell]).sum(-1),
+                             (off * east[cell]).sum(-1))
+        order = np.lexsort((bearing, cell))
+        edge, cell = edge[order], cell[order]
+        count = np.bincount(cell, minlength=len(lat))
+        start = np.cumsum(count) - count
+        poly = np.zeros((len(lat), max(int(count.max()), 3)), dtype=np.int64)
+        poly[cell, np.arange(len(cell)) - start[cell]] = edge
+        return clip_ears(xyz, poly, count)
+
+    if kind == 'nCells':
+        tri = triples('cellsOnVertex')
+    elif kind == 'nVertices':
+        tri = polygons('verticesOnCell')
+    else:
+        tri = np.concatenate([triples('edgesOnVertex'),
+                              edges_around_cells()])
+    return xyz, tri
+
+
+def locate_in_triangles(xyz, tri, points, tol=1e-12, chunk=1 << 18):
+    """
+    For every unit vector in ``points`` the spherical triangle (corners
+    ``xyz[tri]``) that holds it, with the weights of its corners: the
+    barycentric coordinates of the point's central projection onto the
+    triangle's plane (straight lines in 3-D -- ESMF's default ``cartesian``
+    line type for bilinear).  Returns ``(triangle index or -1, weights (n,
+    3))``.  A uniform hash grid over the triangle centroids, one cell as wide
+    as the longest triangle edge, bounds the candidates to the 27 cells
+    around the point.
+    """
+    corners = xyz[tri]                                    # (nt, 3, 3)
+    inv = np.linalg.inv(np.transpose(corners, (0, 2, 1)))  # columns a, b, c
+    cent = corners.sum(axis=1)
+    cent /= np.linalg.norm(cent, axis=1)[:, None]
+    edge = max(np.linalg.norm(corners[:, i] - corners[:, (i + 1) % 3],
+                              axis=1).max() for i in range(3))
+    h = float(min(max(edge, 1e-6), 2.0))
+    nb = int(np.ceil(2.0 / h)) + 2
+
+    def cell_of(p):
+        return np.floor((p + 1.0) / h).astype(np.int64) + 1
+
+    ck = cell_of(cent)
+    key = (ck[:, 0] * nb + ck[:, 1]) * nb + ck[:, 2]
+    order = np.argsort(key, kind='stable')
+    skey = key[order]
+    n = len(points)
+    found = np.full(n, -1, dtype=np.int64)
+    weights = np.zeros((n, 3))
+    offsets = [(a, b, c) for a in (-1, 0, 1) for b in (-1, 0, 1)
+               for c in (-1, 0, 1)]
+    for c0 in range(0, n, chunk):
+        q = points[c0:c0 + chunk]
+        qc = cell_of(q)
+        best = np.full(len(q), len(tri), dtype=np.int64)
+        for off in offsets:
+            k = ((qc[:, 0] + off[0]) * nb + qc[:, 1] + off[1]) * nb + \
+                qc[:, 2] + off[2]
+            lo = np.searchsorted(skey, k, side='left')
+            cnt = np.searchsorted(skey, k, side='right') - lo
+            total = int(cnt.sum())
+            if total == 0:
+                continue
+            qi = np.repeat(np.arange(len(q)), cnt)
+            ti = order[np.repeat(lo, cnt) + np.arange(total) -
+                       np.repeat(np.cumsum(cnt) - cnt, cnt)]
+            w = np.einsum('nij,nj->ni', inv[ti], q[qi])
+            tot = w.sum(axis=1)
+            with np.errstate(divide='ignore', invalid='ignore'):
+                w = w / tot[:, None]
+            inside = (tot > 0.0) & (w >= -tol).all(axis=1)
+            # one triangle per point, the lowest index (a point on a shared
+            # edge gets the same value from either side)
+            np.minimum.at(best, qi[inside], ti[inside])
+        hit = best < len(tri)
+        t = best[hit]
+        w = np.einsum('nij,nj->ni', inv[t], q[hit])
+        w = np.clip(w / w.sum(axis=1)[:, None], 0.0, None)
+        weights[c0:c0 + chunk][hit] = w / w.sum(axis=1)[:, None]
+        found[c0:c0 + chunk][hit] = t
+    return found, weights
+
+
+def _from_cell_mesh(src_descriptor, plat, plon, dst_dims, method):
+    """MPAS cells / edges / vertices -> points (radians): ``bilinear`` = linear
+    on the triangles of the dual mesh; destination points no triangle holds (land, the gaps at the
+    mesh boundary) stay unmapped, ``frac_b`` = 0, as ESMF leaves them."""
+    if method != 'bilinear':
+        raise ValueError(
+            f'from an MPAS mesh only bilinear has a closed form here, not '
+            f'{method!r} (conservative weights need polygon clipping: ESMF / '
+            f'MOAB)')
+    xyz, tri = _dual_triangles(src_descriptor)
+    found, w = locate_in_triangles(xyz, tri, _unit(plat, plon))
+    hit = np.nonzero(found >= 0)[0]
+    row = np.repeat(hit, 3)
+    col = tri[found[hit]].reshape(-1)
+    S = w[hit].reshape(-1)
+    order = np.lexsort((col, row))
+    frac_b = (found >= 0).astype(np.float64)
+    return MappingFile(
+        len(xyz), len(plat), np.array([len(xyz)], dtype=np.int32),
+        np.asarray(dst_dims, dtype=np.int32),
+        (row[order] + 1).astype(np.int32), (col[order] + 1).astype(np.int32),
+        S[order], frac_b)
+
+
+
 def _cell_centres(descriptor):
     """(lat, lon) in radians of every cell centre of a rectangular grid, in
     C order, and its Fortran-ordered dims."""
@@ -291,6 +536,12 @@ def build_weights(src_descriptor, dst_descriptor, method='conserve'):
     if method not in METHODS:
         raise ValueError(f'method {method!r}: expected one of {METHODS}')
     points = _points(dst_descriptor)
+    if isinstance(src_descriptor, MpasMeshDescriptor):
+        if points is not None:
+            return _from_cell_mesh(src_descriptor, points[0], points[1],
+                                   [len(points[0])], method)
+        lat, lon, dims = _cell_centres(dst_descriptor)
+        return _from_cell_mesh(src_descriptor, lat, lon, dims, method)
     if points is not None:
         return _to_points(src_descriptor, points[0], points[1],
                           [len(points[0])], method)

@@ -484,6 +484,106 @@ def test_reference_fixture_latlon_to_stereographic(tmp_path):
                    'ncremap vs remap_numpy')
 
 
+# the variables NCO adds and the reference's tests drop before comparing
+# (tests/test_interpolate.py:200-208)
+NCO_EXTRAS = ('lat_bnds', 'lon_bnds', 'gw', 'area', 'nvertices',
+              'lat_vertices', 'lon_vertices')
+
+
+def _assert_as_the_reference_does(ds, ds_ref, what):
+    """`assertDimsEqual` + `assertDatasetApproxEqual` of the reference's
+    tests/__init__.py:59-99 at ITS tolerances (rtol 1e-5, atol 1e-8) -- and,
+    stricter than the reference (which lets a NaN on either side pass), the
+    same cells masked."""
+    # (2-D lat / lon of a projection grid are coordinates to xarray -- the
+    # file names them in a `coordinates` attribute -- and to this package's
+    # result; the plain reader used for the stored file lists them as data)
+    ref_vars = [v for v in ds_ref.data_vars
+                if v not in NCO_EXTRAS and v not in ds.coords]
+    assert set(ds.data_vars) == set(ref_vars), what
+    for name in ds.coords:
+        if name in ds_ref.variables and \
+                ds_ref[name].values.dtype.kind == 'f':
+            assert np.allclose(ds[name].values, ds_ref[name].values,
+                               rtol=1e-5, atol=1e-8), (what, name)
+    for name in ref_vars:
+        assert set(ds[name].dims) == set(ds_ref[name].dims), (what, name)
+        got, want = ds[name].values, ds_ref[name].values
+        if got.dtype.kind in 'SU' or want.dtype.kind in 'SU':
+            continue
+        assert got.shape == want.shape, (what, name)
+        assert np.array_equal(np.isnan(got), np.isnan(want)), (what, name)
+        ok = ~np.isnan(want)
+        assert np.isclose(got[ok], want[ok], rtol=1e-5, atol=1e-8).all(), \
+            (what, name, np.abs(got[ok] - want[ok]).max())
+        # (in fact they agree to rounding: the weights ARE ESMF's)
+        assert np.isclose(got[ok], want[ok], rtol=1e-9, atol=0.0).all(), \
+            (what, name)
+
+
+@pytest.mark.parametrize('case', ['mpas_cell_to_latlon',
+                                  'mpas_edge_to_latlon',
+                                  'mpas_vertex_to_latlon',
+                                  'mpas_cell_to_stereographic'])
+def test_reference_fixture_mpas_source(tmp_path, case):
+    """
+    The reference's ``test_mpas_cell_to_latlon``, ``test_mpas_edge_to_latlon``,
+    ``test_mpas_vertex_to_latlon`` and ``test_mpas_cell_to_stereographic``
+    (tests/test_interpolate.py:418-545) replayed on ITS data files -- the real
+    QU240 mesh with its real cell numbering, one month of real MPAS-Ocean
+    output -- and checked against the outputs it stored, at its own
+    tolerances: ``build_map`` (bilinear weights on the dual mesh, as ESMF
+    makes them) -> ``ncremap(replace_mpas_fill=True)`` and
+    ``remap_numpy(ds, 0.01)`` on the GPU.
+    """
+    from pyremap_amd import (
+        LatLonGridDescriptor,
+        MpasCellMeshDescriptor,
+        MpasEdgeMeshDescriptor,
+        MpasVertexMeshDescriptor,
+        Remapper,
+        get_polar_descriptor,
+    )
+    from pyremap_amd.io.netcdf import open_dataset
+    gold = os.path.join(os.path.dirname(__file__), 'golden')
+    here = os.path.join(gold, 'ref_fixtures')
+    mesh = os.path.join(here, 'mpasMesh.nc')
+    kind = case.split('_')[1]
+    src = {'cell': MpasCellMeshDescriptor, 'edge': MpasEdgeMeshDescriptor,
+           'vertex': MpasVertexMeshDescriptor}[kind](mesh, mesh_name='oQU240')
+    in_filename = {
+        'cell': os.path.join(here, 'timeSeries.0002-01-01.nc'),
+        'edge': os.path.join(here, 'mpasAreaEdge.nc'),
+        'vertex': os.path.join(gold, 'hdf5', 'nc4_mpasAreaVertex.nc')}[kind]
+    if case.endswith('latlon'):
+        dst = LatLonGridDescriptor.read(
+            os.path.join(here, 'SST_annual_1870-1900.nc'),
+            lat_var_name='lat', lon_var_name='lon')
+    else:
+        dst = get_polar_descriptor(6000.0, 5000.0, 100.0, 100.0)
+    remapper = Remapper(ntasks=1, map_filename=str(tmp_path / 'weights.nc'),
+                        method='bilinear', map_tool='analytic',
+                        use_tmp=False, src_descriptor=src,
+                        dst_descriptor=dst)
+    remapper.build_map()
+    assert os.path.exists(remapper.map_filename)
+    ds_ref = open_dataset(os.path.join(here, f'ref_{case}.nc'))
+    out_filename = str(tmp_path / 'remapped.nc')
+    remapper.ncremap(in_filename=in_filename, out_filename=out_filename,
+                     replace_mpas_fill=True)
+    ds_file = open_dataset(out_filename)
+    _assert_as_the_reference_does(ds_file, ds_ref, 'ncremap')
+    ds_mem = remapper.remap_numpy(open_dataset(in_filename), 0.01)
+    _assert_as_the_reference_does(ds_mem, ds_ref, 'remap_numpy')
+    for name in ds_mem.data_vars:
+        if ds_mem[name].dtype.kind == 'f':
+            assert_bitwise(ds_file[name].values, ds_mem[name].values,
+                           f'ncremap vs remap_numpy: {name}')
+    # the land pattern is there (40 % of a global grid, none dropped)
+    some = next(n for n in ds_mem.data_vars if ds_mem[n].dtype.kind == 'f')
+    assert 0.2 < np.isnan(ds_mem[some].values).mean() < 0.7
+
+
 def test_examples_run(tmp_path, monkeypatch):
     """examples/: the stereographic -> stereographic script of the reference's
     examples directory (analytic weights) and the apply-a-mapping-file
