@@ -14,10 +14,13 @@ axes the common methods have closed forms:
   projection into (overlap in x) x (overlap in y).  ``frac_b`` = covered
   fraction of the destination cell (ESMF's ``destarea`` normalisation: weights
   of a fully covered cell sum to 1).
-* ``bilinear``  -- tensor-product linear interpolation between source cell
-  centres; periodic in longitude when the source grid is global; destination
-  points beyond the first / last centre of a non-periodic axis (e.g. poleward
-  of the last latitude row) take the nearest row.
+* ``bilinear``  -- ESMF's construction (:func:`bilinear_3d`): every
+  destination point is located in the quad of four neighbouring source cell
+  CENTRES, the corners joined by straight lines in 3-D, and takes the patch's
+  bilinear weights; a global lat-lon source closes in longitude and is capped
+  at either pole by a node that stands for the mean of the adjacent row.
+  Reproduces the outputs the reference's tests store (ESMF weights) to the
+  rounding of those files.
 * ``neareststod`` -- nearest source centre per axis.
 
 * ``bilinear`` FROM an MPAS mesh (its cells, edges or vertices) -- linear
@@ -209,9 +212,10 @@ def _to_points(src_descriptor, plat, plon, dst_dims, method):
     """
     Rectangular grid -> points given by latitude / longitude in radians (MPAS
     cell centres, point collections, or the cell centres of a grid of another
-    kind): the per-axis interpolation of the tensor case, one (y, x) pair per
-    destination point.  Points outside the hull of the source cell centres
-    (bilinear; outside the source cells for neareststod) are not mapped.
+    kind).  ``bilinear``: :func:`bilinear_3d` (ESMF's way); points no quad of
+    source centres -- or pole cap of a global source -- holds are not mapped.
+    ``neareststod``: the nearest centre per axis; points outside the source
+    cells are not mapped.
     """
     if method == 'conserve':
         raise ValueError(
@@ -219,6 +223,16 @@ def _to_points(src_descriptor, plat, plon, dst_dims, method):
             'sides; towards points or across grid kinds only bilinear and '
             'neareststod have a closed form')
     sy, sx, sye, sxe, period, kind = _axes(src_descriptor)
+    n = len(plat)
+    if method == 'bilinear':
+        row, col, S, mapped = bilinear_3d(src_descriptor, plat, plon)
+        row, col, S = _merged(row, col, S)
+        return MappingFile(
+            len(sy) * len(sx), n,
+            np.array([len(sx), len(sy)], dtype=np.int32),
+            np.asarray(dst_dims, dtype=np.int32),
+            (row + 1).astype(np.int32), (col + 1).astype(np.int32), S,
+            mapped.astype(np.float64))
     if kind == 'sphere':
         py, px = plat, plon
     else:
@@ -227,8 +241,7 @@ def _to_points(src_descriptor, plat, plon, dst_dims, method):
                              'the destination points with')
         px, py = _forward(src_descriptor.projection, np.degrees(plon),
                           np.degrees(plat))
-    axis = linear_1d if method == 'bilinear' else nearest_1d
-    n = len(py)
+    axis = nearest_1d
     jy, iy, wy = axis(sy, py)
     jx, ix, wx = axis(sx, px, period)
     # pair every y entry of a point with every x entry of the same point
@@ -248,14 +261,10 @@ def _to_points(src_descriptor, plat, plon, dst_dims, method):
     row = point
     col = iy[ky] * len(sx) + ix[kx]
     S = wy[ky] * wx[kx]
-    # what counts as "inside": between the outermost centres for bilinear
-    # (ESMF maps a point only if four source centres surround it), inside
-    # the outermost cells for nearest; a global lat-lon source has no
-    # longitude limits and its latitude rows reach the poles
-    if method == 'bilinear':
-        ylim, xlim = (sy[0], sy[-1]), (sx[0], sx[-1])
-    else:
-        ylim, xlim = (sye[0], sye[-1]), (sxe[0], sxe[-1])
+    # what counts as "inside" for nearest: inside the outermost cells; a
+    # global lat-lon source has no longitude limits and its latitude rows
+    # reach the poles
+    ylim, xlim = (sye[0], sye[-1]), (sxe[0], sxe[-1])
     inside = np.ones(n, dtype=bool)
     if period is None:
         inside &= (px >= min(xlim)) & (px <= max(xlim))
@@ -277,6 +286,7 @@ def _to_points(src_descriptor, plat, plon, dst_dims, method):
 # ---------------------------------------------------------------------------
 
 def _unit(lat, lon):
+    lat, lon = np.broadcast_arrays(lat, lon)
     return np.stack([np.cos(lat) * np.cos(lon), np.cos(lat) * np.sin(lon),
                      np.sin(lat)], axis=-1)
 
@@ -508,6 +518,232 @@ def _from_cell_mesh(src_descriptor, plat, plon, dst_dims, method):
 
 
 
+# ---------------------------------------------------------------------------
+# bilinear from a logically rectangular grid, as ESMF does it: on the quads
+# between four neighbouring cell centres, along straight lines in 3-D
+# ---------------------------------------------------------------------------
+
+def _solve_quads(P, q, iters=12):
+    """
+    Where the ray from the sphere's centre through each unit vector ``q[n]``
+    meets the bilinear patch through the four corners ``P[n]`` (in the order
+    (-1, -1), (1, -1), (1, 1), (-1, 1) of the patch coordinates): Newton on
+    ``sum_i N_i(s, t) P_i - r q = 0``.  Returns ``(s, t)``; NaN where the
+    iteration left the neighbourhood of the patch.
+    """
+    n = len(q)
+    s = np.zeros(n)
+    t = np.zeros(n)
+    r = np.ones(n)
+    p0, p1, p2, p3 = P[:, 0], P[:, 1], P[:, 2], P[:, 3]
+    # X(s, t) = c0 + s c1 + t c2 + s t c3
+    c0 = 0.25 * (p0 + p1 + p2 + p3)
+    c1 = 0.25 * (-p0 + p1 + p2 - p3)
+    c2 = 0.25 * (-p0 - p1 + p2 + p3)
+    c3 = 0.25 * (p0 - p1 + p2 - p3)
+    last = False
+    with np.errstate(all='ignore'):
+        for _ in range(iters):
+            F = c0 + s[:, None] * c1 + t[:, None] * c2 + \
+                (s * t)[:, None] * c3 - r[:, None] * q
+            a = c1 + t[:, None] * c3           # dX/ds
+            b = c2 + s[:, None] * c3           # dX/dt
+            # J = [a, b, -q]; Cramer's rule on J d = -F
+            bq = np.cross(b, q)
+            det = -(a * bq).sum(axis=1)
+            d0 = (F * bq).sum(axis=1) / det
+            d1 = (a * np.cross(F, q)).sum(axis=1) / det
+            d2 = -(a * np.cross(b, F)).sum(axis=1) / det
+            s, t, r = s + d0, t + d1, r + d2
+            far = ~(np.abs(s) <= 50.0) | ~(np.abs(t) <= 50.0)
+            s[far] = t[far] = np.nan
+            r[far] = 1.0
+            if last:
+                break
+            # quadratic convergence: one more step after 1e-8 is rounding
+            step = np.maximum(np.abs(d0), np.abs(d1))
+            last = not (step[~far] > 1e-8).any()
+    return s, t
+
+
+def _merged(row, col, S):
+    """Triplets sorted by (row, col), duplicates summed."""
+    order = np.lexsort((col, row))
+    row, col, S = row[order], col[order], S[order]
+    if len(row) == 0:
+        return row, col, S
+    head = np.ones(len(row), dtype=bool)
+    head[1:] = (row[1:] != row[:-1]) | (col[1:] != col[:-1])
+    start = np.nonzero(head)[0]
+    return row[start], col[start], np.add.reduceat(S, start)
+
+
+def _grid_nodes(descriptor):
+    """
+    The nodes ESMF's bilinear works on for a rectangular source grid -- its
+    cell CENTRES, ``(ny, nx)`` -- as unit vectors, with: whether the columns
+    close around the globe, whether the first / last row is capped by a pole
+    (ESMF's default for a global source: an artificial node at the pole whose
+    value is the mean of the row next to it), and a function that guesses the
+    quad ``(j, i)`` holding points given by latitude / longitude in radians.
+    """
+    if isinstance(descriptor, LatLonGridDescriptor):
+        scale = 1.0 if 'rad' in descriptor.units else np.pi / 180.0
+        lat = np.asarray(descriptor.lat, dtype=np.float64) * scale
+        lon = np.asarray(descriptor.lon, dtype=np.float64) * scale
+        glob = not descriptor.regional
+        nodes = _unit(lat[:, None], lon[None, :])
+
+        def guess(plat, plon):
+            return _bracket(lat, plat, None), \
+                _bracket(lon, plon, 2.0 * np.pi if glob else None)
+        return nodes, glob, glob, guess
+    if isinstance(descriptor, ProjectionGridDescriptor):
+        x = np.asarray(descriptor.x, dtype=np.float64)
+        y = np.asarray(descriptor.y, dtype=np.float64)
+        xx, yy = np.meshgrid(x, y)
+        lat, lon = descriptor.project_to_lat_lon(xx, yy)
+        if lat is None:
+            raise ValueError('the source grid has no usable projection')
+        nodes = _unit(np.radians(lat), np.radians(lon))
+
+        def guess(plat, plon):
+            px, py = _forward(descriptor.projection, np.degrees(plon),
+                              np.degrees(plat))
+            return _bracket(y, py, None), _bracket(x, px, None)
+        return nodes, False, False, guess
+    raise TypeError(
+        f'analytic weights need a LatLonGridDescriptor or a '
+        f'ProjectionGridDescriptor, not {type(descriptor).__name__}')
+
+
+def _bracket(axis, p, period):
+    """Index k of the interval [axis[k], axis[k + 1]] that holds p (axis
+    ascending or descending; with ``period`` the last interval closes the
+    circle); clipped into range."""
+    n = len(axis)
+    if n < 2:
+        return np.zeros(len(p), dtype=np.int64)
+    flip = axis[-1] < axis[0]
+    a = axis[::-1] if flip else axis
+    if period is not None:
+        t = a[0] + np.mod(p - a[0], period)
+        k = np.clip(np.searchsorted(a, t, side='right') - 1, 0, n - 1)
+        return (n - 2 - k) % n if flip else k
+    k = np.clip(np.searchsorted(a, p, side='right') - 1, 0, n - 2)
+    return n - 2 - k if flip else k
+
+
+def bilinear_3d(src_descriptor, plat, plon, tol=1e-10, chunk=1 << 20):
+    """
+    ESMF's ``bilinear`` from a rectangular grid to points (radians): each
+    point is located in a quad of four neighbouring source centres -- corners
+    joined by straight lines in 3-D, the point carried onto the patch along
+    the ray from the sphere's centre -- and takes the patch's bilinear
+    weights; a global lat-lon source closes around the globe and is capped
+    at either pole by triangles to a pole node that stands for the mean of
+    the adjacent row.  (Agrees with the outputs the reference's tests store,
+    made with ESMF weights, to the float32 rounding of those files; bilinear
+    interpolation in latitude / longitude, which this replaced, differs from
+    them by up to 5e-3 K on the 1-degree SST file.)
+
+    Returns ``(row, col, S, mapped)``: 0-based triplets and the mask of the
+    points some quad or cap holds.
+    """
+    plat = np.asarray(plat, dtype=np.float64)
+    plon = np.asarray(plon, dtype=np.float64)
+    if len(plat) > chunk:
+        # bounded memory whatever the destination grid (30 M points for a
+        # 1 km Antarctic grid): the points in pieces
+        parts = [bilinear_3d(src_descriptor, plat[c:c + chunk],
+                             plon[c:c + chunk], tol, chunk)
+                 for c in range(0, len(plat), chunk)]
+        return (np.concatenate([p[0] + k * chunk
+                                for k, p in enumerate(parts)]),
+                np.concatenate([p[1] for p in parts]),
+                np.concatenate([p[2] for p in parts]),
+                np.concatenate([p[3] for p in parts]))
+    nodes, periodic, capped, guess = _grid_nodes(src_descriptor)
+    ny, nx = nodes.shape[:2]
+    q = _unit(plat, plon)
+    n = len(q)
+    j0, i0 = guess(plat, plon)
+    mapped = np.zeros(n, dtype=bool)
+    idx = np.zeros((n, 4), dtype=np.int64)
+    wgt = np.zeros((n, 4))
+    if ny >= 2 and nx >= 2:
+        todo = np.arange(n)
+        for dj, di in ((0, 0), (-1, 0), (1, 0), (0, -1), (0, 1), (-1, -1),
+                       (-1, 1), (1, -1), (1, 1)):
+            if not len(todo):
+                break
+            j = j0[todo] + dj
+            i = i0[todo] + di
+            if periodic:
+                i = i % nx
+                i1 = (i + 1) % nx
+                ok = (j >= 0) & (j <= ny - 2)
+            else:
+                i1 = i + 1
+                ok = (j >= 0) & (j <= ny - 2) & (i >= 0) & (i <= nx - 2)
+            j, i, i1, pts = j[ok], i[ok], i1[ok], todo[ok]
+            P = np.stack([nodes[j, i], nodes[j, i1], nodes[j + 1, i1],
+                          nodes[j + 1, i]], axis=1)
+            s, t = _solve_quads(P, q[pts])
+            with np.errstate(invalid='ignore'):
+                inside = (np.abs(s) <= 1.0 + tol) & (np.abs(t) <= 1.0 + tol)
+            s = np.clip(s[inside], -1.0, 1.0)
+            t = np.clip(t[inside], -1.0, 1.0)
+            hit = pts[inside]
+            wgt[hit] = np.stack([(1 - s) * (1 - t), (1 + s) * (1 - t),
+                                 (1 + s) * (1 + t), (1 - s) * (1 + t)],
+                                -1) * 0.25
+            idx[hit] = np.stack([j * nx + i, j * nx + i1, (j + 1) * nx + i1,
+                                 (j + 1) * nx + i], -1)[inside]
+            mapped[hit] = True
+            todo = todo[~mapped[todo]]
+    row = np.repeat(np.nonzero(mapped)[0], 4)
+    col = idx[mapped].reshape(-1)
+    S = wgt[mapped].reshape(-1)
+    if capped and (~mapped).any():
+        # the pole caps: triangles (pole, node i, node i + 1) of the first /
+        # last row; the pole's share goes to the whole row in equal parts
+        rest = np.nonzero(~mapped)[0]
+        for jrow in (0, ny - 1):
+            if not len(rest):
+                break
+            zs = nodes[jrow, :, 2].mean()
+            pole = np.array([0.0, 0.0, 1.0 if zs > 0 else -1.0])
+            for di in (0, -1, 1):
+                if not len(rest):
+                    break
+                i = (i0[rest] + di) % nx
+                i1 = (i + 1) % nx
+                M = np.stack([np.broadcast_to(pole, (len(rest), 3)),
+                              nodes[jrow, i], nodes[jrow, i1]], -1)
+                w = np.linalg.solve(M, q[rest][:, :, None])[:, :, 0]
+                tot = w.sum(axis=1)
+                w = w / tot[:, None]
+                inside = (tot > 0) & (w >= -tol).all(axis=1)
+                hit = rest[inside]
+                w = np.clip(w[inside], 0.0, None)
+                w = w / w.sum(axis=1)[:, None]
+                ring = jrow * nx + np.arange(nx)
+                row = np.concatenate([row, np.repeat(hit, nx + 2)])
+                col = np.concatenate([col, np.concatenate(
+                    [np.broadcast_to(ring, (len(hit), nx)),
+                     (jrow * nx + i[inside])[:, None],
+                     (jrow * nx + i1[inside])[:, None]], axis=1).reshape(-1)])
+                S = np.concatenate([S, np.concatenate(
+                    [np.repeat(w[:, :1] / nx, nx, axis=1), w[:, 1:]],
+                    axis=1).reshape(-1)])
+                mapped[hit] = True
+                rest = rest[~mapped[rest]]
+    keep = S != 0.0
+    return row[keep], col[keep], S[keep], mapped
+
+
+
 def _cell_centres(descriptor):
     """(lat, lon) in radians of every cell centre of a rectangular grid, in
     C order, and its Fortran-ordered dims."""
@@ -545,6 +781,10 @@ def build_weights(src_descriptor, dst_descriptor, method='conserve'):
     if points is not None:
         return _to_points(src_descriptor, points[0], points[1],
                           [len(points[0])], method)
+    if method == 'bilinear':
+        # the destination cell centres are points for the source grid
+        lat, lon, dims = _cell_centres(dst_descriptor)
+        return _to_points(src_descriptor, lat, lon, dims, method)
     sy, sx, sye, sxe, period, kind = _axes(src_descriptor)
     dy, dx, dye, dxe, _, dkind = _axes(dst_descriptor)
     same_kind = kind == dkind
@@ -570,17 +810,12 @@ def build_weights(src_descriptor, dst_descriptor, method='conserve'):
         frac_b = np.bincount(row, weights=S, minlength=ny_d * nx_d)
         frac_b = np.minimum(frac_b, 1.0)
     else:
-        axis = linear_1d if method == 'bilinear' else nearest_1d
-        row, col, S = _tensor(axis(sy, dy), axis(sx, dx, period), ny_s, nx_s,
-                              ny_d, nx_d)
+        row, col, S = _tensor(nearest_1d(sy, dy), nearest_1d(sx, dx, period),
+                              ny_s, nx_s, ny_d, nx_d)
         frac_b = np.ones(ny_d * nx_d)
         if period is None:
-            # destination points outside the source box are not mapped:
-            # outside the hull of the centres for bilinear (ESMF's rule),
-            # outside the cells for nearest
-            ylim, xlim = ((sy[0], sy[-1]), (sx[0], sx[-1])) \
-                if method == 'bilinear' else \
-                ((sye[0], sye[-1]), (sxe[0], sxe[-1]))
+            # destination points outside the source cells are not mapped
+            ylim, xlim = (sye[0], sye[-1]), (sxe[0], sxe[-1])
             inside_y = (dy >= min(ylim)) & (dy <= max(ylim))
             if kind == 'sphere':
                 # latitude rows reach the poles: nothing is outside
