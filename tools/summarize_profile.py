@@ -84,28 +84,26 @@ def main():
         rows = [r for r in csv.DictReader(open(trace[0]))
                 if 'spmm_' in r['Kernel_Name']]
         rows.sort(key=lambda r: int(r['Start_Timestamp']))
-        # bench.py's last spmm launches are the metric workload's: W warm-up,
-        # K timed, min(K, 50) individually timed, 100 steady ones.  (The
-        # host-buffer extra that follows launches a few more: drop those by
-        # grid size -- it uses other kernels' shapes -- or by count.)
-        main_grid = None
-        by_grid = collections.Counter(r['Grid_Size_X'] for r in rows)
+        # The metric workload's launches are the LAST run of at least W
+        # warm-up + K timed + min(K, 50) individually timed + 100 steady
+        # consecutive launches of one kernel on one grid (what follows --
+        # graph replays of the short extras, the host-buffer extra -- uses
+        # other kernels or shorter runs).
         tail = 100 + min(steps, 50)
-        # the metric kernel is the most frequent grid among the last rows
-        main_grid = collections.Counter(
-            r['Grid_Size_X'] for r in rows[-(tail + steps + 40):]
-        ).most_common(1)[0][0]
-        mine = [r for r in rows if r['Grid_Size_X'] == main_grid and
-                short(r['Kernel_Name']) ==
-                short(rows[-1]['Kernel_Name'])] or \
-            [r for r in rows if r['Grid_Size_X'] == main_grid]
-        # walk back: steady 100, second pass, then the K timed launches
+        block = tail + steps + warmup
+        runs, start = [], 0
+        for n in range(1, len(rows) + 1):
+            if n == len(rows) or \
+                    (rows[n]['Kernel_Name'], rows[n]['Grid_Size_X']) != \
+                    (rows[start]['Kernel_Name'], rows[start]['Grid_Size_X']):
+                runs.append((start, n))
+                start = n
+        long_runs = [r for r in runs if r[1] - r[0] >= block]
+        first, last = long_runs[-1] if long_runs else runs[-1]
+        mine = rows[first:last]
+        main_grid = mine[-1]['Grid_Size_X']
         dur = [int(r['End_Timestamp']) - int(r['Start_Timestamp'])
                for r in mine]
-        # launches after the metric workload (host-buffer extra) may share
-        # the grid: the timed region is located from the END of the block of
-        # 100 + min(K, 50) + K + W consecutive launches of the main plan
-        block = tail + steps + warmup
         cand = dur[-block:] if len(dur) >= block else dur
         timed = cand[warmup:warmup + steps]
         timed_avg = sum(timed) / len(timed)
