@@ -98,7 +98,11 @@ def main():
                     (rows[start]['Kernel_Name'], rows[start]['Grid_Size_X']):
                 runs.append((start, n))
                 start = n
-        long_runs = [r for r in runs if r[1] - r[0] >= block]
+        # (the graph replays of the short extras are long runs too: keep
+        # to the kernel family the bench line names)
+        family = (live['roofline'].get('kernel') or 'spmm_').split()[0]
+        long_runs = [r for r in runs if r[1] - r[0] >= block and
+                     family in rows[r[0]]['Kernel_Name']]
         first, last = long_runs[-1] if long_runs else runs[-1]
         mine = rows[first:last]
         main_grid = mine[-1]['Grid_Size_X']
