@@ -104,42 +104,6 @@ def overlap_1d(src_edges, dst_edges, period=None):
     return j[order], i[order], length[order]
 
 
-def linear_1d(src_centres, dst_points, period=None):
-    """
-    Linear interpolation along one axis.  Returns (j, i, w) with up to two
-    entries per destination point; weights of a point sum to 1.
-    """
-    sc = np.asarray(src_centres, dtype=np.float64)
-    dp = np.asarray(dst_points, dtype=np.float64)
-    n = len(sc)
-    perm = np.arange(n)
-    if n > 1 and sc[-1] < sc[0]:
-        sc, perm = sc[::-1].copy(), perm[::-1].copy()
-    if n == 1:
-        j = np.arange(len(dp))
-        return j, np.zeros_like(j), np.ones(len(dp))
-    if period is not None:
-        # bring the points into [sc[0], sc[0] + period) and close the circle
-        t = sc[0] + np.mod(dp - sc[0], period)
-        ext = np.append(sc, sc[0] + period)
-        k = np.clip(np.searchsorted(ext, t, side='right') - 1, 0, n - 1)
-        w1 = (t - ext[k]) / (ext[k + 1] - ext[k])
-        i0, i1 = k, (k + 1) % n
-    else:
-        t = np.clip(dp, sc[0], sc[-1])
-        k = np.clip(np.searchsorted(sc, t, side='right') - 1, 0, n - 2)
-        w1 = (t - sc[k]) / (sc[k + 1] - sc[k])
-        i0, i1 = k, k + 1
-    jj = np.arange(len(dp))
-    j = np.concatenate([jj, jj])
-    i = perm[np.concatenate([i0, i1])]
-    w = np.concatenate([1.0 - w1, w1])
-    keep = w != 0.0
-    j, i, w = j[keep], i[keep], w[keep]
-    order = np.lexsort((i, j))
-    return j[order], i[order], w[order]
-
-
 def nearest_1d(src_centres, dst_points, period=None):
     sc = np.asarray(src_centres, dtype=np.float64)
     dp = np.asarray(dst_points, dtype=np.float64)

@@ -16,7 +16,6 @@ from pyremap_amd import (
 from pyremap_amd.io import mapfile
 from pyremap_amd.weights import (
     build_weights,
-    linear_1d,
     overlap_1d,
     write_weights,
 )
@@ -63,23 +62,6 @@ def test_overlap_1d_periodic():
     np.add.at(got, (j, i), length)
     assert np.allclose(got.sum(axis=1), 45.0)    # every dst cell covered
     assert np.allclose(got.sum(axis=0), 30.0)    # every src cell used up
-
-
-def test_linear_1d_reproduces_linear_functions():
-    rng = np.random.default_rng(1)
-    sc = np.sort(rng.uniform(0, 10, 9))
-    dp = rng.uniform(sc[0], sc[-1], 50)
-    for src in (sc, sc[::-1].copy()):
-        j, i, w = linear_1d(src, dp)
-        val = np.zeros(50)
-        np.add.at(val, j, w * (3.0 * src[i] - 2.0))
-        assert np.allclose(val, 3.0 * dp - 2.0)
-    # periodic: a point between the last and the first centre
-    lon = np.arange(-175.0, 180.0, 10.0)
-    j, i, w = linear_1d(lon, np.array([178.0, -179.0]), period=360.0)
-    assert sorted(i[j == 0].tolist()) == [0, 35]
-    assert np.isclose(w[(j == 0) & (i == 35)][0], 0.7)
-    assert np.isclose(w[(j == 1) & (i == 0)][0], 0.6)
 
 
 @pytest.mark.parametrize('src_res, dst_res', [((10.0, 5.0), (4.0, 3.0)),
