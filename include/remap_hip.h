@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define REMAP_ABI_VERSION 21
+#define REMAP_ABI_VERSION 22
 
 enum {
     REMAP_OK = 0,
@@ -266,6 +266,17 @@ typedef struct remap_apply_args {
      * reference takes a transpose copy (remap_numpy.py:254-256). */
     int64_t x_src_fold;
     int64_t x_outer_stride;
+    /* Family 7 only, optional (NULL: the patch plan's entries lie row after
+     * row, patch_rowptr addressing them).  Not NULL: they lie COLUMN-MAJOR
+     * inside every patch -- entry j of the patch's slot r at
+     * patch_val / patch_lidx [patch_ell_base[patch] + j * patch_rows + r];
+     * patch_rowptr then only gives the slots' entry counts -- so that the 64
+     * lanes of a wave, one slot each, read their j-th entries with ONE
+     * coalesced load.  For patches of LONG rows: the pole caps of a global
+     * bilinear map as ESMF makes it, 362-1 442 entries per row, where a
+     * lane reading its own row's entries one by one pays a line fetch per
+     * lane and entry (engine.RemapPlan._split_long_rows). */
+    const int64_t *patch_ell_base;
 } remap_apply_args;
 
 /* ABI / build information */

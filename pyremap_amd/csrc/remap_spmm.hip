@@ -223,30 +223,45 @@ patch_fn pick_patch(bool f32, int mode, bool fma, int wc, bool dma)
 typedef void (*cell_fn)(const KParams, const uint32_t, const int32_t *,
                         const double *, const int32_t *, const int32_t *,
                         const int32_t *, const int32_t *, const double *,
-                        const int32_t, const int32_t, const int64_t);
+                        const int32_t, const int32_t, const int64_t,
+                        const int64_t *);
 
-template <typename XT, int TT>
+template <typename XT, int TT, int LAYOUT>
 cell_fn pick_patchcell_mode(int mode, bool fma)
 {
     switch (mode) {
     case REMAP_MODE_RAW:
-        return fma ? spmm_patchcell<XT, REMAP_MODE_RAW, true, TT>
-                   : spmm_patchcell<XT, REMAP_MODE_RAW, false, TT>;
+        return fma ? spmm_patchcell<XT, REMAP_MODE_RAW, true, TT, LAYOUT>
+                   : spmm_patchcell<XT, REMAP_MODE_RAW, false, TT, LAYOUT>;
     case REMAP_MODE_FRACB:
-        return fma ? spmm_patchcell<XT, REMAP_MODE_FRACB, true, TT>
-                   : spmm_patchcell<XT, REMAP_MODE_FRACB, false, TT>;
+        return fma ? spmm_patchcell<XT, REMAP_MODE_FRACB, true, TT, LAYOUT>
+                   : spmm_patchcell<XT, REMAP_MODE_FRACB, false, TT, LAYOUT>;
     default:
-        return fma ? spmm_patchcell<XT, REMAP_MODE_MASKED, true, TT>
-                   : spmm_patchcell<XT, REMAP_MODE_MASKED, false, TT>;
+        return fma ? spmm_patchcell<XT, REMAP_MODE_MASKED, true, TT, LAYOUT>
+                   : spmm_patchcell<XT, REMAP_MODE_MASKED, false, TT, LAYOUT>;
     }
 }
 
-template <typename XT>
-cell_fn pick_patchcell(int tt, int mode, bool fma)
+template <typename XT, int LAYOUT>
+cell_fn pick_patchcell_tt(int tt, int mode, bool fma)
 {
-    return tt == 4    ? pick_patchcell_mode<XT, 4>(mode, fma)
-           : tt == 16 ? pick_patchcell_mode<XT, 16>(mode, fma)
-                      : pick_patchcell_mode<XT, 8>(mode, fma);
+    return tt == 4    ? pick_patchcell_mode<XT, 4, LAYOUT>(mode, fma)
+           : tt == 16 ? pick_patchcell_mode<XT, 16, LAYOUT>(mode, fma)
+                      : pick_patchcell_mode<XT, 8, LAYOUT>(mode, fma);
+}
+
+template <typename XT>
+cell_fn pick_patchcell(int tt, int mode, bool fma, int layout)
+{
+    // long rows (column-major entries): fewer fields per lane -- a row is
+    // ONE dependent chain of hundreds of entries, and a lone wave per SIMD
+    // pays every instruction of it in full: short steps, more workgroups
+    if (layout == 1 && tt == 1)
+        return pick_patchcell_mode<XT, 1, 1>(mode, fma);
+    if (layout == 1 && tt == 2)
+        return pick_patchcell_mode<XT, 2, 1>(mode, fma);
+    return layout == 1 ? pick_patchcell_tt<XT, 1>(tt, mode, fma)
+                       : pick_patchcell_tt<XT, 0>(tt, mode, fma);
 }
 
 // LDS a workgroup may ask for and still leave room for a second one per CU
@@ -871,7 +886,10 @@ int run_patchcell(const remap_apply_args *a, const Call &c, KParams p,
                     "plan covering [row_begin, row_end)");
     const int32_t upitch = (a->patch_umax + 2) & ~1;
     int tt = a->tune[1];
-    if (tt != 4 && tt != 8 && tt != 16) {
+    const bool long_rows = a->patch_ell_base != nullptr;
+    if (long_rows && (tt == 1 || tt == 2)) {
+        // (column-major plans only)
+    } else if (tt != 4 && tt != 8 && tt != 16) {
         tt = 16;
         while (tt > 4 && (int64_t)upitch * tt * 8 > 32 * 1024)
             tt >>= 1;
@@ -886,8 +904,9 @@ int run_patchcell(const remap_apply_args *a, const Call &c, KParams p,
     uint32_t lds_bytes = static_cast<uint32_t>(upitch) * tt * 8u;
     if (lds_bytes < 1024)
         lds_bytes = 1024;
-    cell_fn fn = c.f32 ? pick_patchcell<float>(tt, a->mode, c.fma)
-                       : pick_patchcell<double>(tt, a->mode, c.fma);
+    const int layout = a->patch_ell_base ? 1 : 0;
+    cell_fn fn = c.f32 ? pick_patchcell<float>(tt, a->mode, c.fma, layout)
+                       : pick_patchcell<double>(tt, a->mode, c.fma, layout);
     if (lds_bytes > 64 * 1024)
         REMAP_HIP_CHECK(hipFuncSetAttribute(
             reinterpret_cast<const void *>(fn),
@@ -896,7 +915,8 @@ int run_patchcell(const remap_apply_args *a, const Call &c, KParams p,
                        dim3(kCellBlock), lds_bytes, stream, p, a->flags,
                        a->patch_rowptr, a->patch_val, a->patch_lidx,
                        a->patch_ptr, a->patch_ucol, a->row_order, a->frac_b,
-                       a->patch_rows, upitch, a->n_patches);
+                       a->patch_rows, upitch, a->n_patches,
+                       a->patch_ell_base);
     REMAP_HIP_CHECK(hipGetLastError());
     return REMAP_OK;
 }

@@ -33,10 +33,13 @@ FLAG_TREE = 8
 DTYPE_F64 = 0
 DTYPE_F32 = 1
 
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 #: readable pad entries kept behind col/val (remap_csr.csr_pad)
 CSR_PAD = 8
+#: LDS a workgroup of the lanes-across-rows kernel may take (kPatchLdsMax)
+CELL_LDS_MAX = 160 * 1024
+_LONG_TT = None   # (experiments: fields per lane of the long-row launch)
 
 #: every symbol ``include/remap_hip.h`` declares
 EXPORTS = (
@@ -109,6 +112,7 @@ class _ApplyArgs(ctypes.Structure):
         ('tune', ctypes.c_int32 * 8),
         ('x_src_fold', ctypes.c_int64),
         ('x_outer_stride', ctypes.c_int64),
+        ('patch_ell_base', ctypes.c_void_p),
     ]
 
 
@@ -408,6 +412,9 @@ class RemapPlan:
         #: optional int32 permutation of the rows: the order in which work
         #: slots visit them (scheduling only; see set_row_order)
         self.row_order = None
+        #: (short, long) sibling plans when a few rows hold a large share of
+        #: the entries (see _split_long_rows); None otherwise
+        self._split = None
 
     def _sched_property(name):   # noqa: N805 - class-body helper
         def get(self):
@@ -460,6 +467,8 @@ class RemapPlan:
             args.patch_emax = q['emax']
             args.patch_row_bytes = q['row_bytes']
             args.n_patches = q['n']
+            if q.get('ell_base') is not None:
+                args.patch_ell_base = q['ell_base'].data_ptr()
         elif whole:
             # (a stored order permutes the whole row range: partial ranges
             # run without it, and without the schedules built on it)
@@ -942,7 +951,94 @@ class RemapPlan:
                            union=nu)
         return nu / self.nnz
 
-    def auto_schedule(self, grid_dims):
+    #: a row counts as LONG from this many entries on (the widest stencils
+    #: of ordinary maps -- 2nd-order conservative -- hold ~30)
+    LONG_ROW = 96
+
+    def _split_long_rows(self):
+        """
+        Mappings whose few LONG rows hold a large share of the entries -- a
+        global lat-lon bilinear map as ESMF makes it: the destination cells
+        poleward of the last source row take the WHOLE adjacent source row
+        (the pole cap, ``weights.bilinear_3d``), 362-1 442 entries per row
+        among rows of 4, a third of all entries in 0.6 % of the rows -- lose
+        every schedule built for short rows (no LDS patch holds 1 440 source
+        rows) and serialise the others (a lane walks its row entry by entry:
+        1 deg -> 0.5 deg, one 2-D field, 66 us against 13 us without the caps;
+        K = 64: 150 against 37).
+
+        Such a plan is applied as TWO launches writing disjoint rows: the
+        mapping without the long rows' entries on its own schedule, and the
+        long rows through the LDS-staged lanes-across-rows kernel (family 7):
+        the source rows they share are staged once per 256 rows, every lane
+        sums its row in CSR order from LDS.  Returns ``(short, long)`` plans
+        or ``None`` when the mapping has no such rows (or the long rows'
+        sources do not fit the LDS).
+        """
+        torch = _torch()
+        if self.n_b != self.n_b_global or self.row_offset != 0 or \
+                self.max_row_nnz <= self.LONG_ROW:
+            return None
+        counts = self.rowptr[1:] - self.rowptr[:-1]
+        is_long = counts > self.LONG_ROW
+        ids = is_long.nonzero().squeeze(1)
+        n_long = int(ids.shape[0])
+        long_entries = int(counts[ids].sum())
+        if n_long == 0 or n_long > self.n_b // 8 or \
+                long_entries < self.nnz // 50:
+            return None
+        entry_long = torch.repeat_interleave(is_long, counts)
+
+        def sub(rows_kept, entries_kept, n_rows, frac):
+            rp = torch.zeros(n_rows + 1, dtype=torch.int64,
+                             device=self.device)
+            rp[1:] = torch.cumsum(rows_kept, 0)
+            return RemapPlan(self.n_a, n_rows, rp,
+                             self.col[entries_kept].contiguous(),
+                             self.val[entries_kept].contiguous(), frac)
+        short = sub(torch.where(is_long, torch.zeros_like(counts), counts),
+                    ~entry_long, self.n_b, self.frac_b)
+        long = sub(counts[ids], entry_long, n_long, self.frac_b)
+        # the long rows' patch plan: 256 consecutive long rows per workgroup,
+        # halved until the distinct source rows fit the LDS with 4 fields
+        # per lane; work slot -> row of the WHOLE mapping
+        limit = CELL_LDS_MAX // (4 * 8) - 2
+        q = long._make_patches(None, (1, 256),
+                               lambda rows, umax, emax: umax <= limit, 1024)
+        if q is None:
+            return None
+        q['order'] = ids.to(torch.int32).contiguous()
+        rows, n_p = q['rows'], q['n']
+        rp = q['rowptr'].to(torch.int64)
+        lens = rp[1:] - rp[:-1]
+        slot = torch.arange(n_long, device=self.device)
+        patch, r_local = slot // rows, slot % rows
+        e_slot = torch.repeat_interleave(slot, lens)
+        j = torch.arange(long.nnz, device=self.device) - rp[e_slot]
+        lidx, val = q['lidx'][:long.nnz], q['val'][:long.nnz]
+        # the entries COLUMN-MAJOR inside every patch (patch_ell_base):
+        # the lanes -- one slot each -- read their j-th entries with one
+        # coalesced load instead of a line fetch per lane and entry
+        longest = torch.zeros(n_p, dtype=torch.int64,
+                              device=self.device) \
+            .scatter_reduce(0, patch, lens, 'amax')
+        base = torch.cumsum(longest * rows, 0) - longest * rows
+        dest = base[patch[e_slot]] + j * rows + r_local[e_slot]
+        total = int((longest * rows).sum())
+        val_t = torch.zeros(total + CSR_PAD, dtype=torch.float64,
+                            device=self.device)
+        lidx_t = torch.zeros(total + CSR_PAD, dtype=torch.int32,
+                             device=self.device)
+        val_t[dest] = val
+        lidx_t[dest] = lidx
+        q['val'], q['lidx'] = val_t, lidx_t
+        q['ell_base'] = base.contiguous()
+        q['layout'] = 'column-major'
+        long._cell = q
+        long._long_of = self.n_b
+        return short, long
+
+    def auto_schedule(self, grid_dims, _split_ok=True):
         """
         Choose AND build the schedule for this mapping with the library's
         ``remap_schedule_auto`` (the rules -- LDS patches for heavily shared,
@@ -962,8 +1058,19 @@ class RemapPlan:
         self._cell = None
         self._runs = None
         self._grid_dims = None
+        self._split = None
         if grid_dims is None or self.nnz == 0 or self.n_b == 0:
             return {'family': 'rowscalar', 'reason': 'no destination grid'}
+        if _split_ok:
+            split = self._split_long_rows()
+            if split is not None:
+                short, long = split
+                choice = short.auto_schedule(grid_dims, _split_ok=False)
+                self._split = split
+                self._grid_dims = short._grid_dims
+                return dict(choice, long_rows=long.n_b,
+                            long_row_entries=long.nnz,
+                            long_rows_layout=long._cell['layout'])
         dims = tuple(int(d) for d in grid_dims)
         if len(dims) in (1, 2) and _prod(dims) == self.n_b_global:
             self._grid_dims = dims
@@ -1135,7 +1242,7 @@ def apply_strided(plan, X, Y, *, n_batch, k_inner, x_row_stride,
                   x_batch_stride, y_row_stride, y_batch_stride, mode,
                   threshold=0.0, mask_out=None, flags=0, tune=None,
                   row_begin=0, row_end=None, gate=None, gate_value=0,
-                  x_src_fold=0, x_outer_stride=0):
+                  x_src_fold=0, x_outer_stride=0, _long_rows=False):
     """
     One asynchronous ``remap_apply_f64`` launch on torch's current stream.
     ``X``/``Y``/``mask_out`` are device tensors; strides are in elements.
@@ -1187,11 +1294,27 @@ def apply_strided(plan, X, Y, *, n_batch, k_inner, x_row_stride,
         raise TypeError('mask_out must be a uint8 tensor on the plan device')
     end = plan.n_b if row_end is None else row_end
     whole = row_begin == 0 and end == plan.n_b
+    if plan._split is not None and whole and not tune:
+        # a few long rows hold a large share of the entries (pole caps of a
+        # global bilinear map): two launches writing disjoint rows
+        # (RemapPlan._split_long_rows)
+        for part, is_long in zip(plan._split, (False, True)):
+            apply_strided(part, X, Y, n_batch=n_batch, k_inner=k_inner,
+                          x_row_stride=x_row_stride,
+                          x_batch_stride=x_batch_stride,
+                          y_row_stride=y_row_stride,
+                          y_batch_stride=y_batch_stride, mode=mode,
+                          threshold=threshold, mask_out=mask_out, flags=flags,
+                          gate=gate, gate_value=gate_value,
+                          x_src_fold=x_src_fold,
+                          x_outer_stride=x_outer_stride, _long_rows=is_long)
+        return
     # short contiguous runs in several batches -- (Time, nCells) -- go to the
     # LDS-staged lanes-across-rows kernel on its own patch plan
-    cell = whole and not tune and \
-        ((k_inner < 4 and n_batch > 1) or x_src_fold) and \
-        n_batch * k_inner >= 2 and plan.cell_patches() is not None
+    cell = _long_rows or (
+        whole and not tune and
+        ((k_inner < 4 and n_batch > 1) or x_src_fold) and
+        n_batch * k_inner >= 2 and plan.cell_patches() is not None)
     # short level runs in several batches -- (Time, nCells, 4 ... 15) -- on
     # a row-group mapping: small LDS patches (RemapPlan.run_patches)
     if not cell and whole and not tune and n_batch > 1 and \
@@ -1207,6 +1330,14 @@ def apply_strided(plan, X, Y, *, n_batch, k_inner, x_row_stride,
         # (12, nCells): 22.1 / 22.4 us with 4 / 8, (60, 3.7 M cells): 1.36 /
         # 1.16 ms
         tune = [7, 8 if n_batch * k_inner >= 16 else 4]
+        if _long_rows:
+            # a long row is ONE dependent chain: few fields per lane keep its
+            # steps short and the workgroups many (1 deg -> 0.5 deg with pole
+            # caps, us per apply with 1 / 2 / 4 fields per lane: K = 1 27 /
+            # 30 / 49, K = 12 47 / 50 / 70, K = 64 72 / 65 / 83, K = 512
+            # 423 / 352 / 320 -- every workgroup re-reads its patch's entries)
+            K = n_batch * k_inner
+            tune = [7, _LONG_TT or (1 if K <= 8 else 2 if K <= 128 else 4)]
         flags |= FLAG_TUNE_HINT
     args.row_begin = row_begin
     args.row_end = end

@@ -1,0 +1,205 @@
+"""
+Mappings whose few LONG rows hold a large share of the entries -- a global
+lat-lon bilinear map as ESMF makes it: destination cells poleward of the last
+source row take the whole adjacent source row (the pole cap,
+`pyremap_amd.weights.bilinear_3d`), hundreds of entries per row among rows of
+four -- are applied as two launches writing disjoint rows
+(`RemapPlan._split_long_rows`): the mapping without those rows on its own
+schedule, the long rows through the LDS-staged lanes-across-rows kernel on
+column-major entries.  Every value against the oracle, bit for bit.
+"""
+import numpy as np
+import pytest
+
+from helpers import assert_bitwise
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'these tests need an MI355X'
+    from pyremap_amd import engine
+    engine.load_library()
+    return torch.device('cuda', 0)
+
+
+def _capped_map():
+    """2 deg -> 1 deg global bilinear, ESMF's way: 2 x 360 pole-cap rows
+    holding the 180 cells of the adjacent source row."""
+    from pyremap_amd import get_lat_lon_descriptor
+    from pyremap_amd.weights import build_weights
+    src = get_lat_lon_descriptor(2.0, 2.0)
+    dst = get_lat_lon_descriptor(1.0, 1.0)
+    m = build_weights(src, dst, 'bilinear')
+    rows = np.bincount(m.row - 1, minlength=m.n_b)
+    assert rows.max() == 180 and (rows > 8).sum() == 720
+    return m, (180, 360)
+
+
+def _ragged_long_map(seed=5):
+    """Long rows WITHOUT any structure: 40 rows of 150-700 random columns
+    with random (signed) weights among short conservative-like rows."""
+    from pyremap_amd import synthetic
+    m = synthetic.conservative_map(3000, (40, 50), 1, 6, seed=seed,
+                                   locality='mesh')
+    mm = m.numpy()
+    rng = np.random.default_rng(seed)
+    row, col, S = [mm['row']], [mm['col']], [mm['S']]
+    for r in rng.choice(m.n_b, 40, replace=False):
+        n = int(rng.integers(150, 700))
+        row.append(np.full(n, r + 1))
+        col.append(rng.choice(m.n_a, n, replace=False) + 1)
+        S.append(rng.standard_normal(n))
+    mm['row'] = np.concatenate(row).astype(np.int32)
+    mm['col'] = np.concatenate(col).astype(np.int32)
+    mm['S'] = np.concatenate(S)
+    mm['frac_b'] = np.where(mm['frac_b'] > 0, mm['frac_b'], 0.5)
+    return mm, m.n_a, m.n_b, (40, 50)
+
+
+@pytest.mark.parametrize('which', ['pole caps', 'ragged'])
+def test_long_rows_apart_bitwise(dev, which):
+    from oracle import oracle
+    from pyremap_amd import engine
+    if which == 'pole caps':
+        m, dims = _capped_map()
+        row, col, S, frac_b, n_a, n_b = m.row, m.col, m.S, m.frac_b, \
+            m.n_a, m.n_b
+    else:
+        mm, n_a, n_b, dims = _ragged_long_map()
+        row, col, S, frac_b = mm['row'], mm['col'], mm['S'], mm['frac_b']
+    plan = engine.RemapPlan.from_triplets(row, col, S, frac_b, n_a, n_b,
+                                          device=dev)
+    choice = plan.auto_schedule(dims)
+    assert choice['long_rows'] == (720 if which == 'pole caps' else 40)
+    assert choice['long_rows_layout'] == 'column-major'
+    short, long = plan._split
+    assert short.nnz + long.nnz == plan.nnz and short.max_row_nnz <= 96
+    rowptr, c, v = plan.to_host_csr()
+    csr = oracle.OracleCSR(rowptr, c, v, (n_b, n_a))
+    rng = np.random.default_rng(2)
+    cases = [((n_a,), [0]), ((n_a, 3), [0]), ((n_a, 12), [0]),
+             ((n_a, 64), [0]), ((n_a, 130), [0]), ((5, n_a), [1]),
+             ((40, n_a), [1]), ((3, n_a, 10), [1]), ((2, n_a, 61), [1])]
+    for shape, axes in cases:
+        for dtype in (np.float64, np.float32):
+            x = rng.standard_normal(shape).astype(dtype)
+            holes = x.copy()
+            dead = rng.random(n_a) < 0.2
+            holes[(slice(None),) * axes[0] + (dead,)] = np.nan
+            for field, thr in ((x, None), (holes, 0.3), (holes, None)):
+                masked = thr is not None
+                arg = np.ma.masked_array(field, np.isnan(field)) if masked \
+                    else field
+                want = oracle.remap_numpy_array(csr, frac_b, dims, arg, axes,
+                                                thr)
+                mask_out = None
+                got = engine.remap_tensor(
+                    plan, dims, torch.from_numpy(field).to(dev), axes,
+                    engine.MODE_MASKED if masked else engine.MODE_FRACB,
+                    threshold=thr or 0.0)
+                assert_bitwise(got.cpu().numpy(), np.ma.filled(want, np.nan),
+                               f'{which} {shape} {dtype.__name__} thr {thr}')
+                del mask_out
+    # the mask output, and a row range (no split there: the plain kernels)
+    x = torch.from_numpy(rng.standard_normal((n_a, 24))).to(dev)
+    y, mask = engine.remap_tensor(plan, dims, x, [0], engine.MODE_FRACB,
+                                  want_mask=True)
+    want, wmask = oracle.remap_flat(csr, frac_b, x.cpu().numpy(), False, 0.0)
+    assert np.array_equal(mask.cpu().numpy().reshape(n_b, 24).astype(bool),
+                          wmask)
+    sub = plan.row_slice(100, 900)
+    ys = engine.remap_tensor(sub, None, x, [0], engine.MODE_RAW)
+    assert_bitwise(ys.cpu().numpy(),
+                   oracle.csr_matvecs(csr, x.cpu().numpy())[100:900],
+                   'row slice')
+
+
+def test_pole_capped_map_through_the_remapper(dev, tmp_path):
+    """build_map (ESMF's bilinear, pole caps and all) -> remap_numpy /
+    ncremap: the Dataset path on a split plan, against the oracle; the
+    auto-mode branch (NaN scan + gated launches) takes both launches."""
+    from oracle import oracle
+    from pyremap_amd import (
+        DataArray,
+        Dataset,
+        Remapper,
+        get_lat_lon_descriptor,
+    )
+    from pyremap_amd.io.netcdf import open_dataset, write_netcdf
+    src = get_lat_lon_descriptor(2.0, 2.0)
+    dst = get_lat_lon_descriptor(1.0, 1.0)
+    r = Remapper(map_filename=str(tmp_path / 'map.nc'), method='bilinear',
+                 map_tool='analytic', src_descriptor=src,
+                 dst_descriptor=dst)
+    r.build_map()
+    plan = r.load_mapping()
+    assert plan._split is not None
+    rowptr, c, v = plan.to_host_csr()
+    csr = oracle.OracleCSR(rowptr, c, v, (plan.n_b, plan.n_a))
+    frac_b = plan.frac_b.cpu().numpy()
+    rng = np.random.default_rng(4)
+    sst = rng.standard_normal((90, 180))
+    land = sst.copy()
+    land[20:40, 60:100] = np.nan
+    monthly = rng.standard_normal((12, 90, 180)).astype(np.float32)
+    ds = Dataset()
+    ds['sst'] = DataArray(sst, dims=('lat', 'lon'))
+    ds['land'] = DataArray(land, dims=('lat', 'lon'))
+    ds['monthly'] = DataArray(monthly, dims=('time', 'lat', 'lon'))
+    out = r.remap_numpy(ds, 0.05)
+    for name, field, axes in (('sst', sst, [0, 1]), ('land', land, [0, 1]),
+                              ('monthly', monthly, [1, 2])):
+        nan = np.isnan(field).any()
+        arg = np.ma.masked_array(field, np.isnan(field)) if nan else field
+        want = oracle.remap_numpy_array(csr, frac_b, (180, 360), arg, axes,
+                                        0.05)
+        assert_bitwise(out[name].values, np.ma.filled(want, np.nan), name)
+    # a smooth field survives, the poles included (the cap interpolates
+    # towards the mean of the last row)
+    lat = np.deg2rad(np.asarray(src.lat))[:, None]
+    lon = np.deg2rad(np.asarray(src.lon))[None, :]
+    smooth = np.sin(lat) + 0.3 * np.cos(lat) * np.cos(lon)
+    got = r.remap_numpy(DataArray(smooth, dims=('lat', 'lon'))).values
+    lat_d = np.deg2rad(np.asarray(dst.lat))[:, None]
+    lon_d = np.deg2rad(np.asarray(dst.lon))[None, :]
+    assert np.abs(got - (np.sin(lat_d) + 0.3 * np.cos(lat_d) *
+                         np.cos(lon_d))).max() < 0.01
+    write_netcdf(ds, str(tmp_path / 'in.nc'))
+    r.ncremap(str(tmp_path / 'in.nc'), str(tmp_path / 'out.nc'),
+              renormalize=0.05)
+    back = open_dataset(str(tmp_path / 'out.nc'))
+    for name in ('sst', 'land', 'monthly'):
+        assert_bitwise(back[name].values, out[name].values, name)
+
+
+def test_split_plan_on_devices_shards_and_graphs(dev):
+    """Shards of a capped map (row ranges: unsplit), the single-process
+    multi-device front end, and a captured series -- same bits."""
+    from pyremap_amd import engine
+    from pyremap_amd.parallel import MultiDeviceRemap
+    m, dims = _capped_map()
+    plan = engine.RemapPlan.from_triplets(m.row, m.col, m.S, m.frac_b, m.n_a,
+                                          m.n_b, device=dev)
+    plan.auto_schedule(dims)
+    x = torch.randn((6, m.n_a, 5), device=dev, dtype=torch.float64)
+    want = engine.remap_tensor(plan, dims, x, [1], engine.MODE_FRACB,
+                               tune=[1])            # the plain kernel
+    got = engine.remap_tensor(plan, dims, x, [1], engine.MODE_FRACB)
+    assert torch.equal(got, want)
+    multi = MultiDeviceRemap(plan, [dev, dev, dev], grid_dims=dims)
+    assert torch.equal(engine.remap_tensor(multi, dims, x, [1],
+                                           engine.MODE_FRACB), want)
+    y = torch.empty_like(want)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        engine.remap_tensor(plan, dims, x, [1], engine.MODE_FRACB, out=y)
+    x.copy_(torch.randn_like(x))
+    y.fill_(-1.0)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y, engine.remap_tensor(plan, dims, x, [1],
+                                              engine.MODE_FRACB, tune=[1]))
