@@ -675,6 +675,11 @@ def extras_todo(args, world):
             # (time = 120, lat x lon) float32, the reference's real input
             ('config1_time120_latlon_f32',
              dict(name='config1', K=120, layout='tn', dtype='f32'), 30),
+            # the same map as ESMF makes it: pole-cap rows of 360 entries,
+            # a third of all entries -- applied apart (long rows)
+            ('config1_esmf_pole_caps_K1', dict(name='config1_esmf', K=1), 50),
+            ('config1_esmf_pole_caps_K64', dict(name='config1_esmf', K=64),
+             50),
             ('f32_fields', dict(name='config3', dtype='f32'), 50),
             ('layout_T8_nCells_L64', dict(name='config3', layout='tnl'), 50),
             ('layout_T8_nCells_L60', dict(name='config3', layout='tnl',
@@ -800,7 +805,9 @@ def workload_rows(extra):
             'bytes_alg': e['bytes_alg'],
             'K': e['K'], 'mode': e['mode'], 'layout': e['layout'],
             'dtype': e.get('dtype', 'f64'), 'numbering': e['locality'],
-            'kernel': 'spmm_patchcell' if e['layout'] == 'tn' else
+            'kernel': KERNEL_OF_FAMILY.get(sched.get('family'), 'spmm_*') +
+            ' + spmm_patchcell (long rows apart)' if sched.get('long_rows')
+            else 'spmm_patchcell' if e['layout'] == 'tn' else
             'spmm_patch' if e['layout'] == 'tnl' and
             4 <= e['K'] // e.get('times', 8) < 16 else
             'spmm_rowlane' if e['K'] <= 32 else
