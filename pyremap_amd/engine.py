@@ -976,8 +976,7 @@ class RemapPlan:
         sources do not fit the LDS).
         """
         torch = _torch()
-        if self.n_b != self.n_b_global or self.row_offset != 0 or \
-                self.max_row_nnz <= self.LONG_ROW:
+        if self.max_row_nnz <= self.LONG_ROW:
             return None
         counts = self.rowptr[1:] - self.rowptr[:-1]
         is_long = counts > self.LONG_ROW
@@ -989,16 +988,19 @@ class RemapPlan:
             return None
         entry_long = torch.repeat_interleave(is_long, counts)
 
-        def sub(rows_kept, entries_kept, n_rows, frac):
+        def sub(rows_kept, entries_kept, n_rows, **where):
             rp = torch.zeros(n_rows + 1, dtype=torch.int64,
                              device=self.device)
             rp[1:] = torch.cumsum(rows_kept, 0)
             return RemapPlan(self.n_a, n_rows, rp,
                              self.col[entries_kept].contiguous(),
-                             self.val[entries_kept].contiguous(), frac)
+                             self.val[entries_kept].contiguous(),
+                             self.frac_b, **where)
+        # (a row shard splits like a whole mapping: same place in the grid)
         short = sub(torch.where(is_long, torch.zeros_like(counts), counts),
-                    ~entry_long, self.n_b, self.frac_b)
-        long = sub(counts[ids], entry_long, n_long, self.frac_b)
+                    ~entry_long, self.n_b, row_offset=self.row_offset,
+                    n_b_global=self.n_b_global)
+        long = sub(counts[ids], entry_long, n_long)
         # the long rows' patch plan: 256 consecutive long rows per workgroup,
         # halved until the distinct source rows fit the LDS with 4 fields
         # per lane; work slot -> row of the WHOLE mapping

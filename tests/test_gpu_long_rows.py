@@ -191,6 +191,10 @@ def test_split_plan_on_devices_shards_and_graphs(dev):
     got = engine.remap_tensor(plan, dims, x, [1], engine.MODE_FRACB)
     assert torch.equal(got, want)
     multi = MultiDeviceRemap(plan, [dev, dev, dev], grid_dims=dims)
+    # the first and the last shard hold a pole cap each: split like the whole
+    assert multi.shards[0].plan._split is not None
+    assert multi.shards[1].plan._split is None
+    assert multi.shards[2].plan._split is not None
     assert torch.equal(engine.remap_tensor(multi, dims, x, [1],
                                            engine.MODE_FRACB), want)
     y = torch.empty_like(want)
