@@ -455,7 +455,11 @@ int remap_schedule_auto(const remap_csr *A, const double *frac_b,
  *   Synchronous on `stream`.  REMAP_ERR_ARG if a triplet is out of range.
  * remap_plan_apply = `_remap_numpy_array` (:223-297): one fused launch over
  *   all rows, asynchronous on `stream`; field layout and modes as in
- *   remap_apply_args (same names, same meaning).
+ *   remap_apply_args (same names, same meaning).  (Two launches writing
+ *   disjoint rows for a mapping whose few LONG rows -- more than 96 entries:
+ *   the pole caps of a global bilinear map as ESMF makes it -- hold 2 % of
+ *   the entries or more: remap_plan_create keeps those rows apart, see
+ *   patch_ell_base.)
  *   The calling thread's current HIP device must be the one the plan was
  *   created on (REMAP_ERR_ARG otherwise: the launch would run against
  *   another device's pointers).

@@ -43,6 +43,21 @@ struct remap_plan {
     double *cell_val = nullptr;
     int32_t cell_rows = 0, cell_umax = 0, cell_emax = 0;
     int64_t cell_patches = 0;
+    // LONG ROWS APART (split_long_rows): rowptr / col / val above then hold
+    // the mapping WITHOUT its long rows' entries (schedule and short-run
+    // patches are built on that), the long rows live here: their CSR, the
+    // rows they are in the whole mapping, and their patch plan with the
+    // entries column-major (remap_apply_args.patch_ell_base)
+    int64_t n_long = 0, long_nnz = 0, long_max_row = 0;
+    int64_t *long_rowptr = nullptr;
+    int32_t *long_col = nullptr, *long_ids = nullptr;
+    double *long_val = nullptr;
+    int32_t *long_ptr = nullptr, *long_ucol = nullptr,
+            *long_prow = nullptr, *long_lidx = nullptr;
+    double *long_pval = nullptr;
+    int64_t *long_base = nullptr;
+    int32_t long_rows = 0, long_umax = 0, long_emax = 0;
+    int64_t long_patches = 0;
 };
 
 namespace remap {
@@ -100,6 +115,289 @@ int to_device(Owned &own, const T *src, int64_t n, bool on_host,
     REMAP_HIP_CHECK(hipMemcpyAsync(d, src, static_cast<size_t>(n) * sizeof(T),
                                    hipMemcpyHostToDevice, stream));
     *out = static_cast<const T *>(d);
+    return REMAP_OK;
+}
+
+// one wave per destination row: its entries from row rows[d] (or d) of the
+// source CSR
+__global__ __launch_bounds__(256) void copy_rows_kernel(
+    const int64_t *__restrict__ src_rowptr, const int32_t *__restrict__ rows,
+    const int64_t n_dst, const int64_t *__restrict__ dst_rowptr,
+    const int32_t *__restrict__ col, const double *__restrict__ val,
+    int32_t *__restrict__ col_dst, double *__restrict__ val_dst)
+{
+    const int64_t d = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (d >= n_dst)
+        return;
+    const int lane = threadIdx.x & 63;
+    const int64_t s = src_rowptr[rows ? rows[d] : d];
+    const int64_t o = dst_rowptr[d];
+    const int64_t n = dst_rowptr[d + 1] - o;
+    for (int64_t j = lane; j < n; j += 64) {
+        col_dst[o + j] = col[s + j];
+        val_dst[o + j] = val[s + j];
+    }
+}
+
+// one wave per slot of the long rows' patch plan: its entries to their
+// column-major places (entry j of slot r of patch p at base[p] + j * rows + r)
+__global__ __launch_bounds__(256) void column_major_kernel(
+    const int32_t *__restrict__ prow, const int32_t *__restrict__ lidx,
+    const double *__restrict__ val, const int64_t *__restrict__ base,
+    const int32_t rows, const int64_t n_slots, int32_t *__restrict__ lidx_t,
+    double *__restrict__ val_t)
+{
+    const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= n_slots)
+        return;
+    const int lane = threadIdx.x & 63;
+    const int64_t patch = g / rows;
+    const int64_t r = g - patch * rows;
+    const int32_t s = prow[g];
+    const int32_t n = prow[g + 1] - s;
+    const int64_t b = base[patch] + r;
+    for (int32_t j = lane; j < n; j += 64) {
+        lidx_t[b + (int64_t)j * rows] = lidx[s + j];
+        val_t[b + (int64_t)j * rows] = val[s + j];
+    }
+}
+
+// a row counts as LONG from this many entries on (engine.RemapPlan.LONG_ROW)
+constexpr int64_t kLongRow = 96;
+// LDS the lanes-across-rows kernel may take (kPatchLdsMax), 4 fields a lane
+constexpr int64_t kLongUmax = 160 * 1024 / (4 * 8) - 2;
+
+// Mappings whose few long rows hold a large share of the entries (the pole
+// caps of a global bilinear map as ESMF makes it): the plan keeps the mapping
+// without those rows' entries and the long rows apart, applied by two
+// launches writing disjoint rows -- engine.RemapPlan._split_long_rows, same
+// criteria, same layout.  `h_rowptr`: the CSR's row pointers on the host.
+// Leaves the plan untouched when the mapping has no such rows.
+int split_long_rows(remap_plan *plan, Owned &own,
+                    const std::vector<int64_t> &h_rowptr, hipStream_t stream)
+{
+    const int64_t n_b = plan->n_b;
+    if (plan->max_row_nnz <= kLongRow)
+        return REMAP_OK;
+    std::vector<int32_t> ids;
+    std::vector<int64_t> h_short(static_cast<size_t>(n_b + 1), 0);
+    std::vector<int64_t> h_long(1, 0);
+    int64_t long_max = 0;
+    for (int64_t i = 0; i < n_b; ++i) {
+        const int64_t len = h_rowptr[i + 1] - h_rowptr[i];
+        if (len > kLongRow) {
+            ids.push_back(static_cast<int32_t>(i));
+            h_long.push_back(h_long.back() + len);
+            h_short[i + 1] = h_short[i];
+            if (len > long_max)
+                long_max = len;
+        } else {
+            h_short[i + 1] = h_short[i] + len;
+        }
+    }
+    const int64_t n_long = static_cast<int64_t>(ids.size());
+    const int64_t long_nnz = h_long.back();
+    const int64_t short_nnz = h_short[n_b];
+    if (n_long == 0 || n_long > n_b / 8 || long_nnz < plan->nnz / 50)
+        return REMAP_OK;
+    int rc;
+    void *p = nullptr;
+    // the two CSRs
+    int64_t *s_rowptr = nullptr;
+    int32_t *s_col = nullptr;
+    double *s_val = nullptr;
+    if ((rc = own.alloc(&p, static_cast<size_t>(n_b + 1) * 8)) != REMAP_OK)
+        return rc;
+    s_rowptr = static_cast<int64_t *>(p);
+    if ((rc = own.alloc(&p, static_cast<size_t>(short_nnz + kCsrPad) * 4)) !=
+        REMAP_OK)
+        return rc;
+    s_col = static_cast<int32_t *>(p);
+    if ((rc = own.alloc(&p, static_cast<size_t>(short_nnz + kCsrPad) * 8)) !=
+        REMAP_OK)
+        return rc;
+    s_val = static_cast<double *>(p);
+    if ((rc = own.alloc(&p, static_cast<size_t>(n_long + 1) * 8)) != REMAP_OK)
+        return rc;
+    plan->long_rowptr = static_cast<int64_t *>(p);
+    if ((rc = own.alloc(&p, static_cast<size_t>(long_nnz + kCsrPad) * 4)) !=
+        REMAP_OK)
+        return rc;
+    plan->long_col = static_cast<int32_t *>(p);
+    if ((rc = own.alloc(&p, static_cast<size_t>(long_nnz + kCsrPad) * 8)) !=
+        REMAP_OK)
+        return rc;
+    plan->long_val = static_cast<double *>(p);
+    if ((rc = own.alloc(&p, static_cast<size_t>(n_long) * 4)) != REMAP_OK)
+        return rc;
+    plan->long_ids = static_cast<int32_t *>(p);
+    REMAP_HIP_CHECK(hipMemcpyAsync(s_rowptr, h_short.data(),
+                                   static_cast<size_t>(n_b + 1) * 8,
+                                   hipMemcpyHostToDevice, stream));
+    REMAP_HIP_CHECK(hipMemcpyAsync(plan->long_rowptr, h_long.data(),
+                                   static_cast<size_t>(n_long + 1) * 8,
+                                   hipMemcpyHostToDevice, stream));
+    REMAP_HIP_CHECK(hipMemcpyAsync(plan->long_ids, ids.data(),
+                                   static_cast<size_t>(n_long) * 4,
+                                   hipMemcpyHostToDevice, stream));
+    REMAP_HIP_CHECK(hipMemsetAsync(s_col + short_nnz, 0, kCsrPad * 4, stream));
+    REMAP_HIP_CHECK(hipMemsetAsync(s_val + short_nnz, 0, kCsrPad * 8, stream));
+    REMAP_HIP_CHECK(hipMemsetAsync(plan->long_col + long_nnz, 0, kCsrPad * 4,
+                                   stream));
+    REMAP_HIP_CHECK(hipMemsetAsync(plan->long_val + long_nnz, 0, kCsrPad * 8,
+                                   stream));
+    hipLaunchKernelGGL(copy_rows_kernel,
+                       dim3(static_cast<uint32_t>((n_b + 3) / 4)), dim3(256),
+                       0, stream, plan->rowptr, nullptr, n_b, s_rowptr,
+                       plan->col, plan->val, s_col, s_val);
+    hipLaunchKernelGGL(copy_rows_kernel,
+                       dim3(static_cast<uint32_t>((n_long + 3) / 4)),
+                       dim3(256), 0, stream, plan->rowptr, plan->long_ids,
+                       n_long, plan->long_rowptr, plan->col, plan->val,
+                       plan->long_col, plan->long_val);
+    REMAP_HIP_CHECK(hipGetLastError());
+
+    // the long rows' patch plan: 256 consecutive long rows per workgroup,
+    // halved until the distinct source rows fit the LDS
+    size_t ws_bytes = 0;
+    if ((rc = remap_patches_workspace(n_long, long_nnz, &ws_bytes)) !=
+        REMAP_OK)
+        return rc;
+    void *ws = nullptr, *stats = nullptr, *pl = nullptr, *pv = nullptr;
+    if ((rc = own.alloc(&ws, ws_bytes)) != REMAP_OK ||
+        (rc = own.alloc(&stats, 24)) != REMAP_OK)
+        return rc;
+    if ((rc = own.alloc(&p, static_cast<size_t>(n_long + 1) * 4)) != REMAP_OK)
+        return rc;
+    plan->long_ptr = static_cast<int32_t *>(p);
+    if ((rc = own.alloc(&p, static_cast<size_t>(long_nnz) * 4)) != REMAP_OK)
+        return rc;
+    plan->long_ucol = static_cast<int32_t *>(p);
+    if ((rc = own.alloc(&p, static_cast<size_t>(n_long + 1) * 4)) != REMAP_OK)
+        return rc;
+    plan->long_prow = static_cast<int32_t *>(p);
+    if ((rc = own.alloc(&pl, static_cast<size_t>(long_nnz) * 4)) != REMAP_OK ||
+        (rc = own.alloc(&pv, static_cast<size_t>(long_nnz) * 8)) != REMAP_OK)
+        return rc;
+    remap_csr A;
+    A.n_rows = n_long;
+    A.n_cols = plan->n_a;
+    A.nnz = long_nnz;
+    A.rowptr = plan->long_rowptr;
+    A.col = plan->long_col;
+    A.val = plan->long_val;
+    A.max_row_nnz = long_max;
+    A.csr_pad = kCsrPad;
+    int32_t tx = 256;
+    int64_t h[3] = {0, 0, 0};
+    for (;;) {
+        rc = remap_patches_build(&A, nullptr, 0, 1, tx, nullptr,
+                                 plan->long_ptr, plan->long_ucol,
+                                 plan->long_prow, static_cast<int32_t *>(pl),
+                                 static_cast<double *>(pv),
+                                 static_cast<int64_t *>(stats), ws, ws_bytes,
+                                 stream);
+        if (rc != REMAP_OK)
+            return rc;
+        REMAP_HIP_CHECK(hipMemcpyAsync(h, stats, 24, hipMemcpyDeviceToHost,
+                                       stream));
+        REMAP_HIP_CHECK(hipStreamSynchronize(stream));
+        if (h[1] <= kLongUmax)
+            break;
+        if (tx == 1) {
+            // no patch of long rows fits the LDS: the mapping stays whole
+            for (void *q : {static_cast<void *>(s_rowptr),
+                            static_cast<void *>(s_col),
+                            static_cast<void *>(s_val),
+                            static_cast<void *>(plan->long_rowptr),
+                            static_cast<void *>(plan->long_col),
+                            static_cast<void *>(plan->long_val),
+                            static_cast<void *>(plan->long_ids),
+                            static_cast<void *>(plan->long_ptr),
+                            static_cast<void *>(plan->long_ucol),
+                            static_cast<void *>(plan->long_prow), pl, pv, ws,
+                            stats})
+                own.free_now(q);
+            plan->long_rowptr = nullptr;
+            plan->long_col = plan->long_ids = plan->long_ptr =
+                plan->long_ucol = plan->long_prow = nullptr;
+            plan->long_val = nullptr;
+            return REMAP_OK;
+        }
+        tx /= 2;
+    }
+    // the entries column-major inside every patch
+    const int64_t n_patches = (n_long + tx - 1) / tx;
+    std::vector<int32_t> h_prow(static_cast<size_t>(n_long + 1));
+    REMAP_HIP_CHECK(hipMemcpyAsync(h_prow.data(), plan->long_prow,
+                                   static_cast<size_t>(n_long + 1) * 4,
+                                   hipMemcpyDeviceToHost, stream));
+    REMAP_HIP_CHECK(hipStreamSynchronize(stream));
+    std::vector<int64_t> h_base(static_cast<size_t>(n_patches), 0);
+    int64_t total = 0;
+    for (int64_t q = 0; q < n_patches; ++q) {
+        int64_t longest = 0;
+        for (int64_t g = q * tx; g < n_long && g < (q + 1) * tx; ++g)
+            if (h_prow[g + 1] - h_prow[g] > longest)
+                longest = h_prow[g + 1] - h_prow[g];
+        h_base[q] = total;
+        total += longest * tx;
+    }
+    if ((rc = own.alloc(&p, static_cast<size_t>(n_patches) * 8)) != REMAP_OK)
+        return rc;
+    plan->long_base = static_cast<int64_t *>(p);
+    if ((rc = own.alloc(&p, static_cast<size_t>(total + kCsrPad) * 4)) !=
+        REMAP_OK)
+        return rc;
+    plan->long_lidx = static_cast<int32_t *>(p);
+    if ((rc = own.alloc(&p, static_cast<size_t>(total + kCsrPad) * 8)) !=
+        REMAP_OK)
+        return rc;
+    plan->long_pval = static_cast<double *>(p);
+    REMAP_HIP_CHECK(hipMemcpyAsync(plan->long_base, h_base.data(),
+                                   static_cast<size_t>(n_patches) * 8,
+                                   hipMemcpyHostToDevice, stream));
+    REMAP_HIP_CHECK(hipMemsetAsync(plan->long_lidx, 0,
+                                   static_cast<size_t>(total + kCsrPad) * 4,
+                                   stream));
+    REMAP_HIP_CHECK(hipMemsetAsync(plan->long_pval, 0,
+                                   static_cast<size_t>(total + kCsrPad) * 8,
+                                   stream));
+    hipLaunchKernelGGL(column_major_kernel,
+                       dim3(static_cast<uint32_t>((n_long + 3) / 4)),
+                       dim3(256), 0, stream, plan->long_prow,
+                       static_cast<const int32_t *>(pl),
+                       static_cast<const double *>(pv), plan->long_base, tx,
+                       n_long, plan->long_lidx, plan->long_pval);
+    REMAP_HIP_CHECK(hipGetLastError());
+    REMAP_HIP_CHECK(hipStreamSynchronize(stream));
+    own.free_now(pl);
+    own.free_now(pv);
+    own.free_now(ws);
+    own.free_now(stats);
+    // the plan's CSR becomes the mapping without the long rows' entries
+    own.free_now(plan->rowptr);
+    own.free_now(plan->col);
+    own.free_now(plan->val);
+    plan->rowptr = s_rowptr;
+    plan->col = s_col;
+    plan->val = s_val;
+    plan->n_long = n_long;
+    plan->long_nnz = long_nnz;
+    plan->long_max_row = long_max;
+    plan->long_rows = tx;
+    plan->long_umax = static_cast<int32_t>(h[1]);
+    plan->long_emax = static_cast<int32_t>(h[2]);
+    plan->long_patches = n_patches;
+    plan->max_row_nnz = 0;
+    for (int64_t i = 0; i < n_b; ++i)
+        if (h_short[i + 1] - h_short[i] > plan->max_row_nnz)
+            plan->max_row_nnz = h_short[i + 1] - h_short[i];
+    plan->device_bytes += static_cast<size_t>(n_long + 1) * 16 +
+                          static_cast<size_t>(long_nnz + kCsrPad) * 16 +
+                          static_cast<size_t>(n_long) * 4 +
+                          static_cast<size_t>(total + kCsrPad) * 12 +
+                          static_cast<size_t>(n_patches) * 8;
     return REMAP_OK;
 }
 
@@ -233,11 +531,16 @@ int create(int64_t n_b, int64_t n_a, int64_t n_s, const int32_t *row,
         own.free_now(const_cast<double *>(d_S));
     }
 
-    // 3. the schedule this mapping gets
+    // 3. long rows apart (pole caps of ESMF-made global bilinear maps), then
+    //    the schedule the rest of the mapping gets
+    if (n_dims > 0 && plan->nnz > 0 &&
+        (rc = split_long_rows(plan, own, h_rowptr, stream)) != REMAP_OK)
+        return rc;
+    const int64_t sched_nnz = plan->nnz - plan->long_nnz;
     plan->sched = remap_schedule();
-    if (n_dims > 0 && plan->nnz > 0) {
+    if (n_dims > 0 && sched_nnz > 0) {
         size_t arena_bytes = 0, ws2_bytes = 0;
-        if ((rc = remap_schedule_sizes(n_b, plan->nnz, &arena_bytes,
+        if ((rc = remap_schedule_sizes(n_b, sched_nnz, &arena_bytes,
                                        &ws2_bytes)) != REMAP_OK)
             return rc;
         void *ws2 = nullptr;
@@ -247,7 +550,7 @@ int create(int64_t n_b, int64_t n_a, int64_t n_s, const int32_t *row,
         remap_csr A;
         A.n_rows = n_b;
         A.n_cols = n_a;
-        A.nnz = plan->nnz;
+        A.nnz = sched_nnz;
         A.rowptr = plan->rowptr;
         A.col = plan->col;
         A.val = plan->val;
@@ -271,12 +574,22 @@ int create(int64_t n_b, int64_t n_a, int64_t n_s, const int32_t *row,
     for (void *q : {static_cast<void *>(plan->rowptr),
                     static_cast<void *>(plan->col),
                     static_cast<void *>(plan->val),
-                    static_cast<void *>(plan->frac_b), plan->arena})
+                    static_cast<void *>(plan->frac_b), plan->arena,
+                    static_cast<void *>(plan->long_rowptr),
+                    static_cast<void *>(plan->long_col),
+                    static_cast<void *>(plan->long_val),
+                    static_cast<void *>(plan->long_ids),
+                    static_cast<void *>(plan->long_ptr),
+                    static_cast<void *>(plan->long_ucol),
+                    static_cast<void *>(plan->long_prow),
+                    static_cast<void *>(plan->long_lidx),
+                    static_cast<void *>(plan->long_pval),
+                    static_cast<void *>(plan->long_base)})
         if (q)
             own.release(q);
-    plan->device_bytes =
+    plan->device_bytes +=
         static_cast<size_t>(n_b + 1) * 8 +
-        static_cast<size_t>(n_s + kCsrPad) * 12 +
+        static_cast<size_t>(sched_nnz + kCsrPad) * 12 +
         static_cast<size_t>(n_b) * 8 +
         (plan->arena ? plan->sched.arena_used : 0);
     guard.p = nullptr;
@@ -292,9 +605,11 @@ size_t align256(size_t n) { return (n + 255) / 256 * 256; }
 
 int prepare_short_runs(remap_plan *plan, hipStream_t stream)
 {
-    if (plan->cell_arena || plan->nnz == 0 || plan->n_b == 0)
+    // (a split plan: the mapping without its long rows' entries)
+    const int64_t nnz = plan->nnz - plan->long_nnz;
+    if (plan->cell_arena || nnz == 0 || plan->n_b == 0)
         return REMAP_OK;
-    const int64_t n_b = plan->n_b, nnz = plan->nnz;
+    const int64_t n_b = plan->n_b;
     Owned own;
     size_t ws_bytes = 0;
     int rc = remap_patches_workspace(n_b, nnz, &ws_bytes);
@@ -409,7 +724,17 @@ void remap_plan_destroy(remap_plan *plan)
                     static_cast<void *>(plan->col),
                     static_cast<void *>(plan->val),
                     static_cast<void *>(plan->frac_b), plan->arena,
-                    plan->cell_arena})
+                    plan->cell_arena,
+                    static_cast<void *>(plan->long_rowptr),
+                    static_cast<void *>(plan->long_col),
+                    static_cast<void *>(plan->long_val),
+                    static_cast<void *>(plan->long_ids),
+                    static_cast<void *>(plan->long_ptr),
+                    static_cast<void *>(plan->long_ucol),
+                    static_cast<void *>(plan->long_prow),
+                    static_cast<void *>(plan->long_lidx),
+                    static_cast<void *>(plan->long_pval),
+                    static_cast<void *>(plan->long_base)})
         if (p)
             (void)hipFree(p);
     if (switched)
@@ -424,7 +749,9 @@ int remap_plan_query(const remap_plan *plan, remap_plan_info *info_out)
     info_out->n_a = plan->n_a;
     info_out->n_b = plan->n_b;
     info_out->nnz = plan->nnz;
-    info_out->max_row_nnz = plan->max_row_nnz;
+    info_out->max_row_nnz = plan->long_max_row > plan->max_row_nnz
+                                ? plan->long_max_row
+                                : plan->max_row_nnz;
     info_out->family = plan->sched.family;
     info_out->group_rows = plan->sched.group_rows;
     info_out->ratio = plan->sched.ratio;
@@ -458,7 +785,7 @@ int remap_plan_apply(const remap_plan *plan, const remap_field *f,
     remap_apply_args a = remap_apply_args();
     a.A.n_rows = plan->n_b;
     a.A.n_cols = plan->n_a;
-    a.A.nnz = plan->nnz;
+    a.A.nnz = plan->nnz - plan->long_nnz;
     a.A.rowptr = plan->rowptr;
     a.A.col = plan->col;
     a.A.val = plan->val;
@@ -502,9 +829,7 @@ int remap_plan_apply(const remap_plan *plan, const remap_field *f,
         a.tune[0] = 7;
         a.tune[1] = f->n_batch * f->k_inner >= 16 ? 8 : 4;
         a.flags |= REMAP_FLAG_TUNE_HINT;
-        return remap_apply_f64(&a, stream);
-    }
-    if (s.family != 0) {
+    } else if (s.family != 0) {
         a.row_order = s.row_order;
         a.patch_ptr = s.patch_ptr;
         a.patch_ucol = s.patch_ucol;
@@ -528,7 +853,56 @@ int remap_plan_apply(const remap_plan *plan, const remap_field *f,
             a.tune[t] = s.tune[f->mode][t];
         a.flags |= REMAP_FLAG_TUNE_HINT;
     }
-    return remap_apply_f64(&a, stream);
+    const int rc = remap_apply_f64(&a, stream);
+    if (rc != REMAP_OK || plan->n_long == 0)
+        return rc;
+    // the long rows, apart (split_long_rows): the lanes-across-rows kernel
+    // on their own patch plan, entries column-major; slot -> row of the
+    // whole mapping through row_order.  Few fields per lane: a long row is
+    // one dependent chain (engine.apply_strided has the measurements).
+    remap_apply_args b = remap_apply_args();
+    b.A.n_rows = plan->n_long;
+    b.A.n_cols = plan->n_a;
+    b.A.nnz = plan->long_nnz;
+    b.A.rowptr = plan->long_rowptr;
+    b.A.col = plan->long_col;
+    b.A.val = plan->long_val;
+    b.A.max_row_nnz = plan->long_max_row;
+    b.A.csr_pad = remap::kCsrPad;
+    b.row_begin = 0;
+    b.row_end = plan->n_long;
+    b.X = f->X;
+    b.x_dtype = f->x_dtype;
+    b.mode = f->mode;
+    b.x_row_stride = f->x_row_stride;
+    b.x_batch_stride = f->x_batch_stride;
+    b.Y = f->Y;
+    b.y_row_stride = f->y_row_stride;
+    b.y_batch_stride = f->y_batch_stride;
+    b.n_batch = f->n_batch;
+    b.k_inner = f->k_inner;
+    b.frac_b = a.frac_b;
+    b.threshold = f->threshold;
+    b.mask_out = f->mask_out;
+    b.gate = f->gate;
+    b.gate_value = f->gate_value;
+    b.row_order = plan->long_ids;
+    b.patch_ptr = plan->long_ptr;
+    b.patch_ucol = plan->long_ucol;
+    b.patch_rowptr = plan->long_prow;
+    b.patch_lidx = plan->long_lidx;
+    b.patch_val = plan->long_pval;
+    b.patch_rows = plan->long_rows;
+    b.patch_umax = plan->long_umax;
+    b.patch_emax = plan->long_emax;
+    b.patch_row_bytes = 1024;
+    b.n_patches = plan->long_patches;
+    b.patch_ell_base = plan->long_base;
+    const int64_t K = static_cast<int64_t>(f->n_batch) * f->k_inner;
+    b.tune[0] = 7;
+    b.tune[1] = K <= 8 ? 1 : K <= 128 ? 2 : 4;
+    b.flags = f->flags | REMAP_FLAG_TUNE_HINT;
+    return remap_apply_f64(&b, stream);
 }
 
 }  // extern "C"

@@ -207,3 +207,90 @@ def test_split_plan_on_devices_shards_and_graphs(dev):
     torch.cuda.synchronize()
     assert torch.equal(y, engine.remap_tensor(plan, dims, x, [1],
                                               engine.MODE_FRACB, tune=[1]))
+
+
+@pytest.mark.parametrize('which', ['pole caps', 'ragged'])
+def test_plan_handle_applies_long_rows_apart(dev, which):
+    """The C plan handle (`remap_plan_create` / `_apply`) makes the same
+    split inside the library: host triplets in, two launches per apply, the
+    oracle's bits out -- (n_a, K), (Time, n_a) before and after
+    `remap_plan_prepare_short_runs`, float32, masked."""
+    import ctypes
+
+    from oracle import oracle
+    from pyremap_amd import engine
+    lib = engine.load_library()
+    if which == 'pole caps':
+        m, dims = _capped_map()
+        row, col, S, frac_b, n_a, n_b = m.row, m.col, m.S, m.frac_b, \
+            m.n_a, m.n_b
+    else:
+        mm, n_a, n_b, dims = _ragged_long_map(seed=7)
+        row, col, S, frac_b = mm['row'], mm['col'], mm['S'], mm['frac_b']
+    csr = oracle.coo_to_csr(np.asarray(row) - 1, np.asarray(col) - 1,
+                            np.asarray(S), n_b, n_a)
+
+    def ptr(a):
+        return a.ctypes.data_as(ctypes.c_void_p)
+    row32 = np.ascontiguousarray(row, dtype=np.int32)
+    col32 = np.ascontiguousarray(col, dtype=np.int32)
+    S64 = np.ascontiguousarray(S, dtype=np.float64)
+    fb = np.ascontiguousarray(frac_b, dtype=np.float64)
+    cdims = (ctypes.c_int64 * 2)(*dims)
+    handle = ctypes.c_void_p()
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = lib.remap_plan_create(n_b, n_a, S64.size, ptr(row32), ptr(col32),
+                               ptr(S64), 1, ptr(fb), 1, cdims, 2, stream,
+                               ctypes.byref(handle))
+    assert rc == 0, lib.remap_last_error()
+    try:
+        info = engine._PlanInfo()
+        assert lib.remap_plan_query(handle, ctypes.byref(info)) == 0
+        assert info.nnz == len(csr.data)
+        assert info.max_row_nnz == int(np.diff(csr.indptr).max()) > 96
+        assert info.family in (5, 10)     # the REST got a real schedule
+        rng = np.random.default_rng(6)
+        for prepared in (False, True):
+            if prepared:
+                assert lib.remap_plan_prepare_short_runs(handle, stream) == 0
+            for shape, axis in (((n_a, 1), 0), ((n_a, 12), 0),
+                                ((n_a, 200), 0), ((30, n_a), 1),
+                                ((4, n_a, 9), 1)):
+                for dtype in (np.float64, np.float32):
+                    x = rng.standard_normal(shape).astype(dtype)
+                    x[(slice(None),) * axis + (rng.random(n_a) < 0.2,)] = \
+                        np.nan
+                    for masked in (False, True):
+                        arg = np.ma.masked_array(x, np.isnan(x)) if masked \
+                            else x
+                        want = np.ma.filled(oracle.remap_numpy_array(
+                            csr, fb, dims, arg, [axis],
+                            0.2 if masked else None), np.nan)
+                        X = torch.from_numpy(x).to(dev)
+                        lead = shape[:axis]
+                        tail = shape[axis + 1:]
+                        Y = torch.full(lead + (n_b,) + tail, 3.0,
+                                       dtype=torch.float64, device=dev)
+                        f = engine._Field()
+                        f.X, f.Y = X.data_ptr(), Y.data_ptr()
+                        f.x_dtype = engine.DTYPE_F64 \
+                            if dtype == np.float64 else engine.DTYPE_F32
+                        f.mode = engine.MODE_MASKED if masked \
+                            else engine.MODE_FRACB
+                        f.threshold = 0.2
+                        inner = int(np.prod(tail)) if tail else 1
+                        f.n_batch = int(np.prod(lead)) if lead else 1
+                        f.k_inner = inner
+                        f.x_row_stride = f.y_row_stride = inner
+                        f.x_batch_stride = n_a * inner
+                        f.y_batch_stride = n_b * inner
+                        s = ctypes.c_void_p(
+                            torch.cuda.current_stream().cuda_stream)
+                        rc = lib.remap_plan_apply(handle, ctypes.byref(f), s)
+                        assert rc == 0, lib.remap_last_error()
+                        assert_bitwise(
+                            Y.cpu().numpy().reshape(want.shape), want,
+                            f'{which} {shape} {dtype.__name__} masked '
+                            f'{masked} prepared {prepared}')
+    finally:
+        lib.remap_plan_destroy(handle)
