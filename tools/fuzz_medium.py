@@ -45,6 +45,30 @@ def one(seed, dev):
             int(rng.integers(5000, 80000)), (my, mx), lo, hi, seed=seed,
             device=dev, signed=kind == 'rich',
             locality=str(rng.choice(['raster', 'mesh', 'scatter'])))
+    if rng.random() < 0.35:
+        # a few LONG rows (pole caps of an ESMF-made map, or no structure at
+        # all): applied apart, RemapPlan._split_long_rows
+        import torch as _t
+        n_long = int(rng.integers(1, 60))
+        rows = rng.choice(m.n_b, n_long, replace=False)
+        if rng.random() < 0.5:           # consecutive rows sharing a ring
+            rows = (int(rows[0]) + np.arange(n_long)) % m.n_b
+            ring = np.sort(rng.choice(m.n_a, int(rng.integers(100, min(
+                1500, m.n_a))), replace=False))
+            cols = [ring for _ in rows]
+        else:
+            cols = [rng.choice(m.n_a, int(rng.integers(97, min(900, m.n_a))),
+                               replace=False) for _ in rows]
+        add_row = np.concatenate([np.full(len(c), r + 1)
+                                  for r, c in zip(rows, cols)])
+        add_col = np.concatenate(cols) + 1
+        add_S = rng.standard_normal(len(add_col)) / 50.0
+        m.row = _t.cat([m.row, _t.as_tensor(add_row, dtype=m.row.dtype,
+                                            device=dev)])
+        m.col = _t.cat([m.col, _t.as_tensor(add_col, dtype=m.col.dtype,
+                                            device=dev)])
+        m.S = _t.cat([m.S, _t.as_tensor(add_S, device=dev)])
+        m.frac_b[_t.as_tensor(rows, device=dev)] = 0.75
     plan = engine.RemapPlan.from_triplets(m.row, m.col, m.S, m.frac_b, m.n_a,
                                           m.n_b, device=dev)
     sched = plan.auto_schedule(m.dst_dims) if rng.random() < 0.85 else None
