@@ -479,3 +479,47 @@ def test_mpas_source_point_location_and_errors():
     bare = MpasCellMeshDescriptor(mesh_name='m', lat=lat, lon=lon)
     with pytest.raises(ValueError, match='mesh file'):
         build_weights(bare, pts, 'bilinear')
+
+
+def test_bilinear_descending_shifted_and_regional_sources():
+    """Source axes as files really hold them: latitudes north to south,
+    longitudes from -180; and a regional source (no closure, no caps: points
+    outside the hull of its cell centres stay unmapped)."""
+    from pyremap_amd.weights import _unit
+    dst = get_lat_lon_descriptor(2.0, 2.0)
+    lat_d, lon_d = np.meshgrid(dst.lat, dst.lon, indexing='ij')
+    f = lambda la, lo: np.sin(np.radians(la)) + \
+        0.3 * np.cos(np.radians(la)) * np.cos(np.radians(lo))
+    src = LatLonGridDescriptor.create(np.linspace(90.0, -90.0, 37),
+                                      np.linspace(-180.0, 180.0, 73),
+                                      units='degrees')
+    assert src.regional is False and src.lat[0] > src.lat[-1]
+    m = build_weights(src, dst, 'bilinear')
+    A = _dense(m)
+    assert np.all(m.frac_b == 1.0)
+    lat_s, lon_s = np.meshgrid(src.lat, src.lon, indexing='ij')
+    assert np.abs(A @ f(lat_s, lon_s).ravel() -
+                  f(lat_d, lon_d).ravel()).max() < 2e-3
+    count = np.bincount(m.row - 1, minlength=m.n_b)
+    assert (count > 4).sum() == 2 * 180          # one capped row per pole
+    P = _unit(np.radians(lat_s), np.radians(lon_s)).reshape(-1, 3)
+    q = _unit(np.radians(lat_d), np.radians(lon_d)).reshape(-1, 3)
+    R = A @ P
+    R /= np.linalg.norm(R, axis=1)[:, None]
+    assert np.abs(R - q)[count <= 4].max() < 1e-14
+    # regional
+    src = LatLonGridDescriptor.create(np.linspace(10.0, 50.0, 21),
+                                      np.linspace(-30.0, 40.0, 36),
+                                      units='degrees')
+    assert src.regional is True
+    m = build_weights(src, dst, 'bilinear')
+    lon_w = (lon_d.ravel() + 180.0) % 360.0 - 180.0
+    inside = (lat_d.ravel() >= src.lat.min()) & \
+        (lat_d.ravel() <= src.lat.max()) & (lon_w >= src.lon.min()) & \
+        (lon_w <= src.lon.max())
+    assert np.array_equal(m.frac_b > 0, inside) and inside.sum() == 700
+    assert np.bincount(m.row - 1, minlength=m.n_b).max() <= 4
+    A = _dense(m)
+    lat_s, lon_s = np.meshgrid(src.lat, src.lon, indexing='ij')
+    got = A @ f(lat_s, lon_s).ravel()
+    assert np.abs(got - f(lat_d.ravel(), lon_w))[inside].max() < 1e-3
