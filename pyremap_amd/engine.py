@@ -1037,7 +1037,6 @@ class RemapPlan:
         q['ell_base'] = base.contiguous()
         q['layout'] = 'column-major'
         long._cell = q
-        long._long_of = self.n_b
         return short, long
 
     def auto_schedule(self, grid_dims, _split_ok=True):
