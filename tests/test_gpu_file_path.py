@@ -667,6 +667,29 @@ def test_examples_run(tmp_path, monkeypatch):
     assert out2['temperature'].shape == (3, 18, 36, 4)
     assert 'other' not in out2.variables
     assert np.nanmax(np.abs(out2['temperature'].values)) < 10.0   # no fills
+    # -- the reference's make_mpas_to_lat_lon_mapping.py workflow, no ESMF ---
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden',
+                        'ref_fixtures')
+    r3 = load('make_mpas_to_lat_lon_mapping').main(
+        ['--mesh', os.path.join(gold, 'mpasMesh.nc'), '--mesh-name',
+         'oQU240', '-i', os.path.join(gold, 'timeSeries.0002-01-01.nc'),
+         '--res', '1.0', '-o', 'mpas_example'])
+    assert os.path.basename(r3.map_filename) == \
+        'map_oQU240_to_1.0x1.0degree_analyticbilin.nc'
+    a = open_dataset('mpas_example/remapped_1.0x1.0degree_file.nc')
+    b = open_dataset('mpas_example/remapped_1.0x1.0degree_array.nc')
+    ref = open_dataset(os.path.join(gold, 'ref_mpas_cell_to_latlon.nc'))
+    for name in ('timeMonthly_avg_ssh', 'timeMonthly_avg_tThreshMLD'):
+        assert a[name].dims == ('Time', 'lat', 'lon')
+        assert np.array_equal(a[name].values, b[name].values, equal_nan=True)
+        # get_lat_lon_descriptor(1, 1) holds the cells of the reference's
+        # stored output, longitudes from -179.5 instead of 0.5: the example
+        # lands on it
+        got = np.roll(a[name].values, 180, axis=-1)
+        want = ref[name].values
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        ok = ~np.isnan(want)
+        assert np.isclose(got[ok], want[ok], rtol=1e-9).all()
 
 
 # ---------------------------------------------------------------------------
