@@ -115,3 +115,23 @@ def test_knn_map_on_the_real_cell_centres(qu240):
     r = row // 180
     sel = col[r == 40]
     assert int(sel.max() - sel.min()) > 0.6 * m.n_a
+
+
+def test_config1_as_esmf_makes_it_has_pole_caps():
+    """`config1_esmf`: BASELINE config 1 with ESMF's weights -- 2 x 720
+    destination cells beyond the last source row take that whole row (a third
+    of the entries); the other configs keep the seeds they had before it was
+    added."""
+    from pyremap_amd import synthetic
+    m = synthetic.make_config('config1_esmf')
+    assert (m.n_a, m.n_b, m.dst_dims) == (64800, 259200, (360, 720))
+    rows = np.bincount(m.row.numpy() - 1, minlength=m.n_b)
+    assert rows.max() == 360 and (rows > 96).sum() == 1440
+    assert 0.30 < rows[rows > 96].sum() / rows.sum() < 0.36
+    sums = np.bincount(m.row.numpy() - 1, weights=m.S.numpy(),
+                       minlength=m.n_b)
+    assert np.allclose(sums, 1.0, rtol=0, atol=1e-13)
+    names = sorted(k for k in synthetic.CONFIGS
+                   if 'seed' not in synthetic.CONFIGS[k])
+    assert names == ['config1', 'config2', 'config3', 'config4', 'config5',
+                     'headline']
