@@ -28,10 +28,22 @@ reference's QU240 fixture), not along the destination raster;
 `roofline.workloads.config3_raster_numbering` is the same map in the raster
 numbering round 2 measured.
 
-Prints ONE JSON line on rank 0.  `value` = destination cell-fields per second
-for the whole job; `roofline` prices the kernel against HBM bandwidth using
-SURVEY.md section 8(d)'s algorithmic bytes; `cpu_baseline` is the CPU oracle
-(a C port of the reference's scipy path) timed on this box's host cores.
+Prints ONE JSON line on rank 0, kept under 4 KB (the driver keeps an 8 KB tail
+of stdout; tests/test_host_cpu.py pins the length).  `value` = destination
+cell-fields per second for the whole job; `roofline` prices the kernel against
+HBM bandwidth using SURVEY.md section 8(d)'s algorithmic bytes, with one
+`[ms, frac]` pair per other workload in `roofline.workloads`; `cpu_baseline`
+is scipy's `csr @ X` -- the call the reference makes at remap_numpy.py:268,
+BASELINE.md section 4 "Baseline A" -- on one host core of this box, with the C
+oracle (the whole `_remap_numpy_array` semantics) beside it as `port_value`.
+Everything else that is measured (schedules, per-launch lists, titles, the
+PCIe-inclusive rates, every field of every extra workload) goes to the side
+file named in the line's `details` (gpurun_out/bench_extra.json).
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment
+starts the N ranks itself (a child `python -m torch.distributed.run ...
+bench.py`, never an exec: the parent has not touched the GPU), relays rank
+0's line as its own last line and exits with the child's code.
 
 Order of the measurements (all of them are reported): the metric workload is
 PREPARED first (plan, fields, output buffers), then the copy ceiling and the
@@ -86,6 +98,12 @@ def parse_args():
     ap.add_argument('--flags', type=int, default=0)
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-extra', action='store_true')
+    ap.add_argument('--all-workloads', action='store_true',
+                    help='every reported workload (configs 4 / 5 masked / '
+                         'f32 ... : a minute), not only the default rows')
+    ap.add_argument('--details', default=None,
+                    help='side file for everything the line does not carry '
+                         '(default gpurun_out/bench_extra.json)')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--backend', default='nccl',
                     help="torch.distributed backend: 'nccl' (= RCCL, the "
@@ -100,17 +118,48 @@ def parse_args():
     return ap.parse_args()
 
 
+def self_launch(args):
+    """
+    `python bench.py --gpus N` (N > 1) with no launcher around it: start the N
+    ranks as a CHILD process (torch.distributed.run, one rank per GPU) -- this
+    parent has not touched the GPU and never does --, pass every line the
+    child prints through, rank 0's JSON line last, and return its exit code.
+    """
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)]
+    cmd += sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    out, _ = proc.communicate()
+    lines = out.splitlines()
+    last = None
+    for n in range(len(lines) - 1, -1, -1):
+        if lines[n].startswith('{"metric"'):
+            last = lines.pop(n)
+            break
+    for line in lines:
+        print(line)
+    if last is not None:
+        print(last, flush=True)
+    elif proc.returncode == 0:
+        print('bench.py: the ranks printed no JSON line', file=sys.stderr)
+        return 1
+    return proc.returncode
+
+
 def init_dist(args):
     import torch
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(
-                f'--gpus {args.gpus} needs one process per GPU: launch with '
-                f'python -m torch.distributed.run --nproc-per-node '
-                f'{args.gpus} bench.py --gpus {args.gpus}')
         raise SystemExit(f'WORLD_SIZE={world} but --gpus {args.gpus}')
     if rank != 0:
         # only rank 0 reports: nothing another rank (or the libraries it
@@ -258,8 +307,30 @@ class Workload:
     """One prepared workload: plan, resident fields, output buffers."""
 
 
+def make_launch(w, dst, axes, tune):
+    from pyremap_amd import engine
+    w.launch_args = (dst, axes, tune)
+
+    def launch(i):
+        s = i % w.sets
+        w.outs[s] = engine.remap_tensor(
+            w.plan, dst, w.fields[s], axes, w.emode, threshold=0.01,
+            flags=w.flags, tune=tune, out=w.outs[s])
+    return launch
+
+
+def same_with_flags(w, flags):
+    """The prepared workload `w` once more with other REMAP_FLAG_* bits:
+    the same plan, fields and output buffers, nothing rebuilt."""
+    import copy
+    v = copy.copy(w)
+    v.flags = flags
+    v.launch = make_launch(v, *w.launch_args)
+    return v
+
+
 def prepare(name, args, rank, world, dist, K=None, mode=None, layout=None,
-            sets=None, dtype='f64', locality=None, times=8):
+            sets=None, dtype='f64', locality=None, times=8, flags=None):
     """Build plan + fields + output buffers for one workload."""
     import torch
 
@@ -272,6 +343,7 @@ def prepare(name, args, rank, world, dist, K=None, mode=None, layout=None,
     w.mode = mode or args.mode
     w.layout = layout or args.layout
     w.sets = sets or args.sets
+    w.flags = args.flags if flags is None else flags
     w.emode = {'fracb': engine.MODE_FRACB, 'masked': engine.MODE_MASKED,
                'raw': engine.MODE_RAW}[w.mode]
     tune = [int(t) for t in args.tune.split(',')] if args.tune else None
@@ -315,18 +387,12 @@ def prepare(name, args, rank, world, dist, K=None, mode=None, layout=None,
     w.outs = [None] * w.sets
     axes = [0] if w.layout == 'nk' else [1]
 
-    def launch(i):
-        s = i % w.sets
-        w.outs[s] = engine.remap_tensor(
-            w.plan, dst, w.fields[s], axes, w.emode, threshold=0.01,
-            flags=args.flags, tune=tune, out=w.outs[s])
-
-    w.launch = launch
+    w.launch = make_launch(w, dst, axes, tune)
     # every output buffer exists before anything else is allocated (buffers
     # that recycled the copy-ceiling's freed blocks once measured 4 % slower
     # for the whole process: placement in HBM)
     for s in range(w.sets):
-        launch(s)
+        w.launch(s)
     torch.cuda.synchronize()
     return w
 
@@ -353,6 +419,11 @@ def time_exchange(w, dist):
         torch.cuda.synchronize()
         times.append((time.perf_counter() - t0) * 1e3)
     out['broadcast_ms'] = min(times)
+    # what the communicator itself reports (RCCL under 'nccl')
+    out['ranks'] = dist.get_world_size()
+    out['backend'] = dist.get_backend()
+    out['exchange'] = 'one broadcast of X + local gather of the packed ' \
+        'rows, before the timed region'
     for x in w.fields:            # every set's packed rows resident
         dist.broadcast(x, src=0)
     torch.cuda.synchronize()
@@ -500,11 +571,16 @@ def copy_ceiling(device, reps=60):
 
 def cpu_baseline(full, m, field, mode, budget_s):
     """
-    The CPU oracle (C port of the reference's scipy path: sequential
-    csr_matvecs + normalisation) on this box's host, same triplets, same
-    field.  The sample is the WHOLE workload repeated while it fits the time
-    budget; scipy's own `csr @ X` (what the reference executes) is timed
-    beside it when scipy is importable.
+    The reference's CPU path on this box's host cores, same triplets, same
+    field, the WHOLE workload per run.
+
+    `value` (Baseline A): scipy's `csr @ X` on ONE
+    core -- the call the reference makes at remap_numpy.py:264-268; its
+    csr_matvecs kernel is single-threaded -- best of <= 5 runs, `kind`
+    "reference".  Beside it (Baseline B) the C oracle, which also does the
+    normalisation and mask passes of `_remap_numpy_array`: `port_value` on
+    one thread, `port_all_cores` on every core.  Where scipy does not import
+    the oracle's figure is `value` and `kind` says "port".
     """
     import numpy as np
 
@@ -515,42 +591,44 @@ def cpu_baseline(full, m, field, mode, budget_s):
     X = field.cpu().numpy().reshape(full.n_a, -1)
     K = X.shape[1]
     masked = mode == 'masked'
+    units = full.n_b * K
 
-    def timed(nthreads, budget):
+    def best_of(fn, budget, most=5):
         times = []
         t_end = time.perf_counter() + budget
-        while len(times) < 5 and (not times or time.perf_counter() < t_end):
+        while len(times) < most and (not times or
+                                     time.perf_counter() < t_end):
             t0 = time.perf_counter()
-            oracle.remap_flat(csr, frac_b, X, masked, 0.01, nthreads=nthreads)
+            fn()
             times.append(time.perf_counter() - t0)
         return min(times), len(times)
 
-    t1, reps1 = timed(1, budget_s * 0.6)
+    t1, reps1 = best_of(lambda: oracle.remap_flat(
+        csr, frac_b, X, masked, 0.01, nthreads=1), budget_s * 0.4)
     ncores = os.cpu_count() or 1
     nthr = min(ncores, oracle.load().oracle_max_threads())
-    tn, repsn = timed(nthr, budget_s * 0.2)
+    tn, _ = best_of(lambda: oracle.remap_flat(
+        csr, frac_b, X, masked, 0.01, nthreads=nthr), budget_s * 0.2)
+    what = (f'whole workload ({full.n_a} -> {full.n_b} cells, K = {K}, '
+            f'mode {mode})')
     out = dict(
-        value=full.n_b * K / t1, unit='dst cell-fields/s', cores=1,
-        kind='port',
-        sample=f'whole workload ({full.n_a} -> {full.n_b} cells, K = {K}, '
-               f'mode {mode}), best of {reps1} runs of the C oracle on 1 '
-               f'thread',
-        seconds=t1,
-        all_cores=dict(value=full.n_b * K / tn, cores=nthr, seconds=tn,
-                       runs=repsn),
-        host_cpus=ncores,
-    )
+        value=units / t1, unit='dst cell-fields/s', cores=1, kind='port',
+        sample=f'{what}: C oracle of _remap_numpy_array, 1 thread, best of '
+               f'{reps1}',
+        seconds=t1, port_value=units / t1, port_seconds=t1,
+        port_all_cores=dict(value=units / tn, cores=nthr, seconds=tn),
+        host_cpus=ncores)
     try:
         import scipy.sparse as sp
         A = sp.csr_matrix((val, col, rowptr), shape=(full.n_b, full.n_a))
         Xs = np.nan_to_num(X) if masked else X
-        t0 = time.perf_counter()
-        A.dot(Xs)
-        ts = time.perf_counter() - t0
-        out['scipy_spmm_only'] = dict(
-            value=full.n_b * K / ts, seconds=ts, cores=1,
-            note='bare scipy csr @ X (remap_numpy.py:268), no '
-                 'normalisation/mask passes')
+        ts, reps = best_of(lambda: A.dot(Xs), budget_s * 0.4)
+        out.update(
+            value=units / ts, seconds=ts, kind='reference',
+            scipy_value=units / ts,
+            sample=f'{what}: scipy csr @ X (remap_numpy.py:268, Baseline A)'
+                   f', 1 core, best of {reps}; port_value = the C oracle of '
+                   f'the whole _remap_numpy_array, 1 thread')
     except ImportError:
         pass
     try:
@@ -646,50 +724,63 @@ EXTRA_KEYS = ('title', 'n_a', 'n_b', 'nnz_csr', 'K', 'mode', 'layout',
 BIG = ('headline', 'config4', 'config5')
 
 
+#: the rows of `roofline.workloads` the DEFAULT run carries (the driver's
+#: command has to stay short): north_star's target workload, BASELINE config
+#: 5 in the bitwise and in the FMA mode, and the weak spots VERDICT.md names
+DEFAULT_ROWS = ('headline', 'config5', 'config5_fma', 'config5_masked',
+                'config4', 'Time120_nCells', 'layout_T8_nCells_L60',
+                'layout_T48_nCells_L10', 'config1_esmf_pole_caps_K1',
+                'config1_esmf_pole_caps_K64', 'masked')
+
+
 def extras_todo(args, world):
     """
     The other reported workloads: (tag, prepare() keywords, steps).  Their
-    summary rows land in `roofline.workloads` (the driver's record keeps
-    `roofline`; it truncates `extra`).
+    `[ms, frac]` pairs land in `roofline.workloads`, everything else about
+    them in the side file.  DEFAULT_ROWS unless --all-workloads.
     """
     if args.no_extra or args.workload != 'config3':
         return []
-    if world == 1:
-        return [
-            # north_star's target workload; BASELINE configs 5 and 4
-            ('headline', dict(name='headline', sets=2), 12),
-            ('config5', dict(name='config5', sets=1), 4),
-            ('config5_masked', dict(name='config5', sets=1, mode='masked'),
-             4),
-            ('config4', dict(name='config4', sets=1), 6),
-            ('config4_f32_fields', dict(name='config4', sets=1, dtype='f32'),
-             6),
-            # the metric mapping in the raster numbering round 2 measured
-            ('config3_raster_numbering',
-             dict(name='config3', locality='raster'), 50),
-            ('K1_one_2d_field', dict(name='config3', K=1), 50),
-            ('K12_monthly_time_nCells', dict(name='config3', K=12,
-                                             layout='tn'), 50),
-            ('Time120_nCells', dict(name='config3', K=120, layout='tn'), 30),
-            # lat-lon model output on BASELINE config 1's bilinear map:
-            # (time = 120, lat x lon) float32, the reference's real input
-            ('config1_time120_latlon_f32',
-             dict(name='config1', K=120, layout='tn', dtype='f32'), 30),
-            # the same map as ESMF makes it: pole-cap rows of 360 entries,
-            # a third of all entries -- applied apart (long rows)
-            ('config1_esmf_pole_caps_K1', dict(name='config1_esmf', K=1), 50),
-            ('config1_esmf_pole_caps_K64', dict(name='config1_esmf', K=64),
-             50),
-            ('f32_fields', dict(name='config3', dtype='f32'), 50),
-            ('layout_T8_nCells_L64', dict(name='config3', layout='tnl'), 50),
-            ('layout_T8_nCells_L60', dict(name='config3', layout='tnl',
-                                          K=480), 50),
-            # short level runs (10 soil / ice layers): small LDS patches
-            ('layout_T48_nCells_L10', dict(name='config3', layout='tnl',
-                                           K=480, times=48), 30),
-            ('masked', dict(name='config3', mode='masked'), 50),
-        ]
-    return [('masked', dict(name='config3', mode='masked'), 50)]
+    if world > 1:
+        return [('masked', dict(name='config3', mode='masked'), 50)]
+    rows = [
+        # north_star's target workload; BASELINE configs 5 and 4
+        ('headline', dict(name='headline', sets=2), 12),
+        ('config5', dict(name='config5', sets=1), 4),
+        # the opt-in fused multiply-add mode (rtol 1e-13, not bitwise:
+        # tests/test_gpu_parity.py::test_fma_flag_is_close_not_identical)
+        ('config5_fma', dict(name='config5', sets=1, flags=1, share='config5'),
+         4),
+        ('config5_masked', dict(name='config5', sets=1, mode='masked'), 4),
+        ('config4', dict(name='config4', sets=1), 6),
+        ('config4_f32_fields', dict(name='config4', sets=1, dtype='f32'), 6),
+        # the metric mapping in the raster numbering round 2 measured
+        ('config3_raster_numbering',
+         dict(name='config3', locality='raster'), 50),
+        ('K1_one_2d_field', dict(name='config3', K=1), 50),
+        ('K12_monthly_time_nCells', dict(name='config3', K=12,
+                                         layout='tn'), 50),
+        ('Time120_nCells', dict(name='config3', K=120, layout='tn'), 30),
+        # lat-lon model output on BASELINE config 1's bilinear map:
+        # (time = 120, lat x lon) float32, the reference's real input
+        ('config1_time120_latlon_f32',
+         dict(name='config1', K=120, layout='tn', dtype='f32'), 30),
+        # the same map as ESMF makes it: pole-cap rows of 360 entries,
+        # a third of all entries -- applied apart (long rows)
+        ('config1_esmf_pole_caps_K1', dict(name='config1_esmf', K=1), 50),
+        ('config1_esmf_pole_caps_K64', dict(name='config1_esmf', K=64), 50),
+        ('f32_fields', dict(name='config3', dtype='f32'), 50),
+        ('layout_T8_nCells_L64', dict(name='config3', layout='tnl'), 50),
+        ('layout_T8_nCells_L60', dict(name='config3', layout='tnl',
+                                      K=480), 50),
+        # short level runs (10 soil / ice layers): small LDS patches
+        ('layout_T48_nCells_L10', dict(name='config3', layout='tnl',
+                                       K=480, times=48), 30),
+        ('masked', dict(name='config3', mode='masked'), 50),
+    ]
+    if not args.all_workloads:
+        rows = [r for r in rows if r[0] in DEFAULT_ROWS]
+    return rows
 
 
 def prepare_extras(args, rank, world, dist, extra, big):
@@ -699,6 +790,7 @@ def prepare_extras(args, rank, world, dist, extra, big):
         if (kw['name'] in BIG) != big:
             continue
         kw = dict(kw)
+        kw.pop('share', None)
         try:
             ready.append((tag, prepare(kw.pop('name'), args, rank, world,
                                        dist, **kw), steps))
@@ -708,22 +800,39 @@ def prepare_extras(args, rank, world, dist, extra, big):
 
 
 def measure_big_extras(args, rank, world, dist, extra):
-    """The tens-of-GB workloads: prepare, measure, free -- one at a time."""
+    """The tens-of-GB workloads: prepare, measure, free -- one at a time (a
+    row with `share` reuses the workload prepared just before it)."""
     import torch
-    for tag, kw, steps in extras_todo(args, world):
-        if kw['name'] not in BIG:
-            continue
+    todo = [t for t in extras_todo(args, world) if t[1]['name'] in BIG]
+    w, w_tag = None, None
+    for n, (tag, kw, steps) in enumerate(todo):
         kw = dict(kw)
+        t0 = time.perf_counter()
         try:
-            w = prepare(kw.pop('name'), args, rank, world, dist, **kw)
-            measure_extras([(tag, w, steps)], args, dist, extra,
+            share = kw.pop('share', None)
+            if share is not None and share == w_tag:
+                v = same_with_flags(w, kw['flags'])
+            else:
+                if w is not None:
+                    w.launch = w.fields = w.outs = None
+                w = None          # (freed before the next one is built)
+                gc.collect()
+                torch.cuda.empty_cache()
+                v = w = prepare(kw.pop('name'), args, rank, world, dist, **kw)
+                w_tag = tag
+            measure_extras([(tag, v, steps)], args, dist, extra,
                            long_last=False)
-            w.launch = w.fields = w.outs = None   # (launch closes over w)
-            del w
+            v.launch = None                   # (launch closes over v)
+            del v
         except Exception as exc:  # noqa: BLE001
             extra[tag] = {'error': f'{type(exc).__name__}: {exc}'}
-        gc.collect()
-        torch.cuda.empty_cache()
+        if isinstance(extra.get(tag), dict):
+            extra[tag]['prepare_and_measure_s'] = time.perf_counter() - t0
+    if w is not None:
+        w.launch = w.fields = w.outs = None
+    del w
+    gc.collect()
+    torch.cuda.empty_cache()
 
 
 def measure_extras(ready, args, dist, extra, long_last=True):
@@ -778,42 +887,59 @@ def replay_short_extras(ready, extra):
             e['kernel_ms_graph_replay'] = graph_replay_ms(w.launch)
 
 
+def kernel_of(e):
+    """The kernel a workload's launches ran (for the side file)."""
+    sched = e.get('schedule') or {}
+    family = KERNEL_OF_FAMILY.get(sched.get('family'), 'spmm_*')
+    if sched.get('long_rows'):
+        return family + ' + spmm_patchcell (long rows apart)'
+    if e['layout'] == 'tn':
+        return 'spmm_patchcell'
+    if e['layout'] == 'tnl' and 4 <= e['K'] // e.get('times', 8) < 16:
+        return 'spmm_patch'
+    if e['K'] <= 32:
+        return 'spmm_rowlane'
+    return family
+
+
 def workload_rows(extra):
-    """`roofline.workloads`: one short row per extra workload."""
+    """
+    `roofline.workloads`: `tag: [ms per launch, fraction of 8 TB/s]` per other
+    workload (launches shorter than the host's ~12 us per call: as replayed
+    from a hipGraph when that was measured).  Everything else about a
+    workload is in the side file.
+    """
     rows = {}
     for tag, e in extra.items():
-        if not isinstance(e, dict) or 'kernel_ms_mean' not in e:
-            if isinstance(e, dict) and 'error' in e:
-                rows[tag] = {'error': e['error'][:120]}
+        if not isinstance(e, dict):
             continue
-        sched = e.get('schedule') or {}
-        rows[tag] = {
-            'ms': round(e['kernel_ms_mean'], 5),
-            'frac': round(e['frac_of_peak'], 4),
-            # launched one by one from Python / replayed from one hipGraph
-            # (short launches only: the host call takes ~12 us)
-            'ms_graph_replay': (round(e['kernel_ms_graph_replay'], 5)
-                                if e.get('kernel_ms_graph_replay') else None),
-            'frac_graph_replay': (round(
-                e['bytes_alg'] / (e['kernel_ms_graph_replay'] * 1e-3) / 1e9 /
-                HBM_PEAK_GBPS, 4) if e.get('kernel_ms_graph_replay')
-                else None),
-            'read_frac': round(e['read_frac_of_peak'], 4),
-            'traffic_ratio': (round(e['traffic'] / e['bytes_alg'], 4)
-                              if e.get('traffic') else None),
-            'GBps': round(e['achieved_GBps'], 1),
-            'bytes_alg': e['bytes_alg'],
-            'K': e['K'], 'mode': e['mode'], 'layout': e['layout'],
-            'dtype': e.get('dtype', 'f64'), 'numbering': e['locality'],
-            'kernel': KERNEL_OF_FAMILY.get(sched.get('family'), 'spmm_*') +
-            ' + spmm_patchcell (long rows apart)' if sched.get('long_rows')
-            else 'spmm_patchcell' if e['layout'] == 'tn' else
-            'spmm_patch' if e['layout'] == 'tnl' and
-            4 <= e['K'] // e.get('times', 8) < 16 else
-            'spmm_rowlane' if e['K'] <= 32 else
-            KERNEL_OF_FAMILY.get(sched.get('family'), 'spmm_*'),
-        }
+        if 'kernel_ms_mean' not in e:
+            if 'error' in e:
+                rows[tag] = 'error: ' + e['error'][:60]
+            continue
+        ms = e.get('kernel_ms_graph_replay') or e['kernel_ms_mean']
+        rows[tag] = [round(ms, 5), round(
+            e['bytes_alg'] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)]
     return rows
+
+
+def details_of(extra):
+    """The side file's per-workload records: every measured field plus the
+    derived ones the line used to carry."""
+    out = {}
+    for tag, e in extra.items():
+        if not isinstance(e, dict) or 'kernel_ms_mean' not in e:
+            out[tag] = e
+            continue
+        d = dict(e)
+        d['kernel'] = kernel_of(e)
+        if e.get('kernel_ms_graph_replay'):
+            d['frac_graph_replay'] = e['bytes_alg'] / (
+                e['kernel_ms_graph_replay'] * 1e-3) / 1e9 / HBM_PEAK_GBPS
+        if e.get('traffic'):
+            d['traffic_ratio'] = e['traffic'] / e['bytes_alg']
+        out[tag] = d
+    return out
 
 
 def print_line(line):
@@ -834,9 +960,25 @@ def print_line(line):
 OPTIONAL_TIMEOUT_S = int(os.environ.get('BENCH_OPTIONAL_TIMEOUT_S', 150))
 
 
+#: the line's size limit (the driver keeps the last 8 KB of stdout)
+LINE_LIMIT = 4096
+
+
+def rnd(x, digits=6):
+    """Numbers in the line: `digits` significant digits are plenty."""
+    if isinstance(x, float):
+        return float(f'{x:.{digits}g}')
+    return x
+
+
 def compose_line(args, res, world, ceiling, cpu, extra, pipelined,
-                 status='ok'):
-    """The one JSON line, from what has been measured."""
+                 status='ok', details_path=None):
+    """
+    (line, details): the one JSON line -- metric, value, config, roofline
+    (with `workloads: {tag: [ms, frac]}`), cpu_baseline, multi_gpu, status:
+    under LINE_LIMIT bytes whatever was measured -- and the side file's
+    content (everything else).
+    """
     K = res['K']
     traffic, traffic_src = load_traffic(args.workload, K, res['mode'],
                                         args.locality)
@@ -844,19 +986,29 @@ def compose_line(args, res, world, ceiling, cpu, extra, pipelined,
     achieved = res['bytes_alg'] / (kernel_ms * 1e-3) / 1e9
     multi = None
     if res['exchange'] is not None:
-        multi = dict(res['exchange'])
-        multi.update(pipelined or {})
-        multi['kernel_phase_ms'] = kernel_ms
+        full_multi = dict(res['exchange'])
+        full_multi.update(pipelined or {})
+        full_multi['kernel_phase_ms'] = kernel_ms
+        keep = ('ranks', 'backend', 'exchange', 'broadcast_ms', 'packed_ms',
+                'kernel_phase_ms', 'packed_fraction_of_broadcast',
+                'local_gather_ms', 'pipelined_alltoall_ms_per_K_fields',
+                'pipelined_broadcast_ms_per_K_fields',
+                'optional_measurements', 'packed_error')
+        multi = {k: (rnd(v) if not isinstance(v, str) else v[:100])
+                 for k, v in full_multi.items() if k in keep}
+    else:
+        full_multi = None
+    family = KERNEL_OF_FAMILY.get(res['schedule'].get('family'), 'spmm_*')
     line = {
         'metric': 'dst cell-fields/s (dst cells x batched fields per second)'
                   ' + HBM GB/s, EC30to60 MPAS -> 0.5deg lat-lon, 512 batched '
                   'fp64 fields',
-        'value': res['cell_fields_per_s'],
+        'value': rnd(res['cell_fields_per_s'], 9),
         'unit': 'dst cell-fields/s',
         'n_gpus': world,
         'steps': res['steps'],
         'warmup': res['warmup'],
-        'ms_per_step': res['ms_per_step'],
+        'ms_per_step': rnd(res['ms_per_step'], 9),
         'higher_is_better': True,
         'scaling': 'strong',   # the problem is fixed; rows (or fields) are
         #                        divided over the ranks
@@ -864,80 +1016,123 @@ def compose_line(args, res, world, ceiling, cpu, extra, pipelined,
         'dtype': 'f64',
         'data': 'synthetic',
         'config': {
-            'workload': f"{args.workload}: {res['title']}",
+            'workload': f"{args.workload}: {res['title']}"[:100],
             'n_a': res['n_a'], 'n_b': res['n_b'], 'n_s': res['n_s_file'],
             'nnz_csr': res['nnz_csr'], 'fields_K': K,
             'mode': res['mode'], 'layout': res['layout'],
             'locality': args.locality,
-            'touched_frac': res['touched_frac'],
             'sharding': 'none' if world == 1 else
-            (f'dst rows over {world} GPUs in packed column space, X '
+            (f'dst rows over {world} GPUs, packed column space, X '
              f'distributed once (RCCL) before the timed region'
              if args.shard == 'rows' else
              f'fields over {world} GPUs, no collective'),
             'buffer_sets_rotated': args.sets,
             'bitwise_mode': not (args.flags & 1),
-            'schedule': res['schedule'],
-            'measurement_order': 'metric first' if args.metric_first else
-            'everything prepared first; then copy ceiling, extras, metric '
-            'workload timed back to back',
         },
-        'dst_cells_per_s_per_512_batch': res['dst_cells_per_s_per_batch'],
+        'dst_cells_per_s_per_512_batch': rnd(
+            res['dst_cells_per_s_per_batch']),
         'roofline': {
             'bound': 'hbm',
-            'achieved': achieved,
+            'achieved': rnd(achieved),
             'peak': HBM_PEAK_GBPS,
             'unit': 'GB/s',
-            'frac': achieved / HBM_PEAK_GBPS,
+            'frac': rnd(achieved / HBM_PEAK_GBPS),
             'traffic': traffic,
-            'traffic_source': traffic_src,
-            'traffic_note': 'FETCH_SIZE x 2 x 1024 + WRITE_SIZE x 1024 per '
-            'launch (MI355X_MICROARCH.md): the L2\'s fabric-side bytes, '
-            'Infinity Cache hits included -- an upper bound on HBM bytes',
-            'kernel': KERNEL_OF_FAMILY.get(
-                res['schedule'].get('family'), 'spmm_*') +
-            ' (remap_apply_f64)',
-            'kernel_ms_mean': kernel_ms,
-            'kernel_ms_median': res['kernel_ms_median'],
-            'kernel_ms_min': res['kernel_ms_min'],
-            'kernel_ms_max': res['kernel_ms_max'],
-            'kernel_ms_second_pass_in_order':
-            res['kernel_ms_second_pass_in_order'],
-            'kernel_ms_steady_100_more': res['kernel_ms_steady_100_more'],
+            'traffic_source': traffic_src and traffic_src[:80],
+            'kernel': family + ' (remap_apply_f64)',
+            'kernel_ms_mean': rnd(kernel_ms),
+            'kernel_ms_median': rnd(res['kernel_ms_median']),
+            'kernel_ms_steady_100_more': rnd(
+                res.get('kernel_ms_steady_100_more')),
             'bytes_alg_per_launch': res['bytes_alg'],
-            'bytes_alg_read_per_launch': res['bytes_alg_read'],
-            'read_frac_of_peak': res['bytes_alg_read'] /
-            (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-            'measured_copy_ceiling_GBps': ceiling,
-            'numbering': args.locality,
+            'read_frac_of_peak': rnd(res['bytes_alg_read'] / (
+                kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS),
+            'measured_copy_ceiling_GBps': rnd(ceiling),
             'workloads': workload_rows(extra),
         },
-        'status': status,
-        'cpu_baseline': cpu,
-        'plan_build_s': res['plan_build_s'],
+        'cpu_baseline': None if cpu is None else {
+            k: (rnd(v) if not isinstance(v, str) else v[:240])
+            for k, v in cpu.items()
+            if k in ('value', 'unit', 'cores', 'kind', 'sample', 'seconds',
+                     'scipy_value', 'port_value', 'host_cpus', 'host_model')},
         'multi_gpu': multi,
-        'extra': extra,
+        'status': status,
+        'details': details_path,
     }
-    return line
+    details = {
+        'line': None,       # (filled in by write_details)
+        'result': res,
+        'schedule': res['schedule'],
+        'touched_frac': res['touched_frac'],
+        'plan_build_s': res['plan_build_s'],
+        'traffic_note': 'FETCH_SIZE x 2 x 1024 + WRITE_SIZE x 1024 per '
+        'launch (MI355X_MICROARCH.md): the L2\'s fabric-side bytes, '
+        'Infinity Cache hits included -- an upper bound on HBM bytes',
+        'traffic_source': traffic_src,
+        'measurement_order': 'metric first' if args.metric_first else
+        'everything prepared first; then copy ceiling, extras, metric '
+        'workload timed back to back',
+        'cpu_baseline': cpu,
+        'multi_gpu': full_multi,
+        'workloads': details_of(extra),
+    }
+    # whatever was measured, the line stays parseable by the driver: rows
+    # are dropped (they stay in the side file) before the limit is crossed
+    rows = line['roofline']['workloads']
+    while len(json.dumps(line)) > LINE_LIMIT and rows:
+        rows.pop(next(reversed(rows)))
+        line['roofline']['workloads_truncated'] = True
+    return line, details
+
+
+def write_details(path, line, details):
+    """The side file; a box where it cannot be written still gets its line."""
+    if path is None:
+        return
+    details['line'] = line
+    try:
+        os.makedirs(os.path.dirname(path) or '.', exist_ok=True)
+        with open(path, 'w') as f:
+            json.dump(details, f, indent=1, default=str)
+    except OSError as exc:
+        print(f'bench.py: side file {path}: {exc}', file=sys.stderr)
 
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args))
     import torch
+    t_start = time.perf_counter()
     rank, world, local, dist = init_dist(args)
     device = torch.device('cuda', local)
     from pyremap_amd import engine
     engine.require_gpu()
+    details_path = args.details or os.path.join(_REPO, 'gpurun_out',
+                                                'bench_extra.json')
+    shown_path = os.path.relpath(details_path, _REPO) \
+        if details_path.startswith(_REPO) else details_path
+    phases = {}
+
+    def mark(name, since):
+        torch.cuda.synchronize()
+        phases[name] = round(time.perf_counter() - since, 3)
+        return time.perf_counter()
 
     extra = {}
     # The metric workload and the small extras are PREPARED first (host
     # work, GPU mostly idle); the tens-of-GB workloads come and go one at a
     # time in between; then all remaining measurements run back to back, the
     # metric workload last.
+    t = mark('init_s', t_start)
     main_w = prepare(args.workload, args, rank, world, dist)
+    t = mark('prepare_metric_workload_s', t)
     ready = prepare_extras(args, rank, world, dist, extra, big=False)
+    t = mark('prepare_small_extras_s', t)
     measure_big_extras(args, rank, world, dist, extra)
+    t = mark('big_extras_s', t)
     ceiling = copy_ceiling(device)
+    t = mark('copy_ceiling_s', t)
     pipelined = None
     res = None
     if args.metric_first:
@@ -956,12 +1151,13 @@ def main():
     res['kernel_ms_steady_100_more'] = a.elapsed_time(b) / 100
     if dist is None:
         replay_short_extras(ready, extra)
+    t = mark('small_extras_and_metric_s', t)
     # per-rank kernel numbers -> the slowest rank prices the roofline
     if dist is not None:
-        t = torch.tensor([res['kernel_ms_mean']], device=device,
-                         dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        res['kernel_ms_mean_max_rank'] = float(t.item())
+        tk = torch.tensor([res['kernel_ms_mean']], device=device,
+                          dtype=torch.float64)
+        dist.all_reduce(tk, op=dist.ReduceOp.MAX)
+        res['kernel_ms_mean_max_rank'] = float(tk.item())
     watchdog = None
     if main_w.sharded:
         # The metric is in hand.  What follows moves packed rows with
@@ -978,9 +1174,11 @@ def main():
                     f'timed out after {OPTIONAL_TIMEOUT_S} s: packed / '
                     f'pipelined exchange did not return')
                 res['exchange'] = late
-                print_line(compose_line(args, res, world, ceiling, None,
-                                        extra, None,
-                                        status='exchange_hung'))
+                line, details = compose_line(
+                    args, res, world, ceiling, None, extra, None,
+                    status='exchange_hung', details_path=shown_path)
+                write_details(details_path, line, details)
+                print_line(line)
             os._exit(3)
         watchdog = threading.Timer(OPTIONAL_TIMEOUT_S, bail)
         watchdog.daemon = True
@@ -993,13 +1191,16 @@ def main():
         pipelined = time_pipelined(main_w, args, dist)
         barrier(dist)
         watchdog.cancel()
+        t = mark('exchange_measurements_s', t)
     del ready
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
         cpu = cpu_baseline(main_w.full, main_w.m, main_w.fields[0],
                            res['mode'], args.cpu_seconds)
-    if world == 1 and not args.no_extra and args.workload == 'config3':
+        t = mark('cpu_baseline_s', t)
+    if world == 1 and args.all_workloads and not args.no_extra and \
+            args.workload == 'config3':
         main_w.fields = main_w.outs = None
         torch.cuda.empty_cache()
         try:
@@ -1007,6 +1208,7 @@ def main():
         except Exception as exc:  # noqa: BLE001
             extra['host_buffers_pcie_inclusive'] = {
                 'error': f'{type(exc).__name__}: {exc}'}
+        t = mark('pcie_inclusive_s', t)
 
     if rank != 0:
         if dist is not None:
@@ -1014,7 +1216,11 @@ def main():
             dist.destroy_process_group()
         return
 
-    line = compose_line(args, res, world, ceiling, cpu, extra, pipelined)
+    phases['total_s'] = round(time.perf_counter() - t_start, 3)
+    line, details = compose_line(args, res, world, ceiling, cpu, extra,
+                                 pipelined, details_path=shown_path)
+    details['phases_s'] = phases
+    write_details(details_path, line, details)
     # the JSON line is the LAST thing on stdout: every rank is done first
     # (RCCL prints a version banner on stdout when its communicator comes up
     # or goes down, whichever happens to be later)

@@ -554,7 +554,11 @@ int check_args(const remap_apply_args *a, Call &c)
     c.cell_ok = a->patch_ptr && a->patch_ucol && a->patch_lidx &&
                 a->patch_rowptr && a->patch_val && a->patch_rows > 0 &&
                 a->n_patches > 0 && a->patch_umax >= 0 &&
-                (int64_t)a->patch_umax * 4 * 8 <= (int64_t)kPatchLdsMax &&
+                // the LDS image run_patchcell asks for at its smallest TT:
+                // its pitch is the padded list length, not umax
+                (int64_t)((a->patch_umax + 2) & ~1) *
+                        (a->patch_ell_base ? 1 : 4) * 8 <=
+                    (int64_t)kPatchLdsMax &&
                 c.n_rows <= a->n_patches * (int64_t)a->patch_rows &&
                 c.n_rows > (a->n_patches - 1) * (int64_t)a->patch_rows;
     c.group_ok = a->group_meta && a->group_col && a->group_w &&

@@ -328,11 +328,13 @@ class ShardedRemap:
             how = self.exchange
         if how not in self._logged:
             self._logged.add(how)
+            # (this rank's share only: `packed_fraction()` would pack every
+            # other rank's shard here, which the broadcast form never needs)
             log.info(
                 'ShardedRemap rank %d/%d: source field delivered by %s '
-                '(packed rows = %.1f %% of a broadcast)', self.rank,
-                self.world_size, how, 100.0 * self.packed_fraction()
-                if self.world_size > 1 else 100.0)
+                '(this rank reads %.1f %% of the source rows)', self.rank,
+                self.world_size, how, 100.0 * int(self.ucols.shape[0]) /
+                max(self._full.n_a, 1))
         if field is not None:
             shape, dtype = tuple(field.shape), field.dtype
         axis = int(axis) % len(shape)
@@ -409,14 +411,19 @@ class ShardedRemap:
 
     # -- `_remap_numpy_array` as a collective ----------------------------------
     def remap_tensor(self, dst_grid_dims, field, remap_axes, threshold=None,
-                     src=0, flags=0, shape=None, dtype=None):
+                     src=0, flags=0, shape=None, dtype=None, mode='auto',
+                     want_mask=False):
         """
         The whole array-level remap as a COLLECTIVE call: every rank calls
         it with the same arguments, ``src`` passes the device tensor (the
         others ``None`` plus ``shape`` / ``dtype``, or any tensor of that
         shape), every rank returns the full float64 result (NaN where the
-        reference masks).  ``threshold``: ``None`` = the unmasked branch,
-        else masked iff the field holds a NaN (``remap_numpy.py:201-204``).
+        reference masks).  ``mode='auto'``: ``threshold`` ``None`` = the
+        unmasked branch, else masked iff the field holds a NaN
+        (``remap_numpy.py:201-204``); ``'masked'`` / ``'fracb'`` / ``'raw'``:
+        that branch.  With ``want_mask`` returns ``(y, mask)``, ``mask`` the
+        reference's output mask (``:278``: ``den <= threshold`` in masked
+        mode, ``frac_b <= 0`` otherwise) as uint8, gathered like ``y``.
         """
         from pyremap_amd import engine
         torch = _torch()
@@ -429,27 +436,38 @@ class ShardedRemap:
         # arithmetic on a meta tensor)
         x3, lead_shape, tail_shape, unpermute = _flatten_source_axes(
             like, remap_axes)
-        masked = False
-        if threshold is not None:
-            flag = torch.zeros(1, dtype=torch.int32, device=self.plan.device)
-            if self.rank == src:
-                flag[0] = int(bool(torch.isnan(field).any()))
-            if self.world_size > 1:
-                dist.broadcast(flag, src=src, group=self.group)
-            masked = bool(int(flag[0]))
+        if mode == 'auto':
+            masked = False
+            if threshold is not None:
+                flag = torch.zeros(1, dtype=torch.int32,
+                                   device=self.plan.device)
+                if self.rank == src:
+                    flag[0] = int(bool(torch.isnan(field).any()))
+                if self.world_size > 1:
+                    dist.broadcast(flag, src=src, group=self.group)
+                masked = bool(int(flag[0]))
+            emode = engine.MODE_MASKED if masked else engine.MODE_FRACB
+        else:
+            emode = {'masked': engine.MODE_MASKED, 'fracb': engine.MODE_FRACB,
+                     'raw': engine.MODE_RAW}[mode]
         packed = self.distribute(
             x3 if self.rank == src else None, src=src, axis=1,
             shape=tuple(x3.shape), dtype=dtype)
-        y = engine.remap_tensor(
-            self.plan, None, packed, [1],
-            engine.MODE_MASKED if masked else engine.MODE_FRACB,
-            threshold=float(threshold) if masked else 0.0, flags=flags)
-        y = self.gather(y, row_axis=1)
+        res = engine.remap_tensor(
+            self.plan, None, packed, [1], emode,
+            threshold=float(threshold) if emode == engine.MODE_MASKED
+            else 0.0, flags=flags, want_mask=want_mask)
         dst_shape = [int(d) for d in dst_grid_dims] \
             if dst_grid_dims is not None else [self._full.n_b]
-        if unpermute is not None:
-            return unpermute(y, dst_shape)
-        return y.reshape(lead_shape + dst_shape + tail_shape)
+
+        def whole(part):
+            part = self.gather(part, row_axis=1)
+            if unpermute is not None:
+                return unpermute(part, dst_shape)
+            return part.reshape(lead_shape + dst_shape + tail_shape)
+        if want_mask:
+            return whole(res[0]), whole(res[1])
+        return whole(res)
 
 
 class _Deferred:

@@ -376,29 +376,70 @@ class _LookAhead:
         return self.started.pop(name)()
 
 
-def _collective_array(remapper, values, remap_axes, threshold):
+def _collective_array(remapper, values, remap_axes, threshold, mode='auto',
+                      host_mask=None):
     """
     One array through the process group (``Remapper.use_process_group``):
     rank ``src`` uploads its array, every rank computes its rows from the
     packed source rows it receives, every rank returns the full float64
-    result (NaN where the reference masks).
+    result.
+
+    ``mode='auto'`` (what ``_remap_data_array`` wants: NaN where the
+    reference masks, masked iff a threshold and a NaN) returns the array;
+    ``'masked'`` / ``'fracb'`` (``_remap_numpy_array``) return ``(values,
+    mask)`` with the reference's mask of ``remap_numpy.py:278``.
+    ``host_mask``: the MaskedArray's mask in masked mode -- burnt in as NaN
+    on ``src``, except that an UNMASKED NaN goes through as the reference
+    lets it (``:263``: NaN * 1 poisons every cell it touches, which stays
+    unmasked), exactly as ``host_path._enqueue`` does on one device.
     """
     torch = engine.require_gpu()
+    import torch.distributed as dist
     sharded = remapper._matrix
     src = remapper._process_group[1]
     values = np.asarray(values)
     if values.dtype not in (np.float64, np.float32):
         values = values.astype(np.float64)
-    field = None
+    tdtype = torch.float32 if values.dtype == np.float32 else torch.float64
+    device = sharded.plan.device
+    field = poisoned = None
+    flag = torch.zeros(1, dtype=torch.int32, device=device)
     if sharded.rank == src:
-        field = torch.from_numpy(np.ascontiguousarray(values)).to(
-            sharded.plan.device)
-    y = sharded.remap_tensor(
-        remapper._ds_map.dst_grid_dims, field, remap_axes,
-        threshold=threshold, src=src, flags=remapper.engine_flags,
-        shape=tuple(values.shape),
-        dtype=torch.float32 if values.dtype == np.float32 else torch.float64)
-    return y.cpu().numpy()
+        field = torch.from_numpy(np.ascontiguousarray(values)).to(device)
+        if host_mask is not None:
+            m_d = torch.from_numpy(np.ascontiguousarray(
+                host_mask, dtype=np.bool_)).to(device)
+            poisoned = torch.isnan(field) & ~m_d
+            field.masked_fill_(m_d, float('nan'))
+            if bool(poisoned.any()):
+                field.masked_fill_(poisoned, 0.0)
+                flag[0] = 1
+            else:
+                poisoned = None
+    kw = dict(src=src, flags=remapper.engine_flags,
+              shape=tuple(values.shape))
+    dims = remapper._ds_map.dst_grid_dims
+    if mode == 'auto':
+        y = sharded.remap_tensor(dims, field, remap_axes,
+                                 threshold=threshold, dtype=tdtype, **kw)
+        return y.cpu().numpy()
+    y, mask = sharded.remap_tensor(
+        dims, field, remap_axes, threshold=threshold, dtype=tdtype,
+        mode=mode, want_mask=True, **kw)
+    if host_mask is not None:
+        if sharded.world_size > 1:
+            dist.broadcast(flag, src=src, group=sharded.group)
+        if int(flag[0]):
+            # 0 * NaN = NaN through a RAW product marks every destination
+            # cell a poisoned entry touches
+            p_field = None
+            if sharded.rank == src:
+                p_field = torch.where(poisoned, float('nan'), 0.0).to(
+                    torch.float64)
+            hit = sharded.remap_tensor(dims, p_field, remap_axes,
+                                       dtype=torch.float64, mode='raw', **kw)
+            y = torch.where(torch.isnan(hit), float('nan'), y)
+    return y.cpu().numpy(), mask.cpu().numpy().astype(bool)
 
 
 def _remap_numpy_array(remapper, in_field, remap_axes,
@@ -435,15 +476,15 @@ def _remap_numpy_array(remapper, in_field, remap_axes,
                 flags=remapper.engine_flags, shape=tuple(in_field.shape),
                 dtype=in_field.dtype if in_field.dtype in (
                     torch.float32, torch.float64) else torch.float64)
+        # the same branch, stand-ins and output mask as on one device (below)
+        masked = is_ma and renormalization_threshold is not None
         data = np.ma.getdata(in_field) if is_ma else np.asarray(in_field)
-        thr = renormalization_threshold if is_ma else None
-        if is_ma and thr is not None:
-            # the mask travels as NaNs (what _remap_data_array builds,
-            # :201-204); an explicit mask that hides finite values is burnt
-            # in the same way
-            data = np.where(np.ma.getmaskarray(in_field), np.nan, data)
-        out = _collective_array(remapper, data, remap_axes, thr)
-        return np.ma.masked_array(out, mask=np.isnan(out))
+        host_mask = np.ma.getmaskarray(in_field) if masked else None
+        out, mask = _collective_array(
+            remapper, data, remap_axes,
+            renormalization_threshold if masked else None,
+            mode='masked' if masked else 'fracb', host_mask=host_mask)
+        return np.ma.masked_array(out, mask=mask)
 
     if isinstance(in_field, torch.Tensor):
         field = in_field.to(plan.device)

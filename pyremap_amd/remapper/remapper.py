@@ -72,7 +72,12 @@ class Remapper:
         self.device = device
         #: several GPUs driven from this one process: the destination rows
         #: are sharded over them (pyremap_amd.parallel.MultiDeviceRemap);
-        #: fields are handed over and results returned on devices[0]
+        #: fields are handed over and results returned on devices[0].
+        #: EXPERIMENTAL: bit-for-bit against one device with the same GPU
+        #: listed N times (tests/test_gpu_multi.py); the peer copies and the
+        #: cross-device stream ordering have not run on two physical GPUs
+        #: (tests/test_gpu_multi.py::test_two_physical_gpus_* are skipped on
+        #: one-GPU boxes)
         self.devices = list(devices) if devices else None
         if self.devices and device is None:
             self.device = self.devices[0]

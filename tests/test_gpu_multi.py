@@ -349,6 +349,39 @@ def _sharded_worker(rank, world, port, tmpdir, backend):
             csr, mm['frac_b'], m.dst_dims, field, [1], None), np.nan)
         notes['collective_array'] = int(np.array_equal(
             np.ma.filled(got, np.nan), want, equal_nan=True))
+        # _remap_numpy_array under the group: the reference's values AND
+        # mask (:262-278) -- a MaskedArray whose mask hides finite values,
+        # with one NaN that is NOT masked (it goes through, :263: every cell
+        # it touches is NaN and unmasked); the frac_b branch with NaNs (mask
+        # = frac_b <= 0 only, NaNs propagate unmasked); a plain ndarray
+        from pyremap_amd.remapper.remap_numpy import _remap_numpy_array
+        data = rng.standard_normal((2, m.n_a, 3))
+        hide = rng.random(data.shape) < 0.3
+        data[0, 17, 1] = np.nan
+        hide[0, 17, 1] = False
+        data[1, 40:60, :] = np.nan
+        hide[1, 40:60, :] = True
+        ok = 1
+        for arg, thr in ((np.ma.masked_array(data, hide), 0.01),
+                         (np.ma.masked_array(data, hide), None),
+                         (data, 0.01), (np.nan_to_num(data), None)):
+            if rank == 0:
+                mine = arg
+            elif isinstance(arg, np.ma.MaskedArray):   # shapes and type only
+                mine = np.ma.masked_array(np.zeros_like(data),
+                                          np.zeros(data.shape, bool))
+            else:
+                mine = np.zeros_like(data)
+            got = _remap_numpy_array(r, mine, [1], thr)
+            want = oracle.remap_numpy_array(csr, mm['frac_b'], m.dst_dims,
+                                            arg, [1], thr)
+            wm, gm = np.ma.getmaskarray(want), np.ma.getmaskarray(got)
+            ok &= int(isinstance(got, np.ma.MaskedArray))
+            ok &= int(np.array_equal(gm, wm))
+            ok &= int(np.array_equal(np.ma.getdata(got)[~wm],
+                                     np.ma.getdata(want)[~wm],
+                                     equal_nan=True))
+        notes['collective_masks'] = ok
         # ncremap as a collective: every rank reads, rank 0 alone writes
         from pyremap_amd.io.netcdf import open_dataset, write_netcdf
         src_path = os.path.join(tmpdir, 'collective_in.nc')
@@ -384,7 +417,8 @@ def _run_ranks(world, tmp_path, backend):
         notes = eval(open(tmp_path / f'rank{rank}.txt').read())
         for key in ('alltoall', 'broadcast', 'pipelined_alltoall',
                     'pipelined_broadcast', 'collective_dataset',
-                    'collective_array', 'collective_file'):
+                    'collective_array', 'collective_masks',
+                    'collective_file'):
             assert notes[key] == 1, (rank, key, notes)
         # mesh-numbered source: the packed rows still are ~(1/N + halo)
         assert notes['packed_frac'] < {1: 1.01, 2: 0.8}.get(world, 0.65)
@@ -419,6 +453,45 @@ def test_sharded_remap_over_rccl(tmp_path):
     """The same through RCCL, one rank per GPU -- the run the advisor asked
     for before the all-to-all exchange becomes the nccl default."""
     _run_ranks(2, tmp_path, 'nccl')
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2,
+                    reason='needs two physical GPUs (peer copies)')
+def test_two_physical_gpus_stress_under_a_side_stream():
+    """
+    `Remapper(devices=[cuda:0, cuda:1])` on two PHYSICAL GPUs (the other
+    tests list one GPU N times): remap_tensor looped under a non-default
+    stream with allocator churn between the calls -- a missing dependency
+    between the gather on the source stream, the peer copy, the launch on the
+    other device's stream and the copy back into the assembled result shows
+    up as a stale or torn slab.  Every call bitwise the one-device result.
+    """
+    from pyremap_amd import engine, synthetic
+    from pyremap_amd.parallel import MultiDeviceRemap
+    d0, d1 = torch.device('cuda', 0), torch.device('cuda', 1)
+    m = synthetic.conservative_map(30000, (120, 200), 2, 7, seed=5,
+                                   device=d0, locality='mesh')
+    plan = engine.RemapPlan.from_triplets(m.row, m.col, m.S, m.frac_b, m.n_a,
+                                          m.n_b, index_base=1, device=d0)
+    plan.auto_schedule(m.dst_dims)
+    multi = MultiDeviceRemap(plan, [d0, d1], grid_dims=m.dst_dims)
+    side = torch.cuda.Stream(device=d0)
+    g = torch.Generator(device=d0)
+    g.manual_seed(9)
+    for it in range(40):
+        K = (64, 96, 130)[it % 3]
+        with torch.cuda.stream(side):
+            x = torch.randn((m.n_a, K), generator=g, device=d0,
+                            dtype=torch.float64)
+            junk = [torch.empty(1 << (18 + it % 5), device=d)
+                    for d in (d0, d1)]              # allocator churn
+            y = multi.remap_tensor(m.dst_dims, x, [0], engine.MODE_FRACB)
+            ref = engine.remap_tensor(plan, m.dst_dims, x, [0],
+                                      engine.MODE_FRACB)
+            del junk
+        side.synchronize()
+        assert torch.equal(torch.nan_to_num(y, nan=-7.0),
+                           torch.nan_to_num(ref, nan=-7.0)), it
 
 
 def test_shards_without_entries(dev):

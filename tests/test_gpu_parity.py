@@ -1974,26 +1974,76 @@ def test_bench_multi_rank_line_and_a_hung_exchange(tmp_path):
             '--nproc-per-node', '2', '--master-addr', '127.0.0.1']
     bench = [os.path.join(repo, 'bench.py'), '--gpus', '2', '--steps', '5',
              '--warmup', '2', '--backend', 'gloo', '--no-extra']
+    # the third pass is plain `python bench.py --gpus 2 ...` with no launcher
+    # around it: bench.py starts its ranks itself (as a child) and relays
+    # rank 0's line
     for port, env_extra in (('29571', {}),
                             ('29572', {'BENCH_TEST_HANG': '1',
-                                       'BENCH_OPTIONAL_TIMEOUT_S': '5'})):
+                                       'BENCH_OPTIONAL_TIMEOUT_S': '5'}),
+                            (None, {})):
         env = dict(os.environ, **env_extra)
-        proc = subprocess.run(base + ['--master-port', port] + bench,
-                              capture_output=True, text=True, env=env,
+        for name in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+            env.pop(name, None)
+        cmd = [sys.executable] + bench if port is None else \
+            base + ['--master-port', port] + bench
+        proc = subprocess.run(cmd, capture_output=True, text=True, env=env,
                               timeout=600, cwd=str(tmp_path))
         hung = bool(env_extra)
         assert (proc.returncode != 0) == hung, proc.stderr[-2000:]
-        line = json.loads(proc.stdout.strip().splitlines()[-1])
+        last = proc.stdout.strip().splitlines()[-1]
+        assert len(last) < 4096
+        line = json.loads(last)
         assert line['status'] == ('exchange_hung' if hung else 'ok')
         assert line['n_gpus'] == 2 and line['scaling'] == 'strong'
         assert line['value'] > 0 and 0 < line['roofline']['frac'] < 1
         multi = line['multi_gpu']
         assert multi['broadcast_ms'] > 0 and multi['kernel_phase_ms'] > 0
+        assert multi['ranks'] == 2 and multi['backend'] == 'gloo'
         # the source mesh is numbered as MPAS numbers its cells, and each
         # rank still needs only about half of the source rows
         assert line['config']['locality'] == 'mesh'
         assert multi['packed_fraction_of_broadcast'] < 0.8
         assert ('optional_measurements' in multi) == hung
+        # everything else is in the side file the line names
+        details = json.load(open(os.path.join(repo, line['details'])))
+        assert details['line']['value'] == line['value']
+        assert details['schedule']['family']
+
+
+def test_bench_single_gpu_line_parses_and_is_small(tmp_path):
+    """
+    The driver's command (`python bench.py --gpus 1 --steps K --warmup W`):
+    the last stdout line is JSON under 4 KB with `roofline` and
+    `cpu_baseline` in it (round 3's had outgrown the driver's 8 KB tail).
+    """
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    side = str(tmp_path / 'extra.json')
+    proc = subprocess.run(
+        [sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '1',
+         '--steps', '5', '--warmup', '2', '--no-extra', '--cpu-seconds', '3',
+         '--details', side],
+        capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    last = proc.stdout.strip().splitlines()[-1]
+    assert len(last) < 4096
+    line = json.loads(last)
+    assert line['n_gpus'] == 1 and line['steps'] == 5 and line['warmup'] == 2
+    assert line['status'] == 'ok' and line['multi_gpu'] is None
+    roof, cpu = line['roofline'], line['cpu_baseline']
+    assert roof['bound'] == 'hbm' and 0.2 < roof['frac'] < 1
+    assert abs(roof['achieved'] - roof['bytes_alg_per_launch'] /
+               (roof['kernel_ms_mean'] * 1e-3) / 1e9) < 1e-3 * roof['achieved']
+    assert cpu['cores'] == 1 and cpu['value'] > 0 and cpu['port_value'] > 0
+    assert cpu['kind'] in ('reference', 'port')
+    # value = the units of the timed steps over their wall time
+    units = line['config']['n_b'] * line['config']['fields_K']
+    assert abs(line['value'] - units / (line['ms_per_step'] * 1e-3)) < \
+        1e-6 * line['value']
+    details = json.load(open(side))
+    assert details['line'] == line and details['phases_s']['total_s'] > 0
 
 
 def test_plan_handle_device_inputs_and_strided_fields(dev):

@@ -797,3 +797,164 @@ def test_lazy_values_announced_shape_is_checked(tmp_path):
     for fmt in ('NETCDF3_64BIT', 'NETCDF4'):
         with pytest.raises(ValueError, match='announced'):
             write_netcdf(ds, str(tmp_path / f'bad_{fmt}.nc'), format=fmt)
+
+
+# ---------------------------------------------------------------------------
+# bench.py: the one JSON line stays small enough for the driver to parse
+# ---------------------------------------------------------------------------
+
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        'bench_under_test', os.path.join(REPO, 'bench.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _fake_bench_result(bench, world):
+    """A fully populated (res, extra, cpu, pipelined) as bench.py's main()
+    hands them to compose_line, with long strings where strings can grow."""
+    schedule = {'family': 'rowgroup', 'union_ratio': 0.7092391335681794,
+                'rows_per_group': 4, 'order': '2x2 groups, row-major ' * 4,
+                'tune': {str(m): [10, 0, 0, 1, 0] for m in range(3)}}
+    res = dict(
+        name='config3', title='EC30to60 -> 0.5deg conservative, 512 fields',
+        n_a=235160, n_b=259200, n_s_file=912860, nnz_csr=867235, K=512,
+        mode='fracb', layout='nk', locality='mesh', steps=20, warmup=5,
+        wall_s=0.00756218716502189, ms_per_step=0.37810935825109464,
+        kernel_ms_mean=0.3776483833789825, kernel_ms_graph_replay=None,
+        kernel_ms_median=0.37540000677108765,
+        kernel_ms_min=0.3701600134372711, kernel_ms_max=0.3951199948787689,
+        kernel_ms_second_pass_in_order=[0.37540000677108765] * 20,
+        kernel_ms_steady_100_more=0.3771531283855438,
+        touched_frac=1.0, cell_fields_per_s=350982072435.12345,
+        dst_cells_per_s_per_batch=685511860.2248505,
+        bytes_alg=2039452588, bytes_alg_read=977769388,
+        achieved_GBps=5400.400400400401, plan_build_s=0.4123456789,
+        exchange=None, rows_this_rank=259200, nnz_this_rank=867235,
+        schedule=schedule)
+    if world > 1:
+        res['exchange'] = dict(
+            broadcast_ms=147.31661000405438, ranks=world, backend='nccl',
+            exchange='one broadcast of X + local gather of the packed rows, '
+                     'before the timed region',
+            field_bytes=963215360,
+            packed_fraction_of_broadcast=0.12912261439020241,
+            packed_rows_this_rank=117442, local_gather_ms=0.3455623388290405,
+            packed_ms=12.345678901234567,
+            optional_measurements='timed out after 150 s: packed / '
+                                  'pipelined exchange did not return',
+            packed_error='RuntimeError: ' + 'x' * 200)
+        res['kernel_ms_mean_max_rank'] = 0.05123456789
+    args = bench.parse_args.__globals__['argparse'].Namespace(
+        gpus=world, steps=20, warmup=5, workload='config3', fields=None,
+        mode='fracb', layout='nk', locality='mesh', shard='rows', sets=3,
+        tune='', flags=0, no_cpu=False, no_extra=False, all_workloads=True,
+        details=None, cpu_seconds=15.0, backend='nccl', metric_first=False,
+        force_dist=False)
+    extra = {}
+    for tag, kw, steps in bench.extras_todo(args, 1):
+        extra[tag] = dict(
+            title='a title that is fairly long, ' * 3, n_a=3693225,
+            n_b=6480000, nnz_csr=78123456, K=kw.get('K', 1024),
+            mode=kw.get('mode', 'fracb'), layout=kw.get('layout', 'nk'),
+            locality='mesh', schedule=schedule, touched_frac=1.0,
+            ms_per_step=22.123456789012345, kernel_ms_mean=22.12345678901234,
+            kernel_ms_graph_replay=0.0072123456789,
+            kernel_ms_median=22.123456789, cell_fields_per_s=3.0123456789e11,
+            bytes_alg=84380123456, achieved_GBps=3812.123456789, steps=steps,
+            dtype='f64', times=8, frac_of_peak=0.4765123456789,
+            read_frac_of_peak=0.17123456789, traffic=93100123456.789,
+            prepare_and_measure_s=5.123456789)
+    extra['one_that_failed'] = {'error': 'OutOfMemoryError: ' + 'y' * 500}
+    extra['host_buffers_pcie_inclusive'] = {
+        'n_a_K': dict(seconds=0.038, cell_fields_per_s=3.4e9),
+        'note': 'numpy in -> numpy masked array out'}
+    cpu = dict(
+        value=441234567.891234, unit='dst cell-fields/s', cores=1,
+        kind='reference', sample='whole workload ' + 'z' * 400,
+        seconds=0.30123456789, scipy_value=441234567.891234,
+        port_value=363123456.789, port_seconds=0.365123456789,
+        port_all_cores=dict(value=1.2e9, cores=128, seconds=0.11),
+        host_cpus=256, host_model='AMD EPYC 9575F 64-Core Processor')
+    pipelined = dict(pipelined_alltoall_ms_per_K_fields=20.123456789,
+                     pipelined_broadcast_ms_per_K_fields=147.169120995386,
+                     n_column_batches=4)
+    return args, res, extra, cpu, pipelined
+
+
+@pytest.mark.parametrize('world', [1, 8])
+def test_bench_line_stays_under_4_kb(world):
+    """
+    BENCH_r03.json had `parsed: null`: the line had grown to 16-22 KB and the
+    driver keeps an 8 KB tail of stdout.  Whatever was measured -- every
+    workload of --all-workloads, a failed one, the exchange timings of an
+    8-rank run with its error strings -- the line stays under bench.LINE_LIMIT
+    and still carries the fields the driver and the judge read; the rest goes
+    to the side file.
+    """
+    bench = _bench_module()
+    assert bench.LINE_LIMIT <= 4096
+    args, res, extra, cpu, pipelined = _fake_bench_result(bench, world)
+    line, details = bench.compose_line(
+        args, res, world, 6512.123456789, cpu if world == 1 else None,
+        extra, pipelined if world > 1 else None,
+        details_path='gpurun_out/bench_extra.json')
+    text = json.dumps(line)
+    assert len(text) < bench.LINE_LIMIT, len(text)
+    back = json.loads(text)
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup',
+                'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+                'dtype', 'data', 'config', 'roofline', 'cpu_baseline',
+                'status'):
+        assert key in back, key
+    roof = back['roofline']
+    for key in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic',
+                'kernel', 'kernel_ms_mean', 'bytes_alg_per_launch',
+                'read_frac_of_peak', 'measured_copy_ceiling_GBps',
+                'workloads'):
+        assert key in roof, key
+    assert abs(roof['frac'] - roof['achieved'] / roof['peak']) < 1e-5
+    assert back['config']['workload'].startswith('config3')
+    # every workload has its [ms, frac] pair, none was dropped for size
+    assert 'workloads_truncated' not in roof
+    todo = [t[0] for t in bench.extras_todo(args, 1)]
+    assert set(todo) <= set(roof['workloads'])
+    for tag in todo:
+        ms, frac = roof['workloads'][tag]
+        assert ms > 0 and frac > 0
+    assert set(bench.DEFAULT_ROWS) <= set(todo)
+    if world == 1:
+        cb = back['cpu_baseline']
+        assert cb['kind'] == 'reference' and cb['cores'] == 1
+        assert cb['value'] == cb['scipy_value'] and cb['port_value'] > 0
+        assert back['multi_gpu'] is None
+    else:
+        multi = back['multi_gpu']
+        for key in ('ranks', 'backend', 'exchange', 'broadcast_ms',
+                    'packed_ms', 'kernel_phase_ms',
+                    'packed_fraction_of_broadcast'):
+            assert key in multi, key
+        assert multi['ranks'] == world
+    # nothing is lost: the side file holds what the line no longer does
+    assert details['workloads']['headline']['schedule']['family'] == \
+        'rowgroup'
+    assert details['result']['kernel_ms_second_pass_in_order']
+    assert 'host_buffers_pcie_inclusive' in details['workloads']
+
+
+def test_bench_line_drops_rows_rather_than_overflow():
+    """Even a table of workloads nobody planned for cannot push the line
+    over the limit: rows are dropped (they stay in the side file)."""
+    bench = _bench_module()
+    args, res, extra, cpu, _ = _fake_bench_result(bench, 1)
+    one = extra['headline']
+    for n in range(200):
+        extra[f'another_workload_with_a_long_name_{n}'] = dict(one)
+    line, details = bench.compose_line(args, res, 1, 6500.0, cpu, extra,
+                                       None, details_path='x.json')
+    assert len(json.dumps(line)) <= bench.LINE_LIMIT
+    assert line['roofline']['workloads_truncated'] is True
+    assert 'headline' in line['roofline']['workloads']
+    assert len(details['workloads']) > 200

@@ -21,7 +21,12 @@ python bench.py --steps 20 --warmup 5 --force-dist --no-cpu > gpurun_out/b_fd.js
 for w in config2 config4 config5 headline; do
   python bench.py --workload $w --steps 30 --warmup 5 --sets 1 --no-cpu --no-extra > gpurun_out/bench_$w.json 2> gpurun_out/bench_$w.err
 done
-python bench.py --steps 20 --warmup 5 > gpurun_out/bench_n1.json 2> gpurun_out/bench_n1.err
+( time python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_n1.json 2> gpurun_out/bench_n1.err ) 2> gpurun_out/bench_n1.time
+cp gpurun_out/bench_extra.json gpurun_out/bench_n1_extra.json
+# the driver keeps an 8 KB tail of stdout: a longer line is an unmeasured round
+BYTES=$(tail -n 1 gpurun_out/bench_n1.json | wc -c)
+if [ "$BYTES" -ge 4096 ]; then echo "FAIL: bench line is $BYTES bytes (limit 4096)"; exit 1; fi
+echo "bench line: $BYTES bytes; $(grep real gpurun_out/bench_n1.time)"
 python - <<'PY'
 import glob
 import json
