@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define REMAP_ABI_VERSION 22
+#define REMAP_ABI_VERSION 23
 
 enum {
     REMAP_OK = 0,
@@ -120,6 +120,51 @@ typedef struct remap_csr {
                               kernels that fetch a row's entries 8 at a time
                               through the scalar cache                       */
 } remap_csr;
+
+/*
+ * Optional strip schedule of kernel family 8 (remap_apply_args.strips; built
+ * by the host layer: pyremap_amd.engine.RemapPlan.build_strips).  For
+ * entry-rich mappings onto a 2-D destination grid (2nd-order conservative
+ * stencils: 12-30 entries per row): the grid is cut into strips of
+ * `strip_rows` grid rows, a strip into segments, a segment is walked in steps
+ * of `step_cols` grid columns.  Unit u = one (strip, segment); its steps are
+ * g = u * steps_per_unit + t, t < unit_steps[u].  A workgroup owns one (unit,
+ * 64-column K-chunk): the 512-byte pieces of the source rows a step needs
+ * ARRIVE in an LDS ring of `ring_slots` slots, `depth` steps ahead, and stay
+ * while consecutive steps use them; the rows of a step are dealt to 8
+ * compute waves, `rows_per_wave` each.  Every row still adds its entries in
+ * ascending column order: results are unchanged.
+ */
+typedef struct remap_strips {
+    int64_t n_units;
+    int32_t steps_per_unit;
+    int32_t rows_per_wave;      /* ceil(strip_rows * step_cols / waves)      */
+    int32_t ring_slots;         /* piece slots, even: ring_slots * 512 bytes */
+    int32_t depth;              /* steps an arrival is issued ahead: 1 .. 6
+                                   (= loader waves per workgroup)            */
+    int32_t meta_slot_bytes;    /* largest meta block, rounded up to 1 KiB;
+                                   (depth + 1) such slots follow the piece
+                                   slots and 1 KiB holding a slot of zeros   */
+    int32_t waves;              /* compute waves per workgroup the rows of a
+                                   step are dealt to; waves + depth <= 16    */
+    const int32_t *unit_steps;  /* (device) n_units                          */
+    /* arrival pairs of step g: i in [arr_ptr[g], arr_ptr[g + 1]); pair i
+     * brings the pieces of source rows arr_src[2 i] and arr_src[2 i + 1]
+     * (-1: none) into slots 2 arr_slot[i] and 2 arr_slot[i] + 1. */
+    const int32_t *arr_ptr;     /* (device) n_units * steps_per_unit + 1     */
+    const int32_t *arr_src;     /* (device) 2 per pair                       */
+    const int32_t *arr_slot;    /* (device) 1 per pair                       */
+    /* meta block of step g: 16-byte units [meta_ptr[g], meta_ptr[g + 1]) of
+     * `meta`.  First waves * rows_per_wave row headers of 32 bytes, work
+     * slot wave * rows_per_wave + i: {int32 row id (-1: none), int32 first
+     * record, int32 records (a multiple of 4), 0; double frac_b, 0}; then
+     * the step's records, 16 bytes each, a row's entries in ascending column
+     * order followed by its pads: {int32 byte offset of the source row's
+     * piece in LDS (slot * 512; pads: ring_slots * 512, the slot of zeros),
+     * 0; double weight (pads: +0.0)}. */
+    const int64_t *meta_ptr;    /* (device) n_units * steps_per_unit + 1     */
+    const void *meta;           /* (device) 16-byte aligned (+ 1 KiB readable) */
+} remap_strips;
 
 /*
  * Two levels.  The PUBLIC, frozen face for a binder is
@@ -245,6 +290,8 @@ typedef struct remap_apply_args {
      *                             several batches: (Time, nCells)),
      *                         7 = 4 with the distinct source cells of a
      *                             patch staged in LDS (needs a patch plan)
+     *                         8 = an LDS ring sliding along strips of the
+     *                             destination grid (needs `strips`)
      * tune[1] doubles per lane per tile (1 or 2); family 10: waves per
      *         workgroup (1, 2; else 4); family 2: entries of a row fetched
      *         together (1, 4 or 8)
@@ -277,6 +324,10 @@ typedef struct remap_apply_args {
      * lane reading its own row's entries one by one pays a line fetch per
      * lane and entry (engine.RemapPlan._split_long_rows). */
     const int64_t *patch_ell_base;
+    /* Optional strip schedule (HOST pointer to a struct of device pointers;
+     * NULL = absent), kernel family 8: the whole row range, float64 X, one
+     * batch (n_batch == 1) of an even number of contiguous columns. */
+    const remap_strips *strips;
 } remap_apply_args;
 
 /* ABI / build information */

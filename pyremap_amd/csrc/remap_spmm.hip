@@ -62,6 +62,7 @@ namespace {
 #include "spmm_rowcell.h"
 #include "spmm_patchcell.h"
 #include "spmm_rowsub.h"
+#include "spmm_strip.h"
 
 // ---------------------------------------------------------------------------
 // host-side dispatch
@@ -477,6 +478,7 @@ struct Call {
     bool patch_ok;        // a usable patch plan is attached
     bool cell_ok;         // a patch plan family 7 can use is attached
     bool group_ok;        // a usable row-group schedule is attached
+    bool strip_ok;        // a strip schedule this call can run on is attached
 };
 
 // Argument checks.  Returns REMAP_OK with c.K == 0 for an empty output.
@@ -567,6 +569,24 @@ int check_args(const remap_apply_args *a, Call &c)
                  a->group_reserved == 0 &&
                  a->n_groups ==
                      (c.n_rows + a->group_rows - 1) / a->group_rows;
+    const remap_strips *st = a->strips;
+    c.strip_ok = st && st->n_units > 0 && st->steps_per_unit > 0 &&
+                 st->rows_per_wave > 0 && st->ring_slots >= 2 &&
+                 st->ring_slots % 2 == 0 &&
+                 (int64_t)st->ring_slots * kStripRowBytes <=
+                     (int64_t)kPatchLdsMax &&
+                 st->depth >= 1 && st->depth <= 6 &&
+                 st->meta_slot_bytes > 0 && st->meta_slot_bytes % 1024 == 0 &&
+                 st->waves >= 1 && st->waves + st->depth <= 16 &&
+                 (int64_t)(st->ring_slots + 2) * kStripRowBytes +
+                         (int64_t)(st->depth + 1) * st->meta_slot_bytes <=
+                     (int64_t)kPatchLdsMax &&
+                 st->unit_steps && st->arr_ptr && st->arr_src &&
+                 st->arr_slot && st->meta_ptr && st->meta &&
+                 // the whole mapping, float64, one batch of contiguous
+                 // columns in whole 16-byte pieces
+                 a->row_begin == 0 && a->row_end == A.n_rows && !c.f32 &&
+                 a->n_batch == 1 && c.dma16 && a->x_src_fold == 0;
     return REMAP_OK;
 }
 
@@ -636,6 +656,8 @@ bool hint_usable(const remap_apply_args *a, const Call &c)
         return c.patch_ok;
     case 7:
         return c.cell_ok;
+    case 8:
+        return c.strip_ok;
     case 6:
         return a->A.csr_pad >= 8 && c.small_offsets &&
                (a->tune[1] != 2 || c.can_vec2);
@@ -925,6 +947,71 @@ int run_patchcell(const remap_apply_args *a, const Call &c, KParams p,
     return REMAP_OK;
 }
 
+typedef void (*strip_fn)(const KParams, const int32_t *, const int32_t *,
+                         const int32_t *, const int32_t *, const int64_t *,
+                         const char *, int32_t, int32_t, int32_t, int32_t,
+                         int32_t, int64_t);
+
+template <int DEPTH>
+strip_fn pick_strip_mode(int mode, bool fma)
+{
+    switch (mode) {
+    case REMAP_MODE_RAW:
+        return fma ? spmm_strip<REMAP_MODE_RAW, true, DEPTH>
+                   : spmm_strip<REMAP_MODE_RAW, false, DEPTH>;
+    case REMAP_MODE_FRACB:
+        return fma ? spmm_strip<REMAP_MODE_FRACB, true, DEPTH>
+                   : spmm_strip<REMAP_MODE_FRACB, false, DEPTH>;
+    default:
+        return fma ? spmm_strip<REMAP_MODE_MASKED, true, DEPTH>
+                   : spmm_strip<REMAP_MODE_MASKED, false, DEPTH>;
+    }
+}
+
+// family 8: one workgroup per (strip segment, 64-column K-chunk), unit-major
+int run_strip(const remap_apply_args *a, const Call &c, KParams p,
+              hipStream_t stream)
+{
+    if (!c.strip_ok)
+        return fail(REMAP_ERR_ARG,
+                    "remap_apply_f64: the strip kernel needs a strip "
+                    "schedule, the whole row range and one batch of "
+                    "contiguous float64 columns");
+    const remap_strips *st = a->strips;
+    const int64_t n_chunks = ceil_div(c.K, kStripRowBytes / 8);
+    // unit-major work list: shape_grid's "chunks" are the slow index
+    int64_t grid;
+    const int rc = shape_grid(p, n_chunks, st->n_units, a->tune[4] != 1,
+                              grid);
+    if (rc != REMAP_OK)
+        return rc;
+    strip_fn fn;
+    switch (st->depth) {
+    case 1: fn = pick_strip_mode<1>(a->mode, c.fma); break;
+    case 2: fn = pick_strip_mode<2>(a->mode, c.fma); break;
+    case 3: fn = pick_strip_mode<3>(a->mode, c.fma); break;
+    case 4: fn = pick_strip_mode<4>(a->mode, c.fma); break;
+    case 5: fn = pick_strip_mode<5>(a->mode, c.fma); break;
+    default: fn = pick_strip_mode<6>(a->mode, c.fma); break;
+    }
+    const uint32_t lds_bytes =
+        static_cast<uint32_t>(st->ring_slots + 2) * kStripRowBytes +
+        static_cast<uint32_t>(st->depth + 1) * st->meta_slot_bytes;
+    if (lds_bytes > 64 * 1024)
+        REMAP_HIP_CHECK(hipFuncSetAttribute(
+            reinterpret_cast<const void *>(fn),
+            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    hipLaunchKernelGGL(fn, dim3(static_cast<uint32_t>(grid)),
+                       dim3((st->waves + st->depth) * kWave), lds_bytes,
+                       stream, p, st->unit_steps, st->arr_ptr, st->arr_src,
+                       st->arr_slot, st->meta_ptr,
+                       static_cast<const char *>(st->meta),
+                       st->steps_per_unit, st->rows_per_wave, st->ring_slots,
+                       st->meta_slot_bytes, st->waves, n_chunks);
+    REMAP_HIP_CHECK(hipGetLastError());
+    return REMAP_OK;
+}
+
 // family 3: a sub-group of 8 (4 for rows of at most 4 entries: bilinear
 // maps) lanes per row; tune[1] overrides the sub-group size
 int run_rowsub(const remap_apply_args *a, const Call &c, const KParams &p,
@@ -1038,6 +1125,8 @@ int apply(const remap_apply_args *a, hipStream_t stream)
         return run_rowcell(a, c, p, stream);
     case 7:
         return run_patchcell(a, c, p, stream);
+    case 8:
+        return run_strip(a, c, p, stream);
     case 1:
     case 6:
         return run_rowwave(a, c, p, family, stream);

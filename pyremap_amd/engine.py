@@ -33,7 +33,7 @@ FLAG_TREE = 8
 DTYPE_F64 = 0
 DTYPE_F32 = 1
 
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 #: readable pad entries kept behind col/val (remap_csr.csr_pad)
 CSR_PAD = 8
@@ -113,6 +113,25 @@ class _ApplyArgs(ctypes.Structure):
         ('x_src_fold', ctypes.c_int64),
         ('x_outer_stride', ctypes.c_int64),
         ('patch_ell_base', ctypes.c_void_p),
+        ('strips', ctypes.c_void_p),
+    ]
+
+
+class _Strips(ctypes.Structure):         # struct remap_strips
+    _fields_ = [
+        ('n_units', ctypes.c_int64),
+        ('steps_per_unit', ctypes.c_int32),
+        ('rows_per_wave', ctypes.c_int32),
+        ('ring_slots', ctypes.c_int32),
+        ('depth', ctypes.c_int32),
+        ('meta_slot_bytes', ctypes.c_int32),
+        ('waves', ctypes.c_int32),
+        ('unit_steps', ctypes.c_void_p),
+        ('arr_ptr', ctypes.c_void_p),
+        ('arr_src', ctypes.c_void_p),
+        ('arr_slot', ctypes.c_void_p),
+        ('meta_ptr', ctypes.c_void_p),
+        ('meta', ctypes.c_void_p),
     ]
 
 
@@ -415,6 +434,8 @@ class RemapPlan:
         #: (short, long) sibling plans when a few rows hold a large share of
         #: the entries (see _split_long_rows); None otherwise
         self._split = None
+        #: optional strip schedule of kernel family 8 (see build_strips)
+        self.strips = None
 
     def _sched_property(name):   # noqa: N805 - class-body helper
         def get(self):
@@ -427,6 +448,7 @@ class RemapPlan:
 
     patches = _sched_property('patches')
     groups = _sched_property('groups')
+    strips = _sched_property('strips')
     row_order = _sched_property('row_order')
     del _sched_property
 
@@ -500,6 +522,9 @@ class RemapPlan:
                 args.group_frac = groups['frac'].data_ptr()
                 args.n_groups = groups['n']
                 args.group_rows = groups['rows']
+            if self.strips is not None:
+                # (self-contained: its own row order and row ids)
+                args.strips = ctypes.addressof(self.strips['struct'])
         self._args_cache[key] = (self._sched_version, bytes(args))
         return args
 
@@ -954,6 +979,26 @@ class RemapPlan:
     #: a row counts as LONG from this many entries on (the widest stencils
     #: of ordinary maps -- 2nd-order conservative -- hold ~30)
     LONG_ROW = 96
+
+    def build_strips(self, grid_dims, **shape):
+        """
+        Attach the strip schedule of kernel family 8 (``csrc/spmm_strip.h``):
+        an LDS ring of source-row pieces sliding along strips of the
+        destination grid ``grid_dims``, for entry-rich mappings (2nd-order
+        conservative stencils).  ``shape``: ``strip_rows``, ``step_cols``,
+        ``segments``, ``depth`` (:func:`pyremap_amd.strips.build_strips`).
+        Calls the kernel cannot serve (several batches, float32, a row
+        shard) run on the plan's other schedule as before.  Raises
+        :class:`pyremap_amd.strips.StripsUnfit` when the ring does not fit
+        the LDS.
+        """
+        from pyremap_amd import strips as _strips
+        if self.row_offset != 0 or self.n_b != self.n_b_global:
+            raise ValueError('a strip schedule covers a whole mapping')
+        st = _strips.build_strips(self, grid_dims, **shape)
+        st['struct'] = _strips.struct(st, _Strips)
+        self.strips = st
+        return st
 
     def _split_long_rows(self):
         """

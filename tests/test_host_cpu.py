@@ -57,6 +57,7 @@ def test_struct_layout_matches_header():
     assert fields('remap_plan_info') == \
         [f[0] for f in engine._PlanInfo._fields_]
     assert fields('remap_field') == [f[0] for f in engine._Field._fields_]
+    assert fields('remap_strips') == [f[0] for f in engine._Strips._fields_]
 
 
 def test_no_gpu_means_loud_failure():
