@@ -292,6 +292,15 @@ typedef struct remap_apply_args {
      *                             patch staged in LDS (needs a patch plan)
      *                         8 = an LDS ring sliding along strips of the
      *                             destination grid (needs `strips`)
+     *                         9 = one wave per (row, few columns), the
+     *                             row's entries read lanes-across-entries
+     *                             and summed in order from LDS: for a CSR of
+     *                             LONG rows (hundreds of entries) and few
+     *                             fields.  `A` then holds those rows only:
+     *                             its row r is work slot r and row_order[r],
+     *                             if given, names the row of Y / frac_b /
+     *                             mask_out it writes; needs A.max_row_nnz;
+     *                             tune[1] = columns per wave (1 ... 16)
      * tune[1] doubles per lane per tile (1 or 2); family 10: waves per
      *         workgroup (1, 2; else 4); family 2: entries of a row fetched
      *         together (1, 4 or 8)

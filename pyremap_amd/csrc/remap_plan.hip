@@ -898,9 +898,16 @@ int remap_plan_apply(const remap_plan *plan, const remap_field *f,
     b.patch_row_bytes = 1024;
     b.n_patches = plan->long_patches;
     b.patch_ell_base = plan->long_base;
+    // few fields: one wave per (long row, a few columns), family 9; many:
+    // the lanes-across-rows kernel on the rows' shared source cells
+    // (engine.apply_strided has the measurements)
     const int64_t K = static_cast<int64_t>(f->n_batch) * f->k_inner;
-    b.tune[0] = 7;
-    b.tune[1] = K <= 8 ? 1 : K <= 128 ? 2 : 4;
+    if (K <= 16) {
+        b.tune[0] = 9;
+    } else {
+        b.tune[0] = 7;
+        b.tune[1] = K <= 128 ? 2 : 4;
+    }
     b.flags = f->flags | REMAP_FLAG_TUNE_HINT;
     return remap_apply_f64(&b, stream);
 }

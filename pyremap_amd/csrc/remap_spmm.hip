@@ -63,6 +63,7 @@ namespace {
 #include "spmm_patchcell.h"
 #include "spmm_rowsub.h"
 #include "spmm_strip.h"
+#include "spmm_longrow.h"
 
 // ---------------------------------------------------------------------------
 // host-side dispatch
@@ -524,10 +525,11 @@ int check_args(const remap_apply_args *a, Call &c)
                     "%lld source cells", (long long)a->x_src_fold,
                     (long long)A.n_cols);
     if (a->x_src_fold != 0 && a->tune[0] != 0 && a->tune[0] != 4 &&
-        a->tune[0] != 7 && !(a->flags & REMAP_FLAG_TUNE_HINT))
+        a->tune[0] != 7 && a->tune[0] != 9 &&
+        !(a->flags & REMAP_FLAG_TUNE_HINT))
         return fail(REMAP_ERR_UNSUPPORTED,
                     "remap_apply_f64: two non-adjacent source axes "
-                    "(x_src_fold) are served by kernel families 4 and 7");
+                    "(x_src_fold) are served by kernel families 4, 7 and 9");
     if (c.K >= (int64_t(1) << 31))
         return fail(REMAP_ERR_UNSUPPORTED,
                     "remap_apply_f64: K = %lld fields per call exceeds 2^31",
@@ -645,6 +647,9 @@ bool hint_usable(const remap_apply_args *a, const Call &c)
 {
     if (a->tune[0] == 7)
         return c.cell_ok;   // LDS-staged lanes across rows: any K
+    if (a->tune[0] == 9)    // wave per long row: any K, any layout
+        return a->A.max_row_nnz > 0 &&
+               2 * ((a->A.max_row_nnz + 34) * 8) <= (int64_t)kPatchLdsMax;
     if (c.K <= 32)
         return false;  // the lane-per-(row, k) kernel owns small K
     if (short_runs(a) && a->tune[0] != 4)
@@ -1012,6 +1017,87 @@ int run_strip(const remap_apply_args *a, const Call &c, KParams p,
     return REMAP_OK;
 }
 
+typedef void (*long_fn)(const KParams, const uint32_t, const int32_t);
+
+template <typename XT, int TT>
+long_fn pick_longrow_mode(int mode, bool fma)
+{
+    switch (mode) {
+    case REMAP_MODE_RAW:
+        return fma ? spmm_longrow<XT, REMAP_MODE_RAW, true, TT>
+                   : spmm_longrow<XT, REMAP_MODE_RAW, false, TT>;
+    case REMAP_MODE_FRACB:
+        return fma ? spmm_longrow<XT, REMAP_MODE_FRACB, true, TT>
+                   : spmm_longrow<XT, REMAP_MODE_FRACB, false, TT>;
+    default:
+        return fma ? spmm_longrow<XT, REMAP_MODE_MASKED, true, TT>
+                   : spmm_longrow<XT, REMAP_MODE_MASKED, false, TT>;
+    }
+}
+
+template <typename XT>
+long_fn pick_longrow(int tt, int mode, bool fma)
+{
+    switch (tt) {
+    case 1: return pick_longrow_mode<XT, 1>(mode, fma);
+    case 2: return pick_longrow_mode<XT, 2>(mode, fma);
+    case 4: return pick_longrow_mode<XT, 4>(mode, fma);
+    case 8: return pick_longrow_mode<XT, 8>(mode, fma);
+    default: return pick_longrow_mode<XT, 16>(mode, fma);
+    }
+}
+
+// family 9: one wave per (long row, TT flat columns).  tune[1] = TT (1, 2,
+// 4, 8, 16; 0: the largest that covers K and keeps the wave's LDS image
+// under 16 KB, so that ten or more waves share a CU)
+int run_longrow(const remap_apply_args *a, const Call &c, KParams p,
+                hipStream_t stream)
+{
+    if (a->A.max_row_nnz <= 0)
+        return fail(REMAP_ERR_ARG,
+                    "remap_apply_f64: the long-row kernel needs "
+                    "A.max_row_nnz");
+    // pitch = 2 (mod 32) doubles: columns start 16-byte aligned and the lanes
+    // of the sum phase, one column each, hit different LDS banks
+    const int64_t pitch = (a->A.max_row_nnz + 29) / 32 * 32 + 2;
+    const bool masked = a->mode == REMAP_MODE_MASKED;
+    auto arrays = [&](int t) {
+        return c.fma ? t + 1 : masked ? 2 * t : t;
+    };
+    int tt = a->tune[1];
+    if (tt != 1 && tt != 2 && tt != 4 && tt != 8 && tt != 16) {
+        tt = 16;
+        while (tt > 1 &&
+               (tt / 2 >= c.K || arrays(tt) * pitch * 8 > 16 * 1024))
+            tt >>= 1;
+    }
+    // (an asked-for width that does not fit gives way to one that does)
+    while (tt > 1 && arrays(tt) * pitch * 8 > (int64_t)kPatchLdsMax)
+        tt >>= 1;
+    const int64_t lds = arrays(tt) * pitch * 8;
+    if (lds > (int64_t)kPatchLdsMax)
+        return fail(REMAP_ERR_UNSUPPORTED,
+                    "remap_apply_f64: rows of %lld entries do not fit the "
+                    "long-row kernel's LDS image", (long long)a->A.max_row_nnz);
+    int64_t grid;
+    const int rc = shape_grid(p, c.n_rows, ceil_div(c.K, tt),
+                              a->tune[4] != 1, grid);
+    if (rc != REMAP_OK)
+        return rc;
+    const long_fn fn = c.f32 ? pick_longrow<float>(tt, a->mode, c.fma)
+                             : pick_longrow<double>(tt, a->mode, c.fma);
+    if (lds > 64 * 1024)
+        REMAP_HIP_CHECK(hipFuncSetAttribute(
+            reinterpret_cast<const void *>(fn),
+            hipFuncAttributeMaxDynamicSharedMemorySize,
+            static_cast<int>(lds)));
+    hipLaunchKernelGGL(fn, dim3(static_cast<uint32_t>(grid)), dim3(kWave),
+                       static_cast<uint32_t>(lds), stream, p, a->flags,
+                       static_cast<int32_t>(pitch));
+    REMAP_HIP_CHECK(hipGetLastError());
+    return REMAP_OK;
+}
+
 // family 3: a sub-group of 8 (4 for rows of at most 4 entries: bilinear
 // maps) lanes per row; tune[1] overrides the sub-group size
 int run_rowsub(const remap_apply_args *a, const Call &c, const KParams &p,
@@ -1127,6 +1213,8 @@ int apply(const remap_apply_args *a, hipStream_t stream)
         return run_patchcell(a, c, p, stream);
     case 8:
         return run_strip(a, c, p, stream);
+    case 9:
+        return run_longrow(a, c, p, stream);
     case 1:
     case 6:
         return run_rowwave(a, c, p, family, stream);

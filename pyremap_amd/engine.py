@@ -30,6 +30,11 @@ FLAG_FMA = 1
 FLAG_TUNE_HINT = 4
 FLAG_TREE = 8
 
+#: long rows apart (RemapPlan._split_long_rows): up to this many fields the
+#: long rows run one wave per (row, few columns) -- family 9 -- beyond it on
+#: the LDS-staged lanes-across-rows kernel (family 7)
+LONG_WAVE_FIELDS = 16
+
 DTYPE_F64 = 0
 DTYPE_F32 = 1
 
@@ -40,6 +45,7 @@ CSR_PAD = 8
 #: LDS a workgroup of the lanes-across-rows kernel may take (kPatchLdsMax)
 CELL_LDS_MAX = 160 * 1024
 _LONG_TT = None   # (experiments: fields per lane of the long-row launch)
+_LONG_WAVE_TT = None   # (tests: columns per wave of family 9, 0 = auto)
 
 #: every symbol ``include/remap_hip.h`` declares
 EXPORTS = (
@@ -1344,16 +1350,23 @@ def apply_strided(plan, X, Y, *, n_batch, k_inner, x_row_stride,
         # a few long rows hold a large share of the entries (pole caps of a
         # global bilinear map): two launches writing disjoint rows
         # (RemapPlan._split_long_rows)
-        for part, is_long in zip(plan._split, (False, True)):
-            apply_strided(part, X, Y, n_batch=n_batch, k_inner=k_inner,
-                          x_row_stride=x_row_stride,
-                          x_batch_stride=x_batch_stride,
-                          y_row_stride=y_row_stride,
-                          y_batch_stride=y_batch_stride, mode=mode,
-                          threshold=threshold, mask_out=mask_out, flags=flags,
-                          gate=gate, gate_value=gate_value,
-                          x_src_fold=x_src_fold,
-                          x_outer_stride=x_outer_stride, _long_rows=is_long)
+        kw = dict(n_batch=n_batch, k_inner=k_inner,
+                  x_row_stride=x_row_stride, x_batch_stride=x_batch_stride,
+                  y_row_stride=y_row_stride, y_batch_stride=y_batch_stride,
+                  mode=mode, threshold=threshold, mask_out=mask_out,
+                  flags=flags, gate=gate, gate_value=gate_value,
+                  x_src_fold=x_src_fold, x_outer_stride=x_outer_stride)
+        short, long = plan._split
+        # (Issuing the two launches on two streams joined by events -- they
+        # write disjoint rows -- was built and measured: replayed from a
+        # hipGraph the two branches still ran one after the other, K = 64
+        # 63.5 us against 60.2; issued from Python the four extra stream
+        # calls cost more than the overlap gave, 84 us against 61.  One
+        # stream it stays.)
+        for part, is_long in ((short, False), (long, True)):
+            if part is None:      # (tools/long_rows_probe.py: one part alone)
+                continue
+            apply_strided(part, X, Y, _long_rows=is_long, **kw)
         return
     # short contiguous runs in several batches -- (Time, nCells) -- go to the
     # LDS-staged lanes-across-rows kernel on its own patch plan
@@ -1377,13 +1390,20 @@ def apply_strided(plan, X, Y, *, n_batch, k_inner, x_row_stride,
         # 1.16 ms
         tune = [7, 8 if n_batch * k_inner >= 16 else 4]
         if _long_rows:
-            # a long row is ONE dependent chain: few fields per lane keep its
-            # steps short and the workgroups many (1 deg -> 0.5 deg with pole
-            # caps, us per apply with 1 / 2 / 4 fields per lane: K = 1 27 /
-            # 30 / 49, K = 12 47 / 50 / 70, K = 64 72 / 65 / 83, K = 512
-            # 423 / 352 / 320 -- every workgroup re-reads its patch's entries)
             K = n_batch * k_inner
-            tune = [7, _LONG_TT or (1 if K <= 8 else 2 if K <= 128 else 4)]
+            if K <= LONG_WAVE_FIELDS:
+                # few fields: one wave per (long row, a few columns) -- the
+                # row's loads run lanes-across-entries, only its sum is a
+                # chain (family 9, spmm_longrow.h).  1 deg -> 0.5 deg with
+                # pole caps, the long rows' launch: K = 1 15 -> 3 us
+                tune = [9, _LONG_WAVE_TT or 0]
+            else:
+                # many fields: the 256 rows of a patch share their source
+                # cells, staged once (family 7); a long row is ONE dependent
+                # chain: few fields per lane keep its steps short and the
+                # workgroups many (us per apply with 1 / 2 / 4 fields per
+                # lane: K = 64 72 / 65 / 83, K = 512 423 / 352 / 320)
+                tune = [7, _LONG_TT or (2 if K <= 128 else 4)]
         flags |= FLAG_TUNE_HINT
     args.row_begin = row_begin
     args.row_end = end

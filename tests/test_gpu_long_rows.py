@@ -118,6 +118,58 @@ def test_long_rows_apart_bitwise(dev, which):
                    'row slice')
 
 
+@pytest.mark.parametrize('tt', [1, 2, 4, 8, 16])
+def test_wave_per_long_row_every_width(dev, tt, monkeypatch):
+    """
+    Kernel family 9 (one wave per long row and `tt` columns: entries read
+    lanes-across-entries, summed in order from LDS) is what the long rows
+    take for up to 16 fields; here it is forced for EVERY field count and
+    layout, each column width: the oracle's bits.
+    """
+    from oracle import oracle
+    from pyremap_amd import engine
+    mm, n_a, n_b, dims = _ragged_long_map(seed=11)
+    plan = engine.RemapPlan.from_triplets(mm['row'], mm['col'], mm['S'],
+                                          mm['frac_b'], n_a, n_b, device=dev)
+    plan.auto_schedule(dims)
+    assert plan._split is not None
+    monkeypatch.setattr(engine, 'LONG_WAVE_FIELDS', 1 << 30)
+    monkeypatch.setattr(engine, '_LONG_WAVE_TT', tt)
+    rowptr, c, v = plan.to_host_csr()
+    csr = oracle.OracleCSR(rowptr, c, v, (n_b, n_a))
+    rng = np.random.default_rng(tt)
+    for shape, axes in (((n_a,), [0]), ((n_a, 5), [0]), ((n_a, 37), [0]),
+                        ((7, n_a), [1]), ((33, n_a), [1]),
+                        ((3, n_a, 6), [1])):
+        for dtype in (np.float64, np.float32):
+            x = rng.standard_normal(shape).astype(dtype)
+            holes = x.copy()
+            holes[(slice(None),) * axes[0] + (rng.random(n_a) < 0.2,)] = \
+                np.nan
+            for field, thr in ((x, None), (holes, 0.3), (holes, None)):
+                masked = thr is not None
+                arg = np.ma.masked_array(field, np.isnan(field)) if masked \
+                    else field
+                want = oracle.remap_numpy_array(csr, mm['frac_b'], dims, arg,
+                                                axes, thr)
+                got, mask = engine.remap_tensor(
+                    plan, dims, torch.from_numpy(field).to(dev), axes,
+                    engine.MODE_MASKED if masked else engine.MODE_FRACB,
+                    threshold=thr or 0.0, want_mask=True)
+                assert_bitwise(got.cpu().numpy(), np.ma.filled(want, np.nan),
+                               f'tt {tt} {shape} {dtype.__name__} thr {thr}')
+                assert np.array_equal(mask.cpu().numpy().astype(bool),
+                                      np.ma.getmaskarray(want))
+    # two source axes with another dim between them (x_src_fold)
+    lat, lon = 50, n_a // 50
+    x = rng.standard_normal((lat, 3, lon))
+    want = oracle.remap_numpy_array(csr, mm['frac_b'], dims, x, [0, 2], None)
+    got = engine.remap_tensor(plan, dims, torch.from_numpy(x).to(dev),
+                              [0, 2], engine.MODE_FRACB)
+    assert_bitwise(got.cpu().numpy(), np.ma.filled(want, np.nan),
+                   f'tt {tt} (lat, M, lon)')
+
+
 def test_pole_capped_map_through_the_remapper(dev, tmp_path):
     """build_map (ESMF's bilinear, pole caps and all) -> remap_numpy /
     ncremap: the Dataset path on a split plan, against the oracle; the
