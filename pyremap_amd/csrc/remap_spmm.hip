@@ -252,6 +252,30 @@ cell_fn pick_patchcell_tt(int tt, int mode, bool fma)
                       : pick_patchcell_mode<XT, 8, LAYOUT>(mode, fma);
 }
 
+template <typename XT, int TT>
+cell_fn pick_patchtime_mode(int mode, bool fma)
+{
+    switch (mode) {
+    case REMAP_MODE_RAW:
+        return fma ? spmm_patchtime<XT, REMAP_MODE_RAW, true, TT>
+                   : spmm_patchtime<XT, REMAP_MODE_RAW, false, TT>;
+    case REMAP_MODE_FRACB:
+        return fma ? spmm_patchtime<XT, REMAP_MODE_FRACB, true, TT>
+                   : spmm_patchtime<XT, REMAP_MODE_FRACB, false, TT>;
+    default:
+        return fma ? spmm_patchtime<XT, REMAP_MODE_MASKED, true, TT>
+                   : spmm_patchtime<XT, REMAP_MODE_MASKED, false, TT>;
+    }
+}
+
+template <typename XT>
+cell_fn pick_patchtime(int tt, int mode, bool fma)
+{
+    return tt == 2   ? pick_patchtime_mode<XT, 2>(mode, fma)
+           : tt == 4 ? pick_patchtime_mode<XT, 4>(mode, fma)
+                     : pick_patchtime_mode<XT, 8>(mode, fma);
+}
+
 template <typename XT>
 cell_fn pick_patchcell(int tt, int mode, bool fma, int layout)
 {
@@ -927,17 +951,60 @@ int run_patchcell(const remap_apply_args *a, const Call &c, KParams p,
     }
     while (tt > 4 && (int64_t)upitch * tt * 8 > (int64_t)kPatchLdsMax)
         tt >>= 1;
+    // Row-major plans whose patches fit one lane per row and two cells per
+    // lane: the workgroup stays on its patch over a run of chunks
+    // (spmm_patchtime; tune[2] = 1 keeps the one-chunk kernel).  Runs are
+    // sized so that ~2 000 workgroups exist: (120, nCells) on 1 020 patches:
+    // 2 runs of 8 chunks.
+    if (!long_rows && a->tune[1] == 2)
+        tt = 2;     // (the persistent kernel only)
+    const bool persistent =
+        !long_rows && a->tune[2] != 1 && a->A.nnz > 0 &&
+        (tt == 2 || tt == 4 || tt == 8 || tt == 16) &&
+        a->patch_rows <= kCellBlock && upitch <= 2 * kCellBlock;
+    if (!persistent && tt == 2)
+        tt = 4;
+    if (persistent && tt == 16)
+        tt = 8;
+    const int64_t n_chunks = ceil_div(c.K, tt);
+    int64_t groups = 1, cpw = 1;
+    if (persistent) {
+        // runs of chunks per patch: enough workgroups to fill the chip
+        // (~1 000), beyond that a run of a dozen chunks or more -- config
+        // 3's 1 020 patches, TT = 4, cold: (12, nCells) 1 / 3 runs 16.4 /
+        // 18.8 us; (120, nCells) 1 / 2 / 4 runs 0.146 / 0.141 / 0.144 ms
+        int64_t g_amort = n_chunks / 12;
+        const int64_t g_most = ceil_div(2048, a->n_patches);
+        if (g_amort > g_most)
+            g_amort = g_most;
+        groups = ceil_div(960, a->n_patches);
+        if (groups < g_amort)
+            groups = g_amort;
+        if (a->tune[3] > 0)
+            groups = a->tune[3];
+        if (groups > n_chunks)
+            groups = n_chunks;
+        cpw = ceil_div(n_chunks, groups);
+        groups = ceil_div(n_chunks, cpw);
+        p.rows_per_wave = static_cast<int32_t>(cpw);
+    }
     int64_t grid;
-    const int rc = shape_grid(p, a->n_patches, ceil_div(c.K, tt),
+    const int rc = shape_grid(p, a->n_patches,
+                              persistent ? groups : n_chunks,
                               a->tune[4] != 1, grid);
     if (rc != REMAP_OK)
         return rc;
-    uint32_t lds_bytes = static_cast<uint32_t>(upitch) * tt * 8u;
+    uint32_t lds_bytes =
+        static_cast<uint32_t>(upitch) * tt * 8u * (persistent ? 2u : 1u);
     if (lds_bytes < 1024)
         lds_bytes = 1024;
     const int layout = a->patch_ell_base ? 1 : 0;
-    cell_fn fn = c.f32 ? pick_patchcell<float>(tt, a->mode, c.fma, layout)
-                       : pick_patchcell<double>(tt, a->mode, c.fma, layout);
+    cell_fn fn =
+        persistent
+            ? (c.f32 ? pick_patchtime<float>(tt, a->mode, c.fma)
+                     : pick_patchtime<double>(tt, a->mode, c.fma))
+            : (c.f32 ? pick_patchcell<float>(tt, a->mode, c.fma, layout)
+                     : pick_patchcell<double>(tt, a->mode, c.fma, layout));
     if (lds_bytes > 64 * 1024)
         REMAP_HIP_CHECK(hipFuncSetAttribute(
             reinterpret_cast<const void *>(fn),

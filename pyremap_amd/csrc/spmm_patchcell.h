@@ -169,3 +169,169 @@ __global__ __launch_bounds__(kCellBlock) void spmm_patchcell(
         }
     }
 }
+
+// ---------------------------------------------------------------------------
+// patchtime: the same decomposition with the workgroup PERSISTENT over a run
+// of K chunks (time slices).  In spmm_patchcell every (patch, chunk)
+// workgroup starts from nothing: three dependent trips for the patch's cell
+// list, a trip per ENTRY for its (index, weight) pairs inside the compute
+// loop, the gather, a barrier, the sums -- 13.7 us of life per workgroup for
+// ~1 us of work (rocprofv3 on (Time = 120, nCells): 65 % of the wave cycles
+// waiting, the 14 MB patch plan re-read by every one of the 15 chunks: 200 MB
+// of the 509 MB the fabric moves for 226 MB of X).  Here a workgroup reads
+// its patch's metadata ONCE -- cell bases and the first 8 entries of every
+// row stay in registers -- and walks its chunks with two LDS images: the X
+// values of chunk c + 1 are in flight (registers) while chunk c is summed
+// from LDS and stored.  One barrier per chunk, which does not drain the Y
+// stores.  Same sums, same order, same bits.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void lds_barrier()
+{
+    // (not __syncthreads(): that also waits for the Y stores in flight)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <typename XT, int MODE, bool FMA, int TT>
+__global__ __launch_bounds__(kCellBlock) void spmm_patchtime(
+    const KParams p, const uint32_t flags,
+    const int32_t *__restrict__ prow, const double *__restrict__ pval,
+    const int32_t *__restrict__ plidx, const int32_t *__restrict__ pptr,
+    const int32_t *__restrict__ ucol, const int32_t *__restrict__ row_order,
+    const double *__restrict__ frac_b, const int32_t patch_rows,
+    const int32_t upitch, const int64_t n_patches,
+    const int64_t *__restrict__ ell_base)
+{
+    constexpr int NC = 2;      // cells per lane: patches hold <= 512 cells
+    constexpr int NE = 8;      // entries of a row kept in registers
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    double *xs = reinterpret_cast<double *>(lds);   // [2][TT][upitch]
+    const int tid = threadIdx.x;
+    const int64_t L = logical_block(p);
+    if (L >= p.n_blocks)
+        return;
+    (void)flags;
+    (void)ell_base;
+    const int64_t group = L / n_patches;   // runs of chunks: the slow index
+    const int64_t patch = L - group * n_patches;
+    const int cpw = p.rows_per_wave;       // chunks per workgroup
+    const uint32_t n_chunks = (p.K + TT - 1) / TT;
+    const uint32_t c0 = static_cast<uint32_t>(group) * cpw;
+    const uint32_t c1 = c0 + cpw < n_chunks ? c0 + cpw : n_chunks;
+    const XT *__restrict__ X = static_cast<const XT *>(p.X);
+
+    // ---- once per workgroup: the patch's cells, this lane's row
+    const int u0 = pptr[patch];
+    const int U = pptr[patch + 1] - u0;
+    int64_t cb[NC];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+        // (idle lanes name the patch's first cell -- a patch without cells
+        // the plan's first: no load sits behind a branch, none leaves the
+        // arrays)
+        const int j = tid + q * kCellBlock;
+        cb[q] = cell_base(p, ucol[U > 0 ? u0 + (j < U ? j : 0) : 0]);
+    }
+    const int64_t slot0 = p.row_begin + patch * patch_rows;
+    const int64_t local0 = patch * patch_rows;  // index into prow
+    int nrows = patch_rows;
+    if (slot0 + nrows > p.row_end)
+        nrows = static_cast<int>(p.row_end - slot0);
+    const bool has_row = tid < nrows;
+    const int rr = has_row ? tid : 0;
+    const int64_t i = row_order ? (int64_t)row_order[slot0 + rr] : slot0 + rr;
+    const int s = prow[local0 + rr];
+    const int e = has_row ? prow[local0 + rr + 1] : s;
+    int32_t li[NE];
+    double a[NE];
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+        // clamped to an entry that exists: no load sits behind a branch
+        const int jj = s + u < e ? s + u : (s < e ? s : 0);
+        li[u] = plidx[jj];
+        a[u] = pval[jj];
+    }
+    double fb = 0.0;
+    if constexpr (MODE == REMAP_MODE_FRACB)
+        fb = frac_b[i];
+
+    XT v[NC][TT];
+    auto load = [&](uint32_t c) {
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            const uint32_t kf = c * TT + t;
+            const bool in = kf < p.K;
+            const uint32_t b = in ? kf / p.k_inner : 0u;
+            const uint32_t k = in ? kf - b * p.k_inner : 0u;
+            const int64_t xo = static_cast<int64_t>(b) * p.bsx + k;
+#pragma unroll
+            for (int q = 0; q < NC; ++q)
+                v[q][t] = X[cb[q] + xo];
+        }
+    };
+    if (c0 < c1)
+        load(c0);
+    for (uint32_t c = c0; c < c1; ++c) {
+        double *img = xs + ((c - c0) & 1) * (TT * upitch);
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {
+            const int j = tid + q * kCellBlock;
+            if (j < U) {
+#pragma unroll
+                for (int t = 0; t < TT; ++t)
+                    img[t * upitch + j] = static_cast<double>(v[q][t]);
+            }
+        }
+        lds_barrier();
+        if (c + 1 < c1)
+            load(c + 1);     // in flight while this chunk is summed
+        if (!has_row)
+            continue;
+        double acc[TT], den[TT];
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            acc[t] = 0.0;
+            den[t] = 0.0;
+        }
+        auto add_entry = [&](const int32_t l, const double w) {
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+                const double x = img[t * upitch + l];
+                if constexpr (MODE == REMAP_MODE_MASKED) {
+                    const bool valid = (x == x);
+                    acc[t] = mul_add<FMA>(w, valid ? x : 0.0, acc[t]);
+                    den[t] = den_add(w, valid ? 1.0 : 0.0, den[t]);
+                } else {
+                    acc[t] = mul_add<FMA>(w, x, acc[t]);
+                }
+            }
+        };
+#pragma unroll
+        for (int u = 0; u < NE; ++u)
+            if (s + u < e)
+                add_entry(li[u], a[u]);
+        for (int jj = s + NE; jj < e; ++jj)      // (rows of more than 8)
+            add_entry(plidx[jj], pval[jj]);
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            const uint32_t kf = c * TT + t;
+            if (kf >= p.K)
+                continue;
+            const uint32_t b = kf / p.k_inner;
+            const uint32_t k = kf - b * p.k_inner;
+            bool ok = true;
+            double y = acc[t];
+            if constexpr (MODE == REMAP_MODE_FRACB) {
+                ok = fb > 0.0;
+                y = !ok ? __builtin_nan("")
+                    : (fb == 1.0) ? acc[t] : acc[t] / fb;
+            } else if constexpr (MODE == REMAP_MODE_MASKED) {
+                ok = den[t] > p.thr;
+                y = ok ? acc[t] / den[t] : __builtin_nan("");
+            }
+            const int64_t o = i * p.ldy + static_cast<int64_t>(b) * p.bsy + k;
+            __builtin_nontemporal_store(y, p.Y + o);
+            if (p.mask_out)
+                p.mask_out[o] = ok ? 0 : 1;
+        }
+    }
+}

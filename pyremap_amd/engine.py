@@ -46,6 +46,7 @@ CSR_PAD = 8
 CELL_LDS_MAX = 160 * 1024
 _LONG_TT = None   # (experiments: fields per lane of the long-row launch)
 _LONG_WAVE_TT = None   # (tests: columns per wave of family 9, 0 = auto)
+_CELL_TUNE = None      # (tools/tn_probe.py: [TT, one-chunk kernel?] of family 7)
 
 #: every symbol ``include/remap_hip.h`` declares
 EXPORTS = (
@@ -1385,10 +1386,13 @@ def apply_strided(plan, X, Y, *, n_batch, k_inner, x_row_stride,
         tune = [5]
         flags |= FLAG_TUNE_HINT
     elif cell:
-        # fields per lane: 8 (4 for a handful of fields: more workgroups);
-        # (12, nCells): 22.1 / 22.4 us with 4 / 8, (60, 3.7 M cells): 1.36 /
-        # 1.16 ms
-        tune = [7, 8 if n_batch * k_inner >= 16 else 4]
+        # 4 fields per lane and LDS image: the workgroup stays on its patch
+        # over a run of chunks (spmm_patchtime), two images in LDS -- config
+        # 3's map, Infinity-Cache-cold, 4 / 8 fields: (120, nCells) 0.141 /
+        # 0.146 ms, (12, nCells) 16.4 / 24 us; (60, 3.7 M cells) 1.13 / 1.20
+        tune = [7, 4]
+        if _CELL_TUNE:
+            tune = [7] + list(_CELL_TUNE)
         if _long_rows:
             K = n_batch * k_inner
             if K <= LONG_WAVE_FIELDS:
