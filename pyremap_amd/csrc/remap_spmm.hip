@@ -802,7 +802,7 @@ int run_rowgroup(const remap_apply_args *a, const Call &c, KParams p,
         tiles = c.K > 64 ? 2 : 1;
     int gpw = a->tune[3] > 0 ? a->tune[3] : 2;   // groups per wave
     // union entries in flight
-    const int unr = (a->tune[5] == 4 || a->tune[5] == 16) ? a->tune[5] : 8;
+    int unr = (a->tune[5] == 4 || a->tune[5] == 16) ? a->tune[5] : 8;
     // waves per workgroup (tune[1], unused otherwise by this family)
     int wpb = (a->tune[1] == 1 || a->tune[1] == 2) ? a->tune[1]
                                                    : kWavesPerBlock;
@@ -826,10 +826,19 @@ int run_rowgroup(const remap_apply_args *a, const Call &c, KParams p,
         gpw = 1;
     }
     p.rows_per_wave = gpw;
+    const int64_t k_chunks = shape_tiles(p, a, c.K, kWave * vec, tiles);
+    // several SHORT batches per tile -- (Time, nCells, 60 levels): two
+    // 480-byte runs per source row, neither a whole number of cache lines:
+    // sixteen union entries in flight instead of eight (config 3's map,
+    // (8, nCells, 60), two boxes: 0.447 -> 0.426 ms, 0.412 -> 0.393; 100 or
+    // 61 levels, one batch per tile: slower or no change)
+    if (a->tune[5] == 0 && p.bpc >= 2 && p.bpc != kBatchPerChunk && !lock &&
+        a->group_rows == 4)
+        unr = 16;
     int64_t grid;
     const int rc = shape_grid(
-        p, ceil_div(a->n_groups, (int64_t)wpb * gpw),
-        shape_tiles(p, a, c.K, kWave * vec, tiles), a->tune[4] != 1, grid);
+        p, ceil_div(a->n_groups, (int64_t)wpb * gpw), k_chunks,
+        a->tune[4] != 1, grid);
     if (rc != REMAP_OK)
         return rc;
     return c.f32 ? launch_rowgroup<float>(a, p, tiles, unr, vec, wpb, c.fma,

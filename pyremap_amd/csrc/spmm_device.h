@@ -122,6 +122,17 @@ __device__ __forceinline__ double elem(const V &v, int e)
 template <int VEC>
 __device__ __forceinline__ void store_y(double *p, const double (&y)[VEC])
 {
+#ifdef REMAP_PLAIN_STORES   // (tools/build_diag.py plain: an A/B, never shipped)
+    if constexpr (VEC == 1) {
+        *p = y[0];
+    } else {
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        d2 v;
+        v[0] = y[0];
+        v[1] = y[1];
+        *reinterpret_cast<d2 *>(p) = v;
+    }
+#else
     if constexpr (VEC == 1) {
         __builtin_nontemporal_store(y[0], p);
     } else {
@@ -131,6 +142,7 @@ __device__ __forceinline__ void store_y(double *p, const double (&y)[VEC])
         v[1] = y[1];
         __builtin_nontemporal_store(v, reinterpret_cast<d2 *>(p));
     }
+#endif
 }
 
 // ---------------------------------------------------------------------------

@@ -7,6 +7,8 @@ Build the DIAGNOSTIC variants of libremap_hip.so (never the product):
                                         (LDS occupancy throttle) switches
     python tools/build_diag.py stamps   -DREMAP_STAMPS  in-kernel s_memtime
                                         stamps (tools/stamps.py)
+    python tools/build_diag.py plain    -DREMAP_PLAIN_STORES  write-back instead of
+                                        non-temporal Y stores (an A/B)
     python tools/build_diag.py ceiling  tools/hbm_ceiling.hip -> executable
 
 Outputs go to tools/_build/ (git-ignored; they still travel to the GPU box).
@@ -39,7 +41,8 @@ def main():
                  '-o', os.path.join(OUT, 'hbm_ceiling'),
                  os.path.join(ROOT, 'tools', 'hbm_ceiling.hip')])
             continue
-        define = {'diag': '-DREMAP_DIAG', 'stamps': '-DREMAP_STAMPS'}[w]
+        define = {'diag': '-DREMAP_DIAG', 'stamps': '-DREMAP_STAMPS',
+                  'plain': '-DREMAP_PLAIN_STORES'}[w]
         run([hipcc, '-O3', '-std=c++17', f'--offload-arch={_build.ARCH}',
              '-ffp-contract=off', '-fPIC', '-shared', define,
              f'-I{_build.INCLUDE}', f'-I{_build.CSRC}', '-o',
