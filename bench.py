@@ -200,7 +200,8 @@ def barrier(dist):
 def time_steps(launch, steps, warmup, dist):
     """
     warmup untimed, then EXACTLY `steps` timed between barrier + synchronize.
-    Returns (wall_s, mean_ms, [per-launch ms]).
+    Returns (wall_s, mean_ms, [per-launch ms], shader clock in MHz right
+    behind the timed region).
 
     ``mean_ms`` is the average launch duration over the timed region: ONE pair
     of HIP events on the launch stream (torch's current stream is the stream
@@ -224,6 +225,10 @@ def time_steps(launch, steps, warmup, dist):
         if marks:
             marks[i].record()     # diagnosis only: where the region's time is
     last.record()
+    # which clock state the region ran in: one wave spinning 20 us right
+    # behind it (outside the event pair and the wall time's launches)
+    from pyremap_amd import engine
+    mhz = engine.clock_probe(torch.cuda.current_device())
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     if marks:
@@ -247,7 +252,7 @@ def time_steps(launch, steps, warmup, dist):
         events[i][1].record()
     torch.cuda.synchronize()
     per_launch = [a.elapsed_time(b) for a, b in events]
-    return wall, mean_ms, per_launch
+    return wall, mean_ms, per_launch, mhz()
 
 
 def graph_replay_ms(launch, calls=48, reps=5):
@@ -531,7 +536,8 @@ def measure(w, args, dist, steps=None, warmup=None):
     """W warm-up + K timed steps of a prepared workload."""
     steps = steps or args.steps
     warmup = args.warmup if warmup is None else warmup
-    wall, mean_ms, per_launch = time_steps(w.launch, steps, warmup, dist)
+    wall, mean_ms, per_launch, mhz = time_steps(w.launch, steps, warmup,
+                                                dist)
     in_order = [round(t, 4) for t in per_launch[:20]]
     per_launch.sort()
     m, plan = w.m, w.plan
@@ -545,7 +551,7 @@ def measure(w, args, dist, steps=None, warmup=None):
         layout=w.layout, locality=w.locality, steps=steps, warmup=warmup,
         wall_s=wall,
         ms_per_step=wall * 1e3 / steps,
-        kernel_ms_mean=mean_ms,
+        kernel_ms_mean=mean_ms, clock_mhz=mhz,
         kernel_ms_graph_replay=None,    # (replay_short_extras)
         kernel_ms_median=per_launch[len(per_launch) // 2],
         kernel_ms_min=per_launch[0], kernel_ms_max=per_launch[-1],
@@ -731,7 +737,7 @@ def load_traffic(name, K, mode, locality='mesh'):
 
 EXTRA_KEYS = ('title', 'n_a', 'n_b', 'nnz_csr', 'K', 'mode', 'layout',
               'locality', 'schedule', 'touched_frac', 'ms_per_step',
-              'kernel_ms_mean', 'kernel_ms_graph_replay', 'kernel_ms_median',
+              'kernel_ms_mean', 'clock_mhz', 'kernel_ms_graph_replay', 'kernel_ms_median',
               'cell_fields_per_s',
               'bytes_alg', 'achieved_GBps')
 
@@ -921,9 +927,10 @@ def kernel_of(e):
 
 def workload_rows(extra):
     """
-    `roofline.workloads`: `tag: [ms per launch, fraction of 8 TB/s]` per other
-    workload (launches shorter than the host's ~12 us per call: as replayed
-    from a hipGraph when that was measured).  Everything else about a
+    `roofline.workloads`: `tag: [ms per launch, fraction of 8 TB/s, shader
+    clock in MHz behind the timed launches]` per other workload (launches
+    shorter than the host's ~12 us per call: as replayed from a hipGraph when
+    that was measured).  Everything else about a
     workload is in the side file.
     """
     rows = {}
@@ -937,6 +944,8 @@ def workload_rows(extra):
         ms = e.get('kernel_ms_graph_replay') or e['kernel_ms_mean']
         rows[tag] = [round(ms, 5), round(
             e['bytes_alg'] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)]
+        if e.get('clock_mhz'):
+            rows[tag].append(int(round(e['clock_mhz'])))
     return rows
 
 
@@ -1058,6 +1067,7 @@ def compose_line(args, res, world, ceiling, cpu, extra, pipelined,
             'traffic_source': traffic_src and traffic_src[:80],
             'kernel': family + ' (remap_apply_f64)',
             'kernel_ms_mean': rnd(kernel_ms),
+            'clock_mhz': rnd(res.get('clock_mhz'), 4),
             'kernel_ms_median': rnd(res['kernel_ms_median']),
             'kernel_ms_steady_100_more': rnd(
                 res.get('kernel_ms_steady_100_more')),

@@ -627,6 +627,18 @@ int remap_gather_rows(const void *src, int64_t n_batch,
  */
 int remap_stream_copy(void *dst, const void *src, size_t bytes, void *stream);
 
+/*
+ * The shader clock the chip holds right now (asynchronous on `stream`): one
+ * wave spins for `micros` microseconds (1 ... 1000) and writes the shader
+ * cycles (s_memtime) and the constant-rate 100 MHz ticks (s_memrealtime) it
+ * saw go by to ticks_out[0] / ticks_out[1] (device, 2 x int64): MHz = 100 *
+ * ticks_out[0] / ticks_out[1].  Queued right behind a series of launches it
+ * tells which clock state their times belong to (an instruction-issue-bound
+ * kernel such as the LDS patch kernel runs 5.2 or 6.4 ms per launch on
+ * config 4 depending on it).  Measurement only.
+ */
+int remap_clock_probe(int64_t *ticks_out, int32_t micros, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1395,6 +1395,37 @@ int scan_nan(const void *x, int32_t dtype, int64_t n, int32_t *flag,
     return REMAP_OK;
 }
 
+// one wave: shader cycles and 100 MHz ticks across a spin of `ticks` ticks
+__global__ __launch_bounds__(kWave) void clock_probe_kernel(
+    long long *__restrict__ out, long long ticks)
+{
+    const long long r0 = __builtin_amdgcn_s_memrealtime();
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    long long r1 = r0;
+    while (r1 - r0 < ticks) {
+        __builtin_amdgcn_s_sleep(4);
+        r1 = __builtin_amdgcn_s_memrealtime();
+    }
+    const long long t1 = __builtin_amdgcn_s_memtime();
+    r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) {
+        out[0] = t1 - t0;
+        out[1] = r1 - r0;
+    }
+}
+
+int clock_probe(int64_t *ticks_out, int32_t micros, hipStream_t stream)
+{
+    if (!ticks_out || micros < 1 || micros > 1000)
+        return fail(REMAP_ERR_ARG,
+                    "remap_clock_probe: needs an output and 1 ... 1000 us");
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(kWave), 0, stream,
+                       reinterpret_cast<long long *>(ticks_out),
+                       static_cast<long long>(micros) * 100);
+    REMAP_HIP_CHECK(hipGetLastError());
+    return REMAP_OK;
+}
+
 int stream_copy(void *dst, const void *src, size_t bytes, hipStream_t stream)
 {
     if (bytes == 0)
@@ -1452,6 +1483,12 @@ int remap_scan_nan(const void *x, int32_t x_dtype, int64_t n, int32_t *flag,
 int remap_stream_copy(void *dst, const void *src, size_t bytes, void *stream)
 {
     return remap::stream_copy(dst, src, bytes,
+                              static_cast<hipStream_t>(stream));
+}
+
+int remap_clock_probe(int64_t *ticks_out, int32_t micros, void *stream)
+{
+    return remap::clock_probe(ticks_out, micros,
                               static_cast<hipStream_t>(stream));
 }
 

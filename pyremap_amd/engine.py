@@ -59,6 +59,7 @@ EXPORTS = (
     'remap_plan_create', 'remap_plan_destroy', 'remap_plan_query',
     'remap_plan_apply', 'remap_pack_columns_workspace', 'remap_pack_columns',
     'remap_gather_rows', 'remap_plan_prepare_short_runs',
+    'remap_clock_probe',
 )
 
 
@@ -327,6 +328,9 @@ def load_library():
     lib.remap_stream_copy.restype = ctypes.c_int
     lib.remap_stream_copy.argtypes = [ctypes.c_void_p, ctypes.c_void_p,
                                       ctypes.c_size_t, ctypes.c_void_p]
+    lib.remap_clock_probe.restype = ctypes.c_int
+    lib.remap_clock_probe.argtypes = [ctypes.c_void_p, ctypes.c_int32,
+                                      ctypes.c_void_p]
     if lib.remap_abi_version() != ABI_VERSION:
         raise EngineError(
             f'{path} has ABI {lib.remap_abi_version()}, expected '
@@ -1710,6 +1714,28 @@ def gather_rows(field, axis, rows, out=None):
             inner * item, _ptr(rows), int(rows.shape[0]), inner * item,
             _ptr(out), _stream_ptr(field.device)), 'remap_gather_rows')
     return out
+
+
+def clock_probe(device, micros=20):
+    """
+    Enqueue a shader-clock measurement on torch's current stream of
+    ``device`` (``remap_clock_probe``: one wave spinning for ``micros`` us).
+    Returns a function that, once the stream has been synchronised, gives
+    the clock in MHz the chip held at that point of the stream.
+    """
+    torch = _torch()
+    lib = load_library()
+    device = torch.device(device)
+    ticks = torch.zeros(2, dtype=torch.int64, device=device)
+    with torch.cuda.device(device):
+        _check(lib.remap_clock_probe(_ptr(ticks), int(micros),
+                                     _stream_ptr(device)),
+               'remap_clock_probe')
+
+    def mhz():
+        t, r = (int(v) for v in ticks.cpu())
+        return 100.0 * t / r if r else float('nan')
+    return mhz
 
 
 def stream_copy(dst, src):

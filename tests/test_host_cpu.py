@@ -824,7 +824,8 @@ def _fake_bench_result(bench, world):
         n_a=235160, n_b=259200, n_s_file=912860, nnz_csr=867235, K=512,
         mode='fracb', layout='nk', locality='mesh', steps=20, warmup=5,
         wall_s=0.00756218716502189, ms_per_step=0.37810935825109464,
-        kernel_ms_mean=0.3776483833789825, kernel_ms_graph_replay=None,
+        kernel_ms_mean=0.3776483833789825, clock_mhz=2104.567,
+        kernel_ms_graph_replay=None,
         kernel_ms_median=0.37540000677108765,
         kernel_ms_min=0.3701600134372711, kernel_ms_max=0.3951199948787689,
         kernel_ms_second_pass_in_order=[0.37540000677108765] * 20,
@@ -862,6 +863,7 @@ def _fake_bench_result(bench, world):
             mode=kw.get('mode', 'fracb'), layout=kw.get('layout', 'nk'),
             locality='mesh', schedule=schedule, touched_frac=1.0,
             ms_per_step=22.123456789012345, kernel_ms_mean=22.12345678901234,
+            clock_mhz=1751.234,
             kernel_ms_graph_replay=0.0072123456789,
             kernel_ms_median=22.123456789, cell_fields_per_s=3.0123456789e11,
             bytes_alg=84380123456, achieved_GBps=3812.123456789, steps=steps,
@@ -923,8 +925,8 @@ def test_bench_line_stays_under_4_kb(world):
     todo = [t[0] for t in bench.extras_todo(args, 1)]
     assert set(todo) <= set(roof['workloads'])
     for tag in todo:
-        ms, frac = roof['workloads'][tag]
-        assert ms > 0 and frac > 0
+        ms, frac, mhz = roof['workloads'][tag]
+        assert ms > 0 and frac > 0 and mhz == 1751
     assert set(bench.DEFAULT_ROWS) <= set(todo)
     if world == 1:
         cb = back['cpu_baseline']
