@@ -35,10 +35,9 @@ def main():
     ap.add_argument('--workload', default='config5')
     ap.add_argument('--fields', type=int, default=None)
     ap.add_argument('--shapes', nargs='*',
-                    default=['8,1,4,2,8', '8,1,4,4,8', '8,1,4,6,8', '8,2,4,3,8',
-                             '8,2,4,4,8', '8,2,4,6,8', '14,1,4,4,12',
-                             '14,1,4,6,10', '12,2,4,4,12', '16,1,4,6,8',
-                             '4,2,4,4,8', '4,2,4,6,8'],
+                    default=['8,1,4,2,8', '8,1,4,3,8', '8,2,4,2,8', '8,2,4,3,8',
+                             '14,1,4,2,14', '16,1,4,2,8', '16,1,4,2,14',
+                             '6,1,4,2,6', '12,1,4,2,12'],
                     help='strip_rows,step_cols,segments,depth,waves[,gap]')
     ap.add_argument('--masked', action='store_true')
     ap.add_argument('--check', action='store_true')
