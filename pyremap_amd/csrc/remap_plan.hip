@@ -827,7 +827,8 @@ int remap_plan_apply(const remap_plan *plan, const remap_field *f,
         a.patch_row_bytes = 1024;
         a.n_patches = plan->cell_patches;
         a.tune[0] = 7;
-        a.tune[1] = f->n_batch * f->k_inner >= 16 ? 8 : 4;
+        a.tune[1] = 4;   // (workgroup persistent over a run of chunks:
+                         // spmm_patchtime; engine.apply_strided)
         a.flags |= REMAP_FLAG_TUNE_HINT;
     } else if (s.family != 0) {
         a.row_order = s.row_order;
