@@ -21,6 +21,8 @@ def main():
     ap.add_argument('--times', default='12,120')
     ap.add_argument('--reps', type=int, default=30)
     ap.add_argument('--dtype', default='f64')
+    ap.add_argument('--only', default='',
+                    help='run only the variants whose tag contains this')
     args = ap.parse_args()
     import torch
 
@@ -49,6 +51,8 @@ def main():
                           ('persistent, TT 2, 1 run', [2, 0, 1]),
                           ('persistent, TT 2, 2 runs', [2, 0, 2]),
                           ('default', None)):
+            if args.only and args.only not in tag:
+                continue
             engine._CELL_TUNE = tune
             for sets, label in ((3, 'cold'), (1, 'warm')):
                 def run(i):
