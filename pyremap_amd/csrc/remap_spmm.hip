@@ -252,28 +252,36 @@ cell_fn pick_patchcell_tt(int tt, int mode, bool fma)
                       : pick_patchcell_mode<XT, 8, LAYOUT>(mode, fma);
 }
 
-template <typename XT, int TT>
+template <typename XT, int TT, int BLOCK>
 cell_fn pick_patchtime_mode(int mode, bool fma)
 {
     switch (mode) {
     case REMAP_MODE_RAW:
-        return fma ? spmm_patchtime<XT, REMAP_MODE_RAW, true, TT>
-                   : spmm_patchtime<XT, REMAP_MODE_RAW, false, TT>;
+        return fma ? spmm_patchtime<XT, REMAP_MODE_RAW, true, TT, BLOCK>
+                   : spmm_patchtime<XT, REMAP_MODE_RAW, false, TT, BLOCK>;
     case REMAP_MODE_FRACB:
-        return fma ? spmm_patchtime<XT, REMAP_MODE_FRACB, true, TT>
-                   : spmm_patchtime<XT, REMAP_MODE_FRACB, false, TT>;
+        return fma ? spmm_patchtime<XT, REMAP_MODE_FRACB, true, TT, BLOCK>
+                   : spmm_patchtime<XT, REMAP_MODE_FRACB, false, TT, BLOCK>;
     default:
-        return fma ? spmm_patchtime<XT, REMAP_MODE_MASKED, true, TT>
-                   : spmm_patchtime<XT, REMAP_MODE_MASKED, false, TT>;
+        return fma ? spmm_patchtime<XT, REMAP_MODE_MASKED, true, TT, BLOCK>
+                   : spmm_patchtime<XT, REMAP_MODE_MASKED, false, TT, BLOCK>;
     }
 }
 
-template <typename XT>
-cell_fn pick_patchtime(int tt, int mode, bool fma)
+template <typename XT, int BLOCK>
+cell_fn pick_patchtime_tt(int tt, int mode, bool fma)
 {
-    return tt == 2   ? pick_patchtime_mode<XT, 2>(mode, fma)
-           : tt == 4 ? pick_patchtime_mode<XT, 4>(mode, fma)
-                     : pick_patchtime_mode<XT, 8>(mode, fma);
+    return tt == 2   ? pick_patchtime_mode<XT, 2, BLOCK>(mode, fma)
+           : tt == 4 ? pick_patchtime_mode<XT, 4, BLOCK>(mode, fma)
+                     : pick_patchtime_mode<XT, 8, BLOCK>(mode, fma);
+}
+
+template <typename XT>
+cell_fn pick_patchtime(int tt, int mode, bool fma, int block)
+{
+    return block == 256   ? pick_patchtime_tt<XT, 256>(tt, mode, fma)
+           : block == 512 ? pick_patchtime_tt<XT, 512>(tt, mode, fma)
+                          : pick_patchtime_tt<XT, 1024>(tt, mode, fma);
 }
 
 template <typename XT>
@@ -967,28 +975,43 @@ int run_patchcell(const remap_apply_args *a, const Call &c, KParams p,
     // 2 runs of 8 chunks.
     if (!long_rows && a->tune[1] == 2)
         tt = 2;     // (the persistent kernel only)
+    // one lane per row and at most two cells per lane: 256 threads for the
+    // 16 x 16 patches, 512 / 1024 for larger ones
+    int64_t lanes = a->patch_rows > (upitch + 1) / 2 ? a->patch_rows
+                                                      : (upitch + 1) / 2;
+    const int block = lanes <= 256 ? 256 : lanes <= 512 ? 512 : 1024;
     const bool persistent =
         !long_rows && a->tune[2] != 1 && a->A.nnz > 0 &&
-        (tt == 2 || tt == 4 || tt == 8 || tt == 16) &&
-        a->patch_rows <= kCellBlock && upitch <= 2 * kCellBlock;
+        (tt == 2 || tt == 4 || tt == 8 || tt == 16) && lanes <= 1024 &&
+        (int64_t)upitch * 2 * 16 <= (int64_t)kPatchLdsMax;
     if (!persistent && tt == 2)
         tt = 4;
     if (persistent && tt == 16)
         tt = 8;
+    // (two LDS images: fewer fields per lane until they fit)
+    while (persistent && tt > 2 &&
+           (int64_t)upitch * tt * 16 > (int64_t)kPatchLdsMax)
+        tt >>= 1;
     const int64_t n_chunks = ceil_div(c.K, tt);
     int64_t groups = 1, cpw = 1;
     if (persistent) {
-        // runs of chunks per patch: enough workgroups to fill the chip
-        // (~1 000), beyond that a run of a dozen chunks or more -- config
-        // 3's 1 020 patches, TT = 4, cold: (12, nCells) 1 / 3 runs 16.4 /
-        // 18.8 us; (120, nCells) 1 / 2 / 4 runs 0.146 / 0.141 / 0.144 ms
-        int64_t g_amort = n_chunks / 12;
-        const int64_t g_most = ceil_div(2048, a->n_patches);
-        if (g_amort > g_most)
-            g_amort = g_most;
-        groups = ceil_div(960, a->n_patches);
-        if (groups < g_amort)
-            groups = g_amort;
+        // Runs of chunks per patch: ONE round of workgroups on the chip --
+        // as many as fit at a time (threads, LDS) -- each walking all its
+        // chunks.  Config 3's map, (120, nCells) cold, 4 fields per lane:
+        // 32 x 32 patches (254 workgroups of 1 024 threads, one per CU) 1 /
+        // 4 runs 0.121 / 0.149 ms; 16 x 16 patches (1 013 of 256 threads, 8
+        // per CU) 1 / 2 / 4 runs 0.146 / 0.141 / 0.144.
+        const int64_t lds_wg = (int64_t)upitch * tt * 16;
+        int64_t fit = 2048 / block;
+        if (fit > (int64_t)kPatchLdsMax / lds_wg)
+            fit = (int64_t)kPatchLdsMax / lds_wg;
+        if (fit > 8)
+            fit = 8;
+        if (fit < 1)
+            fit = 1;
+        groups = (256 * fit) / a->n_patches;
+        if (groups < 1)
+            groups = 1;
         if (a->tune[3] > 0)
             groups = a->tune[3];
         if (groups > n_chunks)
@@ -1008,10 +1031,11 @@ int run_patchcell(const remap_apply_args *a, const Call &c, KParams p,
     if (lds_bytes < 1024)
         lds_bytes = 1024;
     const int layout = a->patch_ell_base ? 1 : 0;
+    const int launch_block = persistent ? block : kCellBlock;
     cell_fn fn =
         persistent
-            ? (c.f32 ? pick_patchtime<float>(tt, a->mode, c.fma)
-                     : pick_patchtime<double>(tt, a->mode, c.fma))
+            ? (c.f32 ? pick_patchtime<float>(tt, a->mode, c.fma, block)
+                     : pick_patchtime<double>(tt, a->mode, c.fma, block))
             : (c.f32 ? pick_patchcell<float>(tt, a->mode, c.fma, layout)
                      : pick_patchcell<double>(tt, a->mode, c.fma, layout));
     if (lds_bytes > 64 * 1024)
@@ -1019,8 +1043,9 @@ int run_patchcell(const remap_apply_args *a, const Call &c, KParams p,
             reinterpret_cast<const void *>(fn),
             hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     hipLaunchKernelGGL(fn, dim3(static_cast<uint32_t>(grid)),
-                       dim3(kCellBlock), lds_bytes, stream, p, a->flags,
-                       a->patch_rowptr, a->patch_val, a->patch_lidx,
+                       dim3(launch_block), lds_bytes, stream, p, a->flags,
+                       a->patch_rowptr,
+                       a->patch_val, a->patch_lidx,
                        a->patch_ptr, a->patch_ucol, a->row_order, a->frac_b,
                        a->patch_rows, upitch, a->n_patches,
                        a->patch_ell_base);

@@ -191,8 +191,8 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <typename XT, int MODE, bool FMA, int TT>
-__global__ __launch_bounds__(kCellBlock) void spmm_patchtime(
+template <typename XT, int MODE, bool FMA, int TT, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void spmm_patchtime(
     const KParams p, const uint32_t flags,
     const int32_t *__restrict__ prow, const double *__restrict__ pval,
     const int32_t *__restrict__ plidx, const int32_t *__restrict__ pptr,
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(kCellBlock) void spmm_patchtime(
     const int32_t upitch, const int64_t n_patches,
     const int64_t *__restrict__ ell_base)
 {
-    constexpr int NC = 2;      // cells per lane: patches hold <= 512 cells
+    constexpr int NC = 2;      // cells per lane: patches hold <= 2 BLOCK cells
     constexpr int NE = 8;      // entries of a row kept in registers
     extern __shared__ __attribute__((aligned(16))) char lds[];
     double *xs = reinterpret_cast<double *>(lds);   // [2][TT][upitch]
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(kCellBlock) void spmm_patchtime(
         // (idle lanes name the patch's first cell -- a patch without cells
         // the plan's first: no load sits behind a branch, none leaves the
         // arrays)
-        const int j = tid + q * kCellBlock;
+        const int j = tid + q * BLOCK;
         cb[q] = cell_base(p, ucol[U > 0 ? u0 + (j < U ? j : 0) : 0]);
     }
     const int64_t slot0 = p.row_begin + patch * patch_rows;
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(kCellBlock) void spmm_patchtime(
         double *img = xs + ((c - c0) & 1) * (TT * upitch);
 #pragma unroll
         for (int q = 0; q < NC; ++q) {
-            const int j = tid + q * kCellBlock;
+            const int j = tid + q * BLOCK;
             if (j < U) {
 #pragma unroll
                 for (int t = 0; t < TT; ++t)

@@ -868,9 +868,9 @@ class RemapPlan:
             row_bytes=int(row_bytes))
 
     #: distinct source cells a patch of the lanes-across-rows kernel may
-    #: stage: 8 fields x 8 bytes each stay under 32 KB of LDS, so several
-    #: workgroups share a CU and overlap staging with compute
-    CELL_UMAX = 512
+    #: stage: two cells per lane of a 1 024-thread workgroup, two LDS images
+    #: of 4 fields each = 128 KB (spmm_patchtime)
+    CELL_UMAX = 2046
 
     def run_patches(self):
         """
@@ -913,13 +913,27 @@ class RemapPlan:
             dims = self._grid_dims
             if dims is not None and len(dims) != 2:
                 dims = None
+            # (small grids: smaller tiles, so that there still are a few
+            # hundred workgroups)
+            tile = self.CELL_TILE
+            while tile[0] * tile[1] > 256 and \
+                    self.n_b < 128 * tile[0] * tile[1]:
+                tile = (tile[0], tile[1] // 2) if tile[1] >= tile[0] else \
+                    (tile[0] // 2, tile[1])
             q = self._make_patches(
-                dims, (16, 16) if dims is not None else (1, 256),
-                lambda rows, umax, emax: umax <= self.CELL_UMAX or rows <= 16,
-                1024)
+                dims, tile if dims is not None else (1, tile[0] * tile[1]),
+                lambda rows, umax, emax: umax <= self.CELL_UMAX or
+                rows <= 16, 1024)
             self._cell = q if q is not None else False
             self._sched_version += 1
         return self._cell or None
+
+    #: tile of the destination grid a patch of cell_patches covers (halved
+    #: until a patch holds at most CELL_UMAX source cells): one 1 024-thread
+    #: workgroup per patch and CU walks ALL its chunks -- config 3's map,
+    #: (120, nCells) cold: 16 x 16 / 16 x 32 / 32 x 32 tiles 0.146 / 0.137 /
+    #: 0.121 ms
+    CELL_TILE = (32, 32)
 
     GROUP = 8   # default rows per group (remap_apply_args.group_rows)
 

@@ -142,7 +142,7 @@ def test_time_ncells_takes_one_launch_no_copy(dev, monkeypatch):
     x = torch.randn((120, m.n_a), dtype=torch.float64, device=dev)
     y = engine.remap_tensor(plan, m.dst_dims, x, [1], engine.MODE_FRACB)
     assert calls == [(x.data_ptr(), 120, 1, 1, m.n_a)]
-    assert plan._cell and plan._cell['rows'] <= 256
+    assert plan._cell and plan._cell['rows'] <= 1024
     ref, ref_mask = oracle.remap_flat(csr, frac_b, x.cpu().numpy().T.copy(),
                                       False, 0.0)
     ref[ref_mask] = np.nan
@@ -367,3 +367,47 @@ def test_short_level_runs_take_small_lds_patches(dev, grid):
     ref = np.ma.filled(oracle.remap_numpy_array(csr2, frac2, grid, x, [1],
                                                 None), np.nan)
     assert_bitwise(y.cpu().numpy(), ref, '16 levels')
+
+
+@pytest.mark.parametrize('dims,rows,block', [((256, 300), 512, 512),
+                                             ((300, 480), 1024, 1024)])
+def test_large_patches_persistent_workgroups(dev, dims, rows, block):
+    """
+    Grids of >= 64 K / 128 K cells take 16 x 32 / 32 x 32 patches: one 512- /
+    1 024-thread workgroup per patch walks all its chunks (spmm_patchtime: a
+    lane per row, two cells per lane, two LDS images) -- config 3's
+    (120, nCells) runs this way.  Every value the oracle's, three modes, both
+    dtypes, a K that is no multiple of the fields per lane, (Time, n, 2).
+    """
+    from oracle import oracle
+    from pyremap_amd import engine, synthetic
+    n_a = int(0.9 * dims[0] * dims[1])
+    m = synthetic.conservative_map(n_a, dims, 3, 7, seed=21, device=dev,
+                                   locality='mesh')
+    plan = engine.RemapPlan.from_triplets(m.row, m.col, m.S, m.frac_b, m.n_a,
+                                          m.n_b, index_base=1, device=dev)
+    plan.auto_schedule(m.dst_dims)
+    q = plan.cell_patches()
+    assert q['rows'] == rows and q['umax'] <= 2 * block
+    rowptr, c, v = plan.to_host_csr()
+    csr = oracle.OracleCSR(rowptr, c, v, (m.n_b, m.n_a))
+    frac_b = plan.frac_b.cpu().numpy()
+    rng = np.random.default_rng(5)
+    for shape, axes in (((9, n_a), [1]), ((3, n_a, 2), [1])):
+        for dtype in (np.float64, np.float32):
+            x = rng.standard_normal(shape).astype(dtype)
+            holes = x.copy()
+            holes[(slice(None),) * axes[0] + (rng.random(n_a) < 0.2,)] = \
+                np.nan
+            for field, thr in ((x, None), (holes, 0.3), (holes, None)):
+                masked = thr is not None
+                arg = np.ma.masked_array(field, np.isnan(field)) if masked \
+                    else field
+                want = oracle.remap_numpy_array(csr, frac_b, m.dst_dims, arg,
+                                                axes, thr, nthreads=8)
+                got = engine.remap_tensor(
+                    plan, m.dst_dims, torch.from_numpy(field).to(dev), axes,
+                    engine.MODE_MASKED if masked else engine.MODE_FRACB,
+                    threshold=thr or 0.0)
+                assert_bitwise(got.cpu().numpy(), np.ma.filled(want, np.nan),
+                               f'{dims} {shape} {dtype.__name__} thr {thr}')

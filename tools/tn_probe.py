@@ -21,6 +21,8 @@ def main():
     ap.add_argument('--times', default='12,120')
     ap.add_argument('--reps', type=int, default=30)
     ap.add_argument('--dtype', default='f64')
+    ap.add_argument('--tile', default='16x16',
+                    help='tile of the destination grid per patch')
     ap.add_argument('--only', default='',
                     help='run only the variants whose tag contains this')
     args = ap.parse_args()
@@ -32,7 +34,10 @@ def main():
     plan = engine.RemapPlan.from_triplets(m.row, m.col, m.S, m.frac_b, m.n_a,
                                           m.n_b, index_base=1, device=dev)
     plan.auto_schedule(m.dst_dims)
-    plan.cell_patches()
+    engine.RemapPlan.CELL_TILE = tuple(int(v) for v in args.tile.split('x'))
+    q = plan.cell_patches()
+    print(json.dumps(dict(tile=q['tile'], rows=q['rows'], umax=q['umax'],
+                          patches=q['n'])))
     dt = torch.float32 if args.dtype == 'f32' else torch.float64
     for T in (int(t) for t in args.times.split(',')):
         xs = [torch.randn((T, m.n_a), device=dev, dtype=torch.float64).to(dt)
