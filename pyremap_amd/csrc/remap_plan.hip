@@ -599,7 +599,9 @@ int create(int64_t n_b, int64_t n_a, int64_t n_s, const int32_t *row,
 
 // distinct source cells a patch of the lanes-across-rows kernel may stage
 // (8 fields x 8 bytes each stay under 32 KB of LDS)
-constexpr int64_t kCellUmax = 512;
+// (engine.RemapPlan.CELL_UMAX / CELL_TILE: two cells per lane of a
+// 1 024-thread workgroup; 32 x 32 tiles on grids of >= 128 K cells)
+constexpr int64_t kCellUmax = 2046;
 
 size_t align256(size_t n) { return (n + 255) / 256 * 256; }
 
@@ -639,7 +641,15 @@ int prepare_short_runs(remap_plan *plan, hipStream_t stream)
     A.max_row_nnz = plan->max_row_nnz;
     A.csr_pad = kCsrPad;
     const bool two_d = plan->n_dims == 2;
-    int32_t ty = two_d ? 16 : 1, tx = two_d ? 16 : 256;
+    int32_t ty = two_d ? 32 : 1, tx = two_d ? 32 : 1024;
+    // small grids: smaller tiles, so that there still are a few hundred
+    // workgroups
+    while ((int64_t)ty * tx > 256 && n_b < (int64_t)128 * ty * tx) {
+        if (tx >= ty)
+            tx /= 2;
+        else
+            ty /= 2;
+    }
     int64_t h[3] = {0, 0, 0};
     for (;;) {
         rc = remap_patches_build(

@@ -411,3 +411,55 @@ def test_large_patches_persistent_workgroups(dev, dims, rows, block):
                     threshold=thr or 0.0)
                 assert_bitwise(got.cpu().numpy(), np.ma.filled(want, np.nan),
                                f'{dims} {shape} {dtype.__name__} thr {thr}')
+
+
+def test_plan_handle_large_grid_takes_the_large_patches(dev):
+    """The opaque C plan handle on a grid of >= 128 K cells: its short-run
+    patch plan holds 32 x 32 tiles too (`remap_plan_prepare_short_runs`), a
+    (Time, nCells) field goes through the 1 024-thread persistent
+    workgroups -- the bits of the Python layer's launch on the same map."""
+    import ctypes
+    from pyremap_amd import engine, synthetic
+    dims_t = (300, 480)
+    n_a = int(0.9 * dims_t[0] * dims_t[1])
+    m = synthetic.conservative_map(n_a, dims_t, 3, 7, seed=21, device=dev,
+                                   locality='mesh')
+    mm = m.numpy()
+    lib = engine.load_library()
+    handle = ctypes.c_void_p()
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    dims = (ctypes.c_int64 * 2)(*m.dst_dims)
+
+    def host(a, t):
+        return np.ascontiguousarray(a, dtype=t).ctypes.data
+
+    assert lib.remap_plan_create(
+        m.n_b, m.n_a, len(mm['S']), host(mm['row'], np.int32),
+        host(mm['col'], np.int32), host(mm['S'], np.float64), 1,
+        host(mm['frac_b'], np.float64), 1, dims, 2, stream,
+        ctypes.byref(handle)) == 0, lib.remap_last_error()
+    try:
+        assert lib.remap_plan_prepare_short_runs(handle, stream) == 0, \
+            lib.remap_last_error()
+        x = torch.randn((9, m.n_a), dtype=torch.float64, device=dev)
+        y = torch.empty((9, m.n_b), dtype=torch.float64, device=dev)
+        f = engine._Field()
+        f.X, f.Y = x.data_ptr(), y.data_ptr()
+        f.x_dtype, f.mode = engine.DTYPE_F64, engine.MODE_FRACB
+        f.n_batch, f.k_inner = 9, 1
+        f.x_row_stride, f.x_batch_stride = 1, m.n_a
+        f.y_row_stride, f.y_batch_stride = 1, m.n_b
+        assert lib.remap_plan_apply(handle, ctypes.byref(f), stream) == 0, \
+            lib.remap_last_error()
+        plan = engine.RemapPlan.from_triplets(
+            m.row, m.col, m.S, m.frac_b, m.n_a, m.n_b, index_base=1,
+            device=dev)
+        plan.auto_schedule(m.dst_dims)
+        assert plan.cell_patches()['rows'] == 1024
+        want = engine.remap_tensor(plan, m.dst_dims, x, [1],
+                                   engine.MODE_FRACB)
+        torch.cuda.synchronize()
+        assert torch.equal(torch.nan_to_num(y, nan=-2.0).reshape(-1),
+                           torch.nan_to_num(want, nan=-2.0).reshape(-1))
+    finally:
+        lib.remap_plan_destroy(handle)
