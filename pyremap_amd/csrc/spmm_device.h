@@ -55,6 +55,30 @@ struct KParams {
 #define REMAP_DIAG_SKIP_STORE(p, y0) false
 #endif
 
+#ifdef REMAP_STAMPS
+// The clock the chip holds INSIDE a kernel: shader cycles (s_memtime) and
+// constant-rate 100 MHz ticks (s_memrealtime) of one wave per workgroup,
+// from its first to its last instruction, summed into slots 6 / 7 of the
+// stamps buffer: MHz = 100 * sum(cycles) / sum(ticks) (tools/clock_state.py
+// --in-kernel).  Two scalar reads at either end of a workgroup: the run time
+// of this build is the product's to within a fraction of a per cent.
+#define REMAP_CLOCK_BEGIN()                                                  \
+    const unsigned long long ck_t0 = __builtin_amdgcn_s_memtime();           \
+    const unsigned long long ck_r0 = __builtin_amdgcn_s_memrealtime()
+#define REMAP_CLOCK_END()                                                    \
+    do {                                                                     \
+        if (threadIdx.x == 0 && p.mask_out) {                                \
+            unsigned long long *o =                                          \
+                reinterpret_cast<unsigned long long *>(p.mask_out);          \
+            atomicAdd(o + 6, __builtin_amdgcn_s_memtime() - ck_t0);          \
+            atomicAdd(o + 7, __builtin_amdgcn_s_memrealtime() - ck_r0);      \
+        }                                                                    \
+    } while (0)
+#else
+#define REMAP_CLOCK_BEGIN() do { } while (0)
+#define REMAP_CLOCK_END() do { } while (0)
+#endif
+
 template <bool FMA>
 __device__ __forceinline__ double mul_add(double a, double x, double acc)
 {

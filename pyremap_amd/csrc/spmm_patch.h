@@ -87,6 +87,7 @@ __global__ __launch_bounds__(kPatchBlock) void spmm_patch(
     const int64_t L = logical_block(p);
     if (L >= p.n_blocks)
         return;
+    REMAP_CLOCK_BEGIN();
     const int64_t chunk = L / n_patches;  // chunk-major work list
     const int64_t patch = L - chunk * n_patches;
 
@@ -356,4 +357,5 @@ __global__ __launch_bounds__(kPatchBlock) void spmm_patch(
         rows_loop(std::true_type());
     else
         rows_loop(std::false_type());
+    REMAP_CLOCK_END();
 }

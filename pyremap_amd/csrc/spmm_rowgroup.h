@@ -80,6 +80,7 @@ __global__ __launch_bounds__(BLOCK) void spmm_rowgroup(
     const int64_t L = logical_block(p);
     if (L >= p.n_blocks)
         return;
+    REMAP_CLOCK_BEGIN();
     const int64_t chunk = L / p.n_rowblocks;
     const int64_t rb = L - chunk * p.n_rowblocks;
 
@@ -284,4 +285,5 @@ __global__ __launch_bounds__(BLOCK) void spmm_rowgroup(
             }
         }
     }
+    REMAP_CLOCK_END();
 }
