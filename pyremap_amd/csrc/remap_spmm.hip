@@ -276,6 +276,34 @@ cell_fn pick_patchtime_tt(int tt, int mode, bool fma)
                      : pick_patchtime_mode<XT, 8, BLOCK>(mode, fma);
 }
 
+// (Time, nCells, 4 ... 15): a batch at a time, 4 columns per chunk
+template <typename XT, int BLOCK>
+cell_fn pick_patchruns_mode(int mode, bool fma)
+{
+    switch (mode) {
+    case REMAP_MODE_RAW:
+        return fma ? spmm_patchtime<XT, REMAP_MODE_RAW, true, 4, BLOCK, true>
+                   : spmm_patchtime<XT, REMAP_MODE_RAW, false, 4, BLOCK, true>;
+    case REMAP_MODE_FRACB:
+        return fma
+                   ? spmm_patchtime<XT, REMAP_MODE_FRACB, true, 4, BLOCK, true>
+                   : spmm_patchtime<XT, REMAP_MODE_FRACB, false, 4, BLOCK,
+                                    true>;
+    default:
+        return fma ? spmm_patchtime<XT, REMAP_MODE_MASKED, true, 4, BLOCK,
+                                    true>
+                   : spmm_patchtime<XT, REMAP_MODE_MASKED, false, 4, BLOCK,
+                                    true>;
+    }
+}
+
+template <typename XT>
+cell_fn pick_patchruns(int mode, bool fma, int block)
+{
+    return block == 256 ? pick_patchruns_mode<XT, 256>(mode, fma)
+                        : pick_patchruns_mode<XT, 512>(mode, fma);
+}
+
 template <typename XT>
 cell_fn pick_patchtime(int tt, int mode, bool fma, int block)
 {
@@ -674,9 +702,28 @@ bool short_runs(const remap_apply_args *a)
     return (a->k_inner < 4 && a->n_batch > 1) || a->x_src_fold != 0;
 }
 
+// family 7 with tune[2] = 2: (Time, nCells, 4 ... 15) a batch at a time, the
+// results written out through LDS (spmm_patchtime<..., RUNS>)
+bool runs_usable(const remap_apply_args *a, const Call &c)
+{
+    if (!c.cell_ok || a->patch_ell_base || a->A.nnz <= 0 || a->n_batch < 2 ||
+        a->k_inner < 4 || a->k_inner >= 16)
+        return false;
+    const int64_t upitch = (a->patch_umax + 2) & ~1;
+    const int64_t lanes = a->patch_rows > (upitch + 1) / 2
+                              ? a->patch_rows
+                              : (upitch + 1) / 2;
+    const int64_t out_bytes =
+        (int64_t)a->patch_rows * (a->k_inner * 9 + 4) + 16;
+    return lanes <= 512 &&
+           upitch * 4 * 16 + out_bytes <= (int64_t)kPatchLdsMax;
+}
+
 // REMAP_FLAG_TUNE_HINT: can the preferred family serve this call?
 bool hint_usable(const remap_apply_args *a, const Call &c)
 {
+    if (a->tune[0] == 7 && a->tune[2] == 2)
+        return runs_usable(a, c);
     if (a->tune[0] == 7)
         return c.cell_ok;   // LDS-staged lanes across rows: any K
     if (a->tune[0] == 9)    // wave per long row: any K, any layout
@@ -992,7 +1039,21 @@ int run_patchcell(const remap_apply_args *a, const Call &c, KParams p,
     while (persistent && tt > 2 &&
            (int64_t)upitch * tt * 16 > (int64_t)kPatchLdsMax)
         tt >>= 1;
-    const int64_t n_chunks = ceil_div(c.K, tt);
+    // tune[2] = 2: fields with short runs in several batches, (Time, nCells,
+    // 4 ... 15) -- a batch at a time, results written out through LDS
+    // (spmm_patchtime<..., RUNS>)
+    const int64_t ki = a->k_inner;
+    const int64_t out_bytes = (int64_t)a->patch_rows * (ki * 9 + 4) + 16;
+    const bool runs = persistent && a->tune[2] == 2 && runs_usable(a, c);
+    if (a->tune[2] == 2 && !runs)
+        return fail(REMAP_ERR_UNSUPPORTED,
+                    "remap_apply_f64: tune[2] = 2 (short runs, a batch at a "
+                    "time) needs 4 <= k_inner < 16, several batches and a "
+                    "patch plan of at most 512 rows / 1 022 cells per patch");
+    if (runs)
+        tt = 4;
+    const int64_t sub = runs ? ceil_div(ki, tt) : 1;
+    const int64_t n_chunks = runs ? a->n_batch * sub : ceil_div(c.K, tt);
     int64_t groups = 1, cpw = 1;
     if (persistent) {
         // Runs of chunks per patch: ONE round of workgroups on the chip --
@@ -1001,7 +1062,8 @@ int run_patchcell(const remap_apply_args *a, const Call &c, KParams p,
         // 32 x 32 patches (254 workgroups of 1 024 threads, one per CU) 1 /
         // 4 runs 0.121 / 0.149 ms; 16 x 16 patches (1 013 of 256 threads, 8
         // per CU) 1 / 2 / 4 runs 0.146 / 0.141 / 0.144.
-        const int64_t lds_wg = (int64_t)upitch * tt * 16;
+        const int64_t lds_wg =
+            (int64_t)upitch * tt * 16 + (runs ? out_bytes : 0);
         int64_t fit = 2048 / block;
         if (fit > (int64_t)kPatchLdsMax / lds_wg)
             fit = (int64_t)kPatchLdsMax / lds_wg;
@@ -1014,9 +1076,10 @@ int run_patchcell(const remap_apply_args *a, const Call &c, KParams p,
             groups = 1;
         if (a->tune[3] > 0)
             groups = a->tune[3];
-        if (groups > n_chunks)
-            groups = n_chunks;
-        cpw = ceil_div(n_chunks, groups);
+        if (groups > n_chunks / sub)
+            groups = n_chunks / sub;
+        // (RUNS: whole batches per workgroup)
+        cpw = ceil_div(ceil_div(n_chunks, groups), sub) * sub;
         groups = ceil_div(n_chunks, cpw);
         p.rows_per_wave = static_cast<int32_t>(cpw);
     }
@@ -1027,13 +1090,16 @@ int run_patchcell(const remap_apply_args *a, const Call &c, KParams p,
     if (rc != REMAP_OK)
         return rc;
     uint32_t lds_bytes =
-        static_cast<uint32_t>(upitch) * tt * 8u * (persistent ? 2u : 1u);
+        static_cast<uint32_t>(upitch) * tt * 8u * (persistent ? 2u : 1u) +
+        (runs ? static_cast<uint32_t>(out_bytes) : 0u);
     if (lds_bytes < 1024)
         lds_bytes = 1024;
     const int layout = a->patch_ell_base ? 1 : 0;
     const int launch_block = persistent ? block : kCellBlock;
     cell_fn fn =
-        persistent
+        runs ? (c.f32 ? pick_patchruns<float>(a->mode, c.fma, block)
+                      : pick_patchruns<double>(a->mode, c.fma, block))
+        : persistent
             ? (c.f32 ? pick_patchtime<float>(tt, a->mode, c.fma, block)
                      : pick_patchtime<double>(tt, a->mode, c.fma, block))
             : (c.f32 ? pick_patchcell<float>(tt, a->mode, c.fma, layout)

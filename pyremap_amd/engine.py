@@ -34,6 +34,9 @@ FLAG_TREE = 8
 #: long rows run one wave per (row, few columns) -- family 9 -- beyond it on
 #: the LDS-staged lanes-across-rows kernel (family 7)
 LONG_WAVE_FIELDS = 16
+#: fields whose contiguous run behind the source axes is shorter than this
+#: (and that come in several batches) take the lanes-across-rows kernels
+CELL_MAX_RUN = 4
 
 DTYPE_F64 = 0
 DTYPE_F32 = 1
@@ -431,6 +434,7 @@ class RemapPlan:
         #: lazily built small LDS patches for fields with short level runs
         #: (see run_patches)
         self._runs = None
+        self._run_cells = None
         # schedule attributes are properties: every assignment invalidates
         # the prefilled argument block launches start from (_prefilled)
         self._sched_version = 0
@@ -487,7 +491,8 @@ class RemapPlan:
         args.A.csr_pad = self.csr_pad
         order = self.row_order
         if whole and cell:
-            q = self._runs if cell == 'runs' else self._cell
+            q = self._runs if cell == 'runs' else \
+                self._run_cells if cell == 'run_cells' else self._cell
             args.row_order = q['order'].data_ptr() \
                 if q['order'] is not None else None
             args.patch_ptr = q['ptr'].data_ptr()
@@ -898,6 +903,33 @@ class RemapPlan:
             self._runs = q if q is not None else False
             self._sched_version += 1
         return self._runs or None
+
+    def run_cells(self):
+        """
+        The patch plan of the batch-at-a-time lanes-across-rows kernel
+        (``spmm_patchtime<..., RUNS>``) for ``(Time, nCells, L)`` fields with
+        VERY short level runs, 4 <= L <= ``RUN_CELLS_MAX``: 16 x 16 tiles (256
+        consecutive rows of a 1-D destination), halved until a patch holds at
+        most 510 source cells -- one 256-thread workgroup per patch walks the
+        batches, the results of a batch leave through LDS as whole lines
+        (config 3's map, ms per launch, this kernel / the small LDS patches
+        of :meth:`run_patches` / row groups: L = 4 0.58 / 0.79 / 1.11, 5
+        0.70 / 0.99 / 1.54, 6 0.74 / 0.77 / 1.12; from L = 8 the LDS patches
+        win: 0.68 / 0.53 / 0.61).  Built on first use.
+        """
+        if self._run_cells is None:
+            dims = self._grid_dims
+            if dims is not None and len(dims) != 2:
+                dims = None
+            q = self._make_patches(
+                dims, (16, 16) if dims is not None else (1, 256),
+                lambda rows, umax, emax: umax <= 510 or rows <= 16, 1024)
+            self._run_cells = q if q is not None else False
+            self._sched_version += 1
+        return self._run_cells or None
+
+    #: longest level run the batch-at-a-time kernel takes (see run_cells)
+    RUN_CELLS_MAX = 6
 
     def cell_patches(self):
         """
@@ -1391,17 +1423,23 @@ def apply_strided(plan, X, Y, *, n_batch, k_inner, x_row_stride,
     # LDS-staged lanes-across-rows kernel on its own patch plan
     cell = _long_rows or (
         whole and not tune and
-        ((k_inner < 4 and n_batch > 1) or x_src_fold) and
+        ((k_inner < CELL_MAX_RUN and n_batch > 1) or x_src_fold) and
         n_batch * k_inner >= 2 and plan.cell_patches() is not None)
     # short level runs in several batches -- (Time, nCells, 4 ... 15) -- on
     # a row-group mapping: small LDS patches (RemapPlan.run_patches)
     if not cell and whole and not tune and n_batch > 1 and \
             4 <= k_inner < 16 and n_batch * k_inner >= 64 and \
-            plan.patches is None and plan.run_patches() is not None:
-        cell = 'runs'
+            plan.patches is None:
+        if k_inner <= plan.RUN_CELLS_MAX and plan.run_cells() is not None:
+            cell = 'run_cells'
+        elif plan.run_patches() is not None:
+            cell = 'runs'
     args = plan._prefilled(whole, cell)
     if cell == 'runs':
         tune = [5]
+        flags |= FLAG_TUNE_HINT
+    elif cell == 'run_cells':
+        tune = [7, 4, 2]
         flags |= FLAG_TUNE_HINT
     elif cell:
         # 4 fields per lane and LDS image: the workgroup stays on its patch

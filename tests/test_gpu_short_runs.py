@@ -333,16 +333,18 @@ def test_empty_shapes_through_every_layout(dev):
 def test_short_level_runs_take_small_lds_patches(dev, grid):
     """`(Time, nCells, L)` with 4 <= L < 16 on a row-group mapping: the plan
     builds small LDS patches on first use and the patch kernel (family 5)
-    serves the call; bitwise, every mode and dtype; longer runs and partial
-    row ranges keep the row groups."""
+    serves 7 <= L < 16, the batch-at-a-time lanes-across-rows kernel (family
+    7, RUNS) on 256-row patches serves 4 <= L <= 6; bitwise, every mode and
+    dtype; longer runs and partial row ranges keep the row groups."""
     from oracle import oracle
     from pyremap_amd import engine
     m, plan, csr, frac_b, choice = _problem(dev, grid)
     assert choice['family'] == 'rowgroup'
     rng = np.random.default_rng(11)
-    assert plan._runs is None
+    assert plan._runs is None and plan._run_cells is None
     for shape in ((20, m.n_a, 4), (9, m.n_a, 10), (7, m.n_a, 12),
-                  (5, m.n_a, 15), (2, 9, m.n_a, 5), (13, m.n_a, 7)):
+                  (5, m.n_a, 15), (2, 9, m.n_a, 5), (13, m.n_a, 7),
+                  (11, m.n_a, 6), (1, 17, m.n_a, 4)):
         axes = [len(shape) - 2]
         for dtype in (np.float64, np.float32):
             x = rng.standard_normal(shape).astype(dtype)
@@ -357,13 +359,16 @@ def test_short_level_runs_take_small_lds_patches(dev, grid):
                     threshold=thr or 0.0)
                 assert_bitwise(y.cpu().numpy(), ref,
                                f'{shape} {dtype.__name__} {thr}')
+        if shape == (20, m.n_a, 4):
+            assert plan._run_cells and plan._runs is None
     assert plan._runs and plan._runs['rows'] <= 32
+    assert plan._run_cells and 32 < plan._run_cells['rows'] <= 256
     # 16 levels and more: the row groups, no patch plan needed
     m2, plan2, csr2, frac2, _ = _problem(dev, grid, seed=4)
     x = rng.standard_normal((4, m2.n_a, 16))
     y = engine.remap_tensor(plan2, grid, torch.from_numpy(x).to(dev), [1],
                             engine.MODE_FRACB)
-    assert plan2._runs is None
+    assert plan2._runs is None and plan2._run_cells is None
     ref = np.ma.filled(oracle.remap_numpy_array(csr2, frac2, grid, x, [1],
                                                 None), np.nan)
     assert_bitwise(y.cpu().numpy(), ref, '16 levels')
