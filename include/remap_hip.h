@@ -301,6 +301,15 @@ typedef struct remap_apply_args {
      *                             if given, names the row of Y / frac_b /
      *                             mask_out it writes; needs A.max_row_nnz;
      *                             tune[1] = columns per wave (1 ... 16)
+     *                         11 = one wave per LONG row x 64 columns, the
+     *                             distinct source cells of a patch of R <=
+     *                             16 consecutive long rows sliding through
+     *                             LDS in windows of 8 R cells (many fields;
+     *                             `A` and row_order as for 9).  Needs a
+     *                             patch plan (remap_patches_build, tile 1 x
+     *                             R, no patch_ell_base) whose patch_lidx do
+     *                             not decrease inside a row -- true when the
+     *                             rows of A are sorted by column
      * tune[1] doubles per lane per tile (1 or 2); family 10: waves per
      *         workgroup (1, 2; else 4); family 2: entries of a row fetched
      *         together (1, 4 or 8)

@@ -64,6 +64,7 @@ namespace {
 #include "spmm_rowsub.h"
 #include "spmm_strip.h"
 #include "spmm_longrow.h"
+#include "spmm_longwave.h"
 
 // ---------------------------------------------------------------------------
 // host-side dispatch
@@ -585,11 +586,12 @@ int check_args(const remap_apply_args *a, Call &c)
                     "%lld source cells", (long long)a->x_src_fold,
                     (long long)A.n_cols);
     if (a->x_src_fold != 0 && a->tune[0] != 0 && a->tune[0] != 4 &&
-        a->tune[0] != 7 && a->tune[0] != 9 &&
+        a->tune[0] != 7 && a->tune[0] != 9 && a->tune[0] != 11 &&
         !(a->flags & REMAP_FLAG_TUNE_HINT))
         return fail(REMAP_ERR_UNSUPPORTED,
                     "remap_apply_f64: two non-adjacent source axes "
-                    "(x_src_fold) are served by kernel families 4, 7 and 9");
+                    "(x_src_fold) are served by kernel families 4, 7, 9 "
+                    "and 11");
     if (c.K >= (int64_t(1) << 31))
         return fail(REMAP_ERR_UNSUPPORTED,
                     "remap_apply_f64: K = %lld fields per call exceeds 2^31",
@@ -719,6 +721,23 @@ bool runs_usable(const remap_apply_args *a, const Call &c)
            upitch * 4 * 16 + out_bytes <= (int64_t)kPatchLdsMax;
 }
 
+// family 11: one wave per long row x 64 columns, source cells sliding through
+// LDS in windows (spmm_longwave.h).  The patch plan attached names R <= 16
+// consecutive long rows per patch, row-major entries (no patch_ell_base).
+bool longwave_usable(const remap_apply_args *a, const Call &c)
+{
+    return a->patch_ptr && a->patch_ucol && a->patch_lidx &&
+           a->patch_rowptr && a->patch_val && !a->patch_ell_base &&
+           a->patch_rows > 0 && a->patch_rows <= kPatchWaves &&
+           a->n_patches > 0 && a->A.max_row_nnz > 0 &&
+           a->patch_rows * (2 * kLongPre * kLongCellBytes +
+                            ((a->A.max_row_nnz + 15) / 16 * 16 + 16) *
+                                (int64_t)kLongRecordBytes) <=
+               (int64_t)kPatchLdsMax &&
+           c.n_rows <= a->n_patches * (int64_t)a->patch_rows &&
+           c.n_rows > (a->n_patches - 1) * (int64_t)a->patch_rows;
+}
+
 // REMAP_FLAG_TUNE_HINT: can the preferred family serve this call?
 bool hint_usable(const remap_apply_args *a, const Call &c)
 {
@@ -726,6 +745,8 @@ bool hint_usable(const remap_apply_args *a, const Call &c)
         return runs_usable(a, c);
     if (a->tune[0] == 7)
         return c.cell_ok;   // LDS-staged lanes across rows: any K
+    if (a->tune[0] == 11)   // wave per long row, windows through LDS
+        return longwave_usable(a, c);
     if (a->tune[0] == 9)    // wave per long row: any K, any layout
         return a->A.max_row_nnz > 0 &&
                2 * ((a->A.max_row_nnz + 34) * 8) <= (int64_t)kPatchLdsMax;
@@ -1031,8 +1052,8 @@ int run_patchcell(const remap_apply_args *a, const Call &c, KParams p,
         !long_rows && a->tune[2] != 1 && a->A.nnz > 0 &&
         (tt == 2 || tt == 4 || tt == 8 || tt == 16) && lanes <= 1024 &&
         (int64_t)upitch * 2 * 16 <= (int64_t)kPatchLdsMax;
-    if (!persistent && tt == 2)
-        tt = 4;
+    if (!persistent && !long_rows && tt == 2)
+        tt = 4;   // (the one-chunk kernel stages 4, 8 or 16 fields)
     if (persistent && tt == 16)
         tt = 8;
     // (two LDS images: fewer fields per lane until they fit)
@@ -1265,6 +1286,67 @@ int run_longrow(const remap_apply_args *a, const Call &c, KParams p,
     return REMAP_OK;
 }
 
+template <typename XT>
+patch_fn pick_longwave(int mode, bool fma)
+{
+    switch (mode) {
+    case REMAP_MODE_RAW:
+        return fma ? spmm_longwave<XT, REMAP_MODE_RAW, true>
+                   : spmm_longwave<XT, REMAP_MODE_RAW, false>;
+    case REMAP_MODE_FRACB:
+        return fma ? spmm_longwave<XT, REMAP_MODE_FRACB, true>
+                   : spmm_longwave<XT, REMAP_MODE_FRACB, false>;
+    default:
+        return fma ? spmm_longwave<XT, REMAP_MODE_MASKED, true>
+                   : spmm_longwave<XT, REMAP_MODE_MASKED, false>;
+    }
+}
+
+int run_longwave(const remap_apply_args *a, const Call &c, KParams p,
+                 hipStream_t stream)
+{
+    if (!longwave_usable(a, c))
+        return fail(REMAP_ERR_ARG,
+                    "remap_apply_f64: the long-wave kernel needs a row-major "
+                    "patch plan of at most %d rows per patch covering "
+                    "[row_begin, row_end)", kPatchWaves);
+    int64_t grid;
+    const int rc = shape_grid(p, a->n_patches,
+                              shape_tiles(p, a, c.K, kWave, 1),
+                              a->tune[4] == 2, grid);
+    if (rc != REMAP_OK)
+        return rc;
+    // per wave: two windows of 8 cells, 512 bytes per cell, and the row's
+    // records (a multiple of 16, + 16: the last batch is read whole)
+    const int64_t epitch = (a->A.max_row_nnz + 15) / 16 * 16 + 16;
+    const int64_t lds_need =
+        a->patch_rows *
+        (2 * kLongPre * kLongCellBytes + epitch * kLongRecordBytes);
+    if (a->A.max_row_nnz <= 0 || lds_need > (int64_t)kPatchLdsMax)
+        return fail(REMAP_ERR_UNSUPPORTED,
+                    "remap_apply_f64: %d rows of up to %lld entries do not "
+                    "fit the long-wave kernel's LDS image (A.max_row_nnz "
+                    "must be given)", a->patch_rows,
+                    (long long)a->A.max_row_nnz);
+    const uint32_t lds_bytes = static_cast<uint32_t>(lds_need);
+    const patch_fn fn = c.f32 ? pick_longwave<float>(a->mode, c.fma)
+                              : pick_longwave<double>(a->mode, c.fma);
+    if (lds_bytes > 64 * 1024)
+        REMAP_HIP_CHECK(hipFuncSetAttribute(
+            reinterpret_cast<const void *>(fn),
+            hipFuncAttributeMaxDynamicSharedMemorySize,
+            static_cast<int>(lds_bytes)));
+    hipLaunchKernelGGL(fn, dim3(static_cast<uint32_t>(grid)),
+                       dim3(static_cast<uint32_t>(a->patch_rows) * kWave),
+                       lds_bytes, stream, p, a->flags, a->patch_rowptr,
+                       a->patch_val, a->patch_lidx, a->patch_ptr,
+                       a->patch_ucol, a->row_order, a->frac_b, a->patch_rows,
+                       a->patch_umax, static_cast<int32_t>(epitch),
+                       a->n_patches);
+    REMAP_HIP_CHECK(hipGetLastError());
+    return REMAP_OK;
+}
+
 // family 3: a sub-group of 8 (4 for rows of at most 4 entries: bilinear
 // maps) lanes per row; tune[1] overrides the sub-group size
 int run_rowsub(const remap_apply_args *a, const Call &c, const KParams &p,
@@ -1382,6 +1464,8 @@ int apply(const remap_apply_args *a, hipStream_t stream)
         return run_strip(a, c, p, stream);
     case 9:
         return run_longrow(a, c, p, stream);
+    case 11:
+        return run_longwave(a, c, p, stream);
     case 1:
     case 6:
         return run_rowwave(a, c, p, family, stream);

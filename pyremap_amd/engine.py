@@ -34,6 +34,14 @@ FLAG_TREE = 8
 #: long rows run one wave per (row, few columns) -- family 9 -- beyond it on
 #: the LDS-staged lanes-across-rows kernel (family 7)
 LONG_WAVE_FIELDS = 16
+#: long rows per workgroup (one wave each) of family 11 (spmm_longwave), which
+#: takes the long rows' launch from LONG_WAVE_FIELDS + 1 to LONG_WAVE_MAX
+#: fields; 0: family 7 there too.  1 deg -> 0.5 deg with pole caps, the long
+#: rows' launch replayed, us, family 7 / family 11 with 4 / 6 / 8 rows:
+#: K = 24 26.5 / 23.9 / 20.0 / 19.2, 64 26.2 / 23.4 / 19.8 / 19.1, 128 38.2 /
+#: 28.3 / 27.4 / 36.3, 256 50.7 / 51.4 / 50.0 / 54.2, 512 61.3 / 98 / 95 / 107
+LONG_WAVE_ROWS = 6
+LONG_WAVE_MAX = 128
 #: fields whose contiguous run behind the source axes is shorter than this
 #: (and that come in several batches) take the lanes-across-rows kernels
 CELL_MAX_RUN = 4
@@ -435,6 +443,7 @@ class RemapPlan:
         #: (see run_patches)
         self._runs = None
         self._run_cells = None
+        self._wave = None
         # schedule attributes are properties: every assignment invalidates
         # the prefilled argument block launches start from (_prefilled)
         self._sched_version = 0
@@ -492,7 +501,8 @@ class RemapPlan:
         order = self.row_order
         if whole and cell:
             q = self._runs if cell == 'runs' else \
-                self._run_cells if cell == 'run_cells' else self._cell
+                self._run_cells if cell == 'run_cells' else \
+                self._wave if cell == 'wave' else self._cell
             args.row_order = q['order'].data_ptr() \
                 if q['order'] is not None else None
             args.patch_ptr = q['ptr'].data_ptr()
@@ -1112,6 +1122,27 @@ class RemapPlan:
         if q is None:
             return None
         q['order'] = ids.to(torch.int32).contiguous()
+        # many fields: a wave per long row, the source cells of a few
+        # neighbouring rows sliding through LDS (family 11) -- row-major
+        # entries whose local indices do not decrease inside a row (they
+        # cannot: the rows are sorted by column; checked all the same)
+        long._wave = None
+        # (its LDS image per row: two windows of 8 cells x 512 bytes and the
+        # row's records, 12 bytes each -- run_longwave)
+        per_row = 2 * 8 * 512 + ((long.max_row_nnz + 15) // 16 * 16 + 16) * 12
+        wave_rows = min(int(LONG_WAVE_ROWS), CELL_LDS_MAX // per_row)
+        if wave_rows >= 1:
+            w = long._make_patches(None, (1, wave_rows),
+                                   lambda rows, umax, emax: True, 1024)
+            if w is not None:
+                li = w['lidx'][:long.nnz]
+                first = torch.zeros(long.nnz, dtype=torch.bool,
+                                    device=self.device)
+                first[w['rowptr'][:-1].to(torch.int64)
+                      .clamp_(max=long.nnz - 1)] = True
+                if bool(((li[1:] >= li[:-1]) | first[1:]).all()):
+                    w['order'] = q['order']
+                    long._wave = w
         rows, n_p = q['rows'], q['n']
         rp = q['rowptr'].to(torch.int64)
         lens = rp[1:] - rp[:-1]
@@ -1160,6 +1191,7 @@ class RemapPlan:
         self._arena = None
         self._cell = None
         self._runs = None
+        self._run_cells = None
         self._grid_dims = None
         self._split = None
         if grid_dims is None or self.nnz == 0 or self.n_b == 0:
@@ -1434,8 +1466,16 @@ def apply_strided(plan, X, Y, *, n_batch, k_inner, x_row_stride,
             cell = 'run_cells'
         elif plan.run_patches() is not None:
             cell = 'runs'
+    if _long_rows and LONG_WAVE_FIELDS < n_batch * k_inner <= \
+            LONG_WAVE_MAX and plan._wave is not None and LONG_WAVE_ROWS:
+        cell = 'wave'
     args = plan._prefilled(whole, cell)
-    if cell == 'runs':
+    if cell == 'wave':
+        # many fields on long rows: one wave per row, the cells a few rows
+        # share sliding through LDS (family 11, spmm_longwave.h)
+        tune = [11]
+        flags |= FLAG_TUNE_HINT
+    elif cell == 'runs':
         tune = [5]
         flags |= FLAG_TUNE_HINT
     elif cell == 'run_cells':

@@ -170,6 +170,80 @@ def test_wave_per_long_row_every_width(dev, tt, monkeypatch):
                    f'tt {tt} (lat, M, lon)')
 
 
+@pytest.mark.parametrize('rows', [0, 1, 3, 8, 16])
+@pytest.mark.parametrize('which', ['pole caps', 'ragged'])
+def test_wave_per_long_row_windows_through_lds(dev, which, rows, monkeypatch):
+    """
+    Kernel family 11 (one wave per long row x 64 columns, the source cells of
+    `rows` neighbouring long rows sliding through LDS in windows of 8 x rows
+    cells) is what the long rows take beyond 16 fields; here for EVERY field
+    count and layout, several patch heights (the ragged rows' unions span
+    dozens of windows with a handful of entries each; the pole caps fill
+    every window).  `rows` = 0: family 7 on column-major entries, the path
+    of rounds 3 and 4 before.  The oracle's bits.
+    """
+    from oracle import oracle
+    from pyremap_amd import engine
+    monkeypatch.setattr(engine, 'LONG_WAVE_ROWS', rows)
+    if which == 'pole caps':
+        m, dims = _capped_map()
+        row, col, S, frac_b, n_a, n_b = m.row, m.col, m.S, m.frac_b, \
+            m.n_a, m.n_b
+    else:
+        mm, n_a, n_b, dims = _ragged_long_map(seed=23)
+        row, col, S, frac_b = mm['row'], mm['col'], mm['S'], mm['frac_b']
+    plan = engine.RemapPlan.from_triplets(row, col, S, frac_b, n_a, n_b,
+                                          device=dev)
+    plan.auto_schedule(dims)
+    long = plan._split[1]
+    if rows:
+        assert 1 <= long._wave['rows'] <= rows   # (what the LDS holds)
+        monkeypatch.setattr(engine, 'LONG_WAVE_FIELDS', 0)
+        monkeypatch.setattr(engine, 'LONG_WAVE_MAX', 1 << 30)
+    else:
+        assert long._wave is None
+    rowptr, c, v = plan.to_host_csr()
+    csr = oracle.OracleCSR(rowptr, c, v, (n_b, n_a))
+    rng = np.random.default_rng(rows)
+    for shape, axes in (((n_a,), [0]), ((n_a, 17), [0]), ((n_a, 64), [0]),
+                        ((n_a, 200), [0]), ((70, n_a), [1]),
+                        ((3, n_a, 61), [1]), ((2, n_a, 128), [1])):
+        for dtype in (np.float64, np.float32):
+            x = rng.standard_normal(shape).astype(dtype)
+            holes = x.copy()
+            holes[(slice(None),) * axes[0] + (rng.random(n_a) < 0.2,)] = \
+                np.nan
+            for field, thr in ((x, None), (holes, 0.3), (holes, None)):
+                masked = thr is not None
+                arg = np.ma.masked_array(field, np.isnan(field)) if masked \
+                    else field
+                want = oracle.remap_numpy_array(csr, frac_b, dims, arg, axes,
+                                                thr)
+                got, mask = engine.remap_tensor(
+                    plan, dims, torch.from_numpy(field).to(dev), axes,
+                    engine.MODE_MASKED if masked else engine.MODE_FRACB,
+                    threshold=thr or 0.0, want_mask=True)
+                assert_bitwise(got.cpu().numpy(), np.ma.filled(want, np.nan),
+                               f'{rows} rows {shape} {dtype.__name__} {thr}')
+                assert np.array_equal(mask.cpu().numpy().astype(bool),
+                                      np.ma.getmaskarray(want))
+    # two source axes with another dim between them (x_src_fold)
+    lat = 50 if which == 'ragged' else dims[0] // 2
+    x = rng.standard_normal((lat, 40, n_a // lat))
+    want = oracle.remap_numpy_array(csr, frac_b, dims, x, [0, 2], None)
+    got = engine.remap_tensor(plan, dims, torch.from_numpy(x).to(dev),
+                              [0, 2], engine.MODE_FRACB)
+    assert_bitwise(got.cpu().numpy(), np.ma.filled(want, np.nan),
+                   f'{rows} rows (lat, M, lon)')
+    # REMAP_FLAG_FMA: fused multiply-adds, within rounding of the oracle
+    x = rng.standard_normal((n_a, 96))
+    want = oracle.remap_numpy_array(csr, frac_b, dims, x, [0], None)
+    got = engine.remap_tensor(plan, dims, torch.from_numpy(x).to(dev), [0],
+                              engine.MODE_FRACB, flags=engine.FLAG_FMA)
+    np.testing.assert_allclose(got.cpu().numpy(), np.ma.filled(want, np.nan),
+                               rtol=1e-12, atol=1e-13)
+
+
 def test_pole_capped_map_through_the_remapper(dev, tmp_path):
     """build_map (ESMF's bilinear, pole caps and all) -> remap_numpy /
     ncremap: the Dataset path on a split plan, against the oracle; the

@@ -39,12 +39,17 @@ def main():
     ap.add_argument('--workload', default='config1_esmf')
     ap.add_argument('--wave-fields', type=int, default=None,
                     help='engine.LONG_WAVE_FIELDS (family 9 up to that K)')
+    ap.add_argument('--wave-rows', type=int, default=None,
+                    help='engine.LONG_WAVE_ROWS (long rows per workgroup of '
+                         'family 11; 0: family 7 beyond --wave-fields)')
     args = ap.parse_args()
     import torch
 
     from pyremap_amd import engine, synthetic
     if args.wave_fields is not None:
         engine.LONG_WAVE_FIELDS = args.wave_fields
+    if args.wave_rows is not None:
+        engine.LONG_WAVE_ROWS = args.wave_rows
     dev = torch.device('cuda', 0)
     m = synthetic.make_config(args.workload, device=dev)
     plan = engine.RemapPlan.from_triplets(m.row, m.col, m.S, m.frac_b, m.n_a,
