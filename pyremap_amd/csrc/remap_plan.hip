@@ -666,7 +666,10 @@ int prepare_short_runs(remap_plan *plan, hipStream_t stream)
         REMAP_HIP_CHECK(hipMemcpyAsync(h, stats, 24, hipMemcpyDeviceToHost,
                                        stream));
         REMAP_HIP_CHECK(hipStreamSynchronize(stream));
-        if (h[1] <= kCellUmax || ty * tx <= 16)
+        // coarse -> fine (fewer than half as many staged source cells as
+        // rows): 256-row patches (engine.RemapPlan.cell_patches)
+        const bool dst_heavy = ty * tx > 256 && 2 * h[1] < (int64_t)ty * tx;
+        if ((h[1] <= kCellUmax || ty * tx <= 16) && !dst_heavy)
             break;
         if (tx >= ty && tx > 1)
             tx /= 2;

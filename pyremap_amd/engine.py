@@ -962,10 +962,24 @@ class RemapPlan:
                     self.n_b < 128 * tile[0] * tile[1]:
                 tile = (tile[0], tile[1] // 2) if tile[1] >= tile[0] else \
                     (tile[0] // 2, tile[1])
-            q = self._make_patches(
-                dims, tile if dims is not None else (1, tile[0] * tile[1]),
-                lambda rows, umax, emax: umax <= self.CELL_UMAX or
-                rows <= 16, 1024)
+            def build(tile):
+                return self._make_patches(
+                    dims, tile if dims is not None
+                    else (1, tile[0] * tile[1]),
+                    lambda rows, umax, emax: umax <= self.CELL_UMAX or
+                    rows <= 16, 1024)
+            q = build(tile)
+            # coarse -> fine (a patch stages fewer than half as many source
+            # cells as it has rows): the output stores are the work, and
+            # four 256-thread workgroups do them sooner than one of 1 024 --
+            # 1 deg -> 0.5 deg bilinear, short rows, (12, n) 20.3 -> 17.3 us,
+            # (120, n) float32 75.8 -> 71.9
+            if q is not None and q['rows'] > 256 and \
+                    2 * q['umax'] < q['rows']:
+                ty, tx = q['tile']
+                while ty * tx > 256:
+                    ty, tx = (ty, tx // 2) if tx >= ty else (ty // 2, tx)
+                q = build((ty, tx))
             self._cell = q if q is not None else False
             self._sched_version += 1
         return self._cell or None

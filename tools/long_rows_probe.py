@@ -42,12 +42,17 @@ def main():
     ap.add_argument('--wave-rows', type=int, default=None,
                     help='engine.LONG_WAVE_ROWS (long rows per workgroup of '
                          'family 11; 0: family 7 beyond --wave-fields)')
+    ap.add_argument('--tile', default=None,
+                    help='engine.RemapPlan.CELL_TILE, e.g. 16x16')
     args = ap.parse_args()
     import torch
 
     from pyremap_amd import engine, synthetic
     if args.wave_fields is not None:
         engine.LONG_WAVE_FIELDS = args.wave_fields
+    if args.tile:
+        engine.RemapPlan.CELL_TILE = tuple(int(v)
+                                           for v in args.tile.split('x'))
     if args.wave_rows is not None:
         engine.LONG_WAVE_ROWS = args.wave_rows
     dev = torch.device('cuda', 0)
