@@ -58,6 +58,13 @@ struct remap_plan {
     int64_t *long_base = nullptr;
     int32_t long_rows = 0, long_umax = 0, long_emax = 0;
     int64_t long_patches = 0;
+    // the long rows once more as a ROW-MAJOR patch plan of a few consecutive
+    // rows per patch: kernel family 11 (spmm_longwave.h), 17 ... 128 fields
+    int32_t *wave_ptr = nullptr, *wave_ucol = nullptr, *wave_prow = nullptr,
+            *wave_lidx = nullptr;
+    double *wave_val = nullptr;
+    int32_t wave_rows = 0, wave_umax = 0, wave_emax = 0;
+    int64_t wave_patches = 0;
 };
 
 namespace remap {
@@ -166,6 +173,10 @@ __global__ __launch_bounds__(256) void column_major_kernel(
 constexpr int64_t kLongRow = 96;
 // LDS the lanes-across-rows kernel may take (kPatchLdsMax), 4 fields a lane
 constexpr int64_t kLongUmax = 160 * 1024 / (4 * 8) - 2;
+// long rows per workgroup of family 11 (engine.LONG_WAVE_ROWS) and the most
+// fields it takes (engine.LONG_WAVE_MAX)
+constexpr int64_t kWaveRows = 6;
+constexpr int64_t kWaveMaxFields = 128;
 
 // Mappings whose few long rows hold a large share of the entries (the pole
 // caps of a global bilinear map as ESMF makes it): the plan keeps the mapping
@@ -373,6 +384,60 @@ int split_long_rows(remap_plan *plan, Owned &own,
     REMAP_HIP_CHECK(hipStreamSynchronize(stream));
     own.free_now(pl);
     own.free_now(pv);
+    // ... and row-major, kWaveRows consecutive long rows per patch (fewer
+    // when their records would not fit the LDS beside the windows: per row
+    // two windows of 8 cells x 512 bytes + 12 bytes per record, see
+    // run_longwave): family 11 (engine.LONG_WAVE_ROWS has the measurements)
+    {
+        const int64_t per_row =
+            2 * 8 * 512 + ((long_max + 15) / 16 * 16 + 16) * 12;
+        int64_t wr = 160 * 1024 / per_row;
+        if (wr > kWaveRows)
+            wr = kWaveRows;
+        if (wr >= 1) {
+            void *w_ptr = nullptr, *w_ucol = nullptr, *w_prow = nullptr,
+                 *w_lidx = nullptr, *w_val = nullptr;
+            const int64_t n_wp = (n_long + wr - 1) / wr;
+            if ((rc = own.alloc(&w_ptr, static_cast<size_t>(n_wp + 1) * 4)) !=
+                    REMAP_OK ||
+                (rc = own.alloc(&w_ucol,
+                                static_cast<size_t>(long_nnz) * 4)) !=
+                    REMAP_OK ||
+                (rc = own.alloc(&w_prow,
+                                static_cast<size_t>(n_long + 1) * 4)) !=
+                    REMAP_OK ||
+                (rc = own.alloc(&w_lidx,
+                                static_cast<size_t>(long_nnz) * 4)) !=
+                    REMAP_OK ||
+                (rc = own.alloc(&w_val, static_cast<size_t>(long_nnz) * 8)) !=
+                    REMAP_OK)
+                return rc;
+            rc = remap_patches_build(
+                &A, nullptr, 0, 1, static_cast<int32_t>(wr), nullptr,
+                static_cast<int32_t *>(w_ptr), static_cast<int32_t *>(w_ucol),
+                static_cast<int32_t *>(w_prow),
+                static_cast<int32_t *>(w_lidx), static_cast<double *>(w_val),
+                static_cast<int64_t *>(stats), ws, ws_bytes, stream);
+            if (rc != REMAP_OK)
+                return rc;
+            int64_t hw[3] = {0, 0, 0};
+            REMAP_HIP_CHECK(hipMemcpyAsync(hw, stats, 24,
+                                           hipMemcpyDeviceToHost, stream));
+            REMAP_HIP_CHECK(hipStreamSynchronize(stream));
+            plan->wave_ptr = static_cast<int32_t *>(w_ptr);
+            plan->wave_ucol = static_cast<int32_t *>(w_ucol);
+            plan->wave_prow = static_cast<int32_t *>(w_prow);
+            plan->wave_lidx = static_cast<int32_t *>(w_lidx);
+            plan->wave_val = static_cast<double *>(w_val);
+            plan->wave_rows = static_cast<int32_t>(wr);
+            plan->wave_umax = static_cast<int32_t>(hw[1]);
+            plan->wave_emax = static_cast<int32_t>(hw[2]);
+            plan->wave_patches = n_wp;
+            plan->device_bytes += static_cast<size_t>(n_wp + 1) * 4 +
+                                  static_cast<size_t>(n_long + 1) * 4 +
+                                  static_cast<size_t>(long_nnz) * 16;
+        }
+    }
     own.free_now(ws);
     own.free_now(stats);
     // the plan's CSR becomes the mapping without the long rows' entries
@@ -584,7 +649,12 @@ int create(int64_t n_b, int64_t n_a, int64_t n_s, const int32_t *row,
                     static_cast<void *>(plan->long_prow),
                     static_cast<void *>(plan->long_lidx),
                     static_cast<void *>(plan->long_pval),
-                    static_cast<void *>(plan->long_base)})
+                    static_cast<void *>(plan->long_base),
+                    static_cast<void *>(plan->wave_ptr),
+                    static_cast<void *>(plan->wave_ucol),
+                    static_cast<void *>(plan->wave_prow),
+                    static_cast<void *>(plan->wave_lidx),
+                    static_cast<void *>(plan->wave_val)})
         if (q)
             own.release(q);
     plan->device_bytes +=
@@ -747,7 +817,12 @@ void remap_plan_destroy(remap_plan *plan)
                     static_cast<void *>(plan->long_prow),
                     static_cast<void *>(plan->long_lidx),
                     static_cast<void *>(plan->long_pval),
-                    static_cast<void *>(plan->long_base)})
+                    static_cast<void *>(plan->long_base),
+                    static_cast<void *>(plan->wave_ptr),
+                    static_cast<void *>(plan->wave_ucol),
+                    static_cast<void *>(plan->wave_prow),
+                    static_cast<void *>(plan->wave_lidx),
+                    static_cast<void *>(plan->wave_val)})
         if (p)
             (void)hipFree(p);
     if (switched)
@@ -918,6 +993,20 @@ int remap_plan_apply(const remap_plan *plan, const remap_field *f,
     const int64_t K = static_cast<int64_t>(f->n_batch) * f->k_inner;
     if (K <= 16) {
         b.tune[0] = 9;
+    } else if (K <= remap::kWaveMaxFields && plan->wave_ptr) {
+        // 17 ... 128 fields: a wave per long row, the cells a few rows
+        // share sliding through LDS (family 11)
+        b.patch_ptr = plan->wave_ptr;
+        b.patch_ucol = plan->wave_ucol;
+        b.patch_rowptr = plan->wave_prow;
+        b.patch_lidx = plan->wave_lidx;
+        b.patch_val = plan->wave_val;
+        b.patch_rows = plan->wave_rows;
+        b.patch_umax = plan->wave_umax;
+        b.patch_emax = plan->wave_emax;
+        b.n_patches = plan->wave_patches;
+        b.patch_ell_base = nullptr;
+        b.tune[0] = 11;
     } else {
         b.tune[0] = 7;
         b.tune[1] = K <= 128 ? 2 : 4;

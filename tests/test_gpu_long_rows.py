@@ -379,9 +379,11 @@ def test_plan_handle_applies_long_rows_apart(dev, which):
         for prepared in (False, True):
             if prepared:
                 assert lib.remap_plan_prepare_short_runs(handle, stream) == 0
+            # (1, 12 fields: family 9; 30 ... 128: family 11; 200: family 7)
             for shape, axis in (((n_a, 1), 0), ((n_a, 12), 0),
                                 ((n_a, 200), 0), ((30, n_a), 1),
-                                ((4, n_a, 9), 1)):
+                                ((4, n_a, 9), 1), ((n_a, 64), 0),
+                                ((2, n_a, 64), 1)):
                 for dtype in (np.float64, np.float32):
                     x = rng.standard_normal(shape).astype(dtype)
                     x[(slice(None),) * axis + (rng.random(n_a) < 0.2,)] = \
