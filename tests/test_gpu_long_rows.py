@@ -244,6 +244,48 @@ def test_wave_per_long_row_windows_through_lds(dev, which, rows, monkeypatch):
                                rtol=1e-12, atol=1e-13)
 
 
+def test_bench_pole_cap_map_at_full_size(dev, monkeypatch):
+    """`config1_esmf` (the bench's 1 deg -> 0.5 deg map with pole caps: 1 440
+    rows of 360 entries) at its full size, the field counts of the bench
+    rows and their neighbours: the default route (families 9 / 11 / 7 for
+    the long rows by field count) against the oracle, bit for bit, and --
+    the same bits -- with family 11 switched off."""
+    from oracle import oracle
+    from pyremap_amd import engine, synthetic
+    m = synthetic.make_config('config1_esmf', device=dev)
+    plans = []
+    for rows in (engine.LONG_WAVE_ROWS, 0):
+        monkeypatch.setattr(engine, 'LONG_WAVE_ROWS', rows)
+        plan = engine.RemapPlan.from_triplets(m.row, m.col, m.S, m.frac_b,
+                                              m.n_a, m.n_b, index_base=1,
+                                              device=dev)
+        choice = plan.auto_schedule(m.dst_dims)
+        assert choice['long_rows'] == 1440
+        plans.append(plan)
+    assert plans[0]._split[1]._wave['rows'] == 6
+    assert plans[1]._split[1]._wave is None
+    rowptr, c, v = plans[0].to_host_csr()
+    csr = oracle.OracleCSR(rowptr, c, v, (m.n_b, m.n_a))
+    frac_b = m.frac_b.cpu().numpy()
+    rng = np.random.default_rng(0)
+    for shape, axes in (((m.n_a,), [0]), ((m.n_a, 17), [0]),
+                        ((m.n_a, 64), [0]), ((m.n_a, 128), [0]),
+                        ((m.n_a, 129), [0]), ((12, m.n_a), [1]),
+                        ((2, m.n_a, 60), [1])):
+        x = rng.standard_normal(shape)
+        x[(slice(None),) * axes[0] + (rng.random(m.n_a) < 0.1,)] = np.nan
+        for thr in (None, 0.2):
+            arg = x if thr is None else np.ma.masked_array(x, np.isnan(x))
+            want = np.ma.filled(oracle.remap_numpy_array(
+                csr, frac_b, m.dst_dims, arg, axes, thr), np.nan)
+            for plan in plans:
+                got = engine.remap_tensor(
+                    plan, m.dst_dims, torch.from_numpy(x).to(dev), axes,
+                    engine.MODE_FRACB if thr is None else engine.MODE_MASKED,
+                    threshold=thr or 0.0)
+                assert_bitwise(got.cpu().numpy(), want, f'{shape} thr {thr}')
+
+
 def test_pole_capped_map_through_the_remapper(dev, tmp_path):
     """build_map (ESMF's bilinear, pole caps and all) -> remap_numpy /
     ncremap: the Dataset path on a split plan, against the oracle; the
