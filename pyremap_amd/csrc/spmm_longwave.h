@@ -66,8 +66,8 @@ __device__ __forceinline__ double lds_read_f64(uint32_t addr)
 // four 16-lane rows): ALL the LDS reads first, then the products added in
 // order.  FULL: every record counts.  Otherwise records [j0, j1) count
 // (window borders, row tails): the others are read all the same -- wherever
-// their offsets point; LDS reads beyond the allocation return 0 -- and their
-// sums dropped behind a wave-uniform test.
+// their (512-byte aligned) offsets point; LDS reads beyond the allocation
+// return 0 -- and their sums dropped behind a wave-uniform test.
 template <int MODE, bool FMA, bool FULL>
 struct LongBatch {
     template <int J>
@@ -108,8 +108,8 @@ struct LongBatch {
     {
         double x[16];
         reads<0>(off, mine, x);
-        // (left alone hipcc keeps three reads ahead of the sums: an LDS
-        // round trip per entry shows)
+        // (left alone hipcc keeps three reads ahead of the sums; sixteen
+        // measured the same -- the sums are issue-bound -- and cost nothing)
         asm volatile("" ::: "memory");
         sums<0>(w, x, j0, j1, acc, den);
     }
@@ -232,8 +232,10 @@ __global__ __launch_bounds__(kPatchBlock) void spmm_longwave(
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
+            // (the last batch of 16 is read whole: the records behind the
+            // row's end repeat its last one -- aligned offsets, never summed)
             const int r = k + u * kWave + lane;
-            if (r < n) {
+            if (r < ((n + 15) & ~15)) {
                 eoff[r] = static_cast<uint32_t>(li[u]) * kLongCellBytes;
                 ew[r] = w[u];
             }
