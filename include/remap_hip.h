@@ -573,16 +573,22 @@ int remap_plan_create(int64_t n_b, int64_t n_a, int64_t n_s,
                       int32_t n_dims, void *stream, remap_plan **plan_out);
 /*
  * Optional, once per plan, before fields whose contiguous run behind the
- * source axes is short and that come in several batches -- (Time, nCells),
- * MPAS's 2-D time series, the reference's most common input
- * (tests/test_interpolate.py:57-59; k_inner < 4 and n_batch > 1): builds the
- * patch plan of the LDS-staged lanes-across-rows kernel (16 x 16 tiles of the
- * destination grid, halved until no patch references more than 512 distinct
- * source cells), which remap_plan_apply then uses for such fields.  Without
- * it they take the unstaged lanes-across-rows kernel (2.5 x slower on
- * EC30to60 -> 0.5 degree at Time = 120).  Allocates device memory
- * (remap_plan_apply never does) and synchronises `stream`; a second call
- * does nothing.
+ * source axes is short and that come in several batches:
+ *   (Time, nCells), MPAS's 2-D time series, the reference's most common
+ *   input (tests/test_interpolate.py:57-59; k_inner < 4 and n_batch > 1):
+ *   builds the patch plan of the LDS-staged lanes-across-rows kernel (32 x 32
+ *   tiles of the destination grid -- 16 x 16 on grids under 128 K cells and
+ *   on coarse-to-fine maps -- halved until no patch references more than
+ *   2 046 distinct source cells), which remap_plan_apply then uses for such
+ *   fields.  Without it they take the unstaged lanes-across-rows kernel
+ *   (2.5 x slower on EC30to60 -> 0.5 degree at Time = 120);
+ *   (Time, nCells, 4 ... 15 levels) on mappings scheduled as row groups:
+ *   two more patch plans -- 16 x 16 tiles for the batch-at-a-time kernel
+ *   (4 ... 6 levels), 4 x 8 tiles for the LDS patch kernel (7 ... 15) --
+ *   1.3-1.9 x faster than the row groups on such runs.
+ * Each plan takes 16 bytes per entry of the mapping.  Allocates device
+ * memory (remap_plan_apply never does) and synchronises `stream`; a second
+ * call does nothing.
  */
 int remap_plan_prepare_short_runs(remap_plan *plan, void *stream);
 void remap_plan_destroy(remap_plan *plan);

@@ -43,6 +43,19 @@ struct remap_plan {
     double *cell_val = nullptr;
     int32_t cell_rows = 0, cell_umax = 0, cell_emax = 0;
     int64_t cell_patches = 0;
+    // ... and, for mappings scheduled as row groups, the two patch plans
+    // that serve (Time, nCells, 4 ... 15 levels): 256-row patches for the
+    // batch-at-a-time kernel (4 <= L <= 6, engine.RemapPlan.run_cells) and
+    // small LDS patches for family 5 (7 <= L < 16, run_patches)
+    struct PatchSet {
+        void *arena = nullptr;
+        int32_t *order = nullptr, *ptr = nullptr, *ucol = nullptr,
+                *rowptr = nullptr, *lidx = nullptr;
+        double *val = nullptr;
+        int32_t rows = 0, umax = 0, emax = 0;
+        int64_t n = 0;
+    };
+    PatchSet run_cells, runs;
     // LONG ROWS APART (split_long_rows): rowptr / col / val above then hold
     // the mapping WITHOUT its long rows' entries (schedule and short-run
     // patches are built on that), the long rows live here: their CSR, the
@@ -675,12 +688,14 @@ constexpr int64_t kCellUmax = 2046;
 
 size_t align256(size_t n) { return (n + 255) / 256 * 256; }
 
-int prepare_short_runs(remap_plan *plan, hipStream_t stream)
+// one patch plan of the mapping without its long rows: tiles ty x tx of the
+// destination grid, halved until fits(rows, umax, emax)
+template <typename Fits>
+int build_patch_set(remap_plan *plan, int32_t ty, int32_t tx, Fits fits,
+                    bool dst_heavy_rule, remap_plan::PatchSet &out,
+                    hipStream_t stream)
 {
-    // (a split plan: the mapping without its long rows' entries)
     const int64_t nnz = plan->nnz - plan->long_nnz;
-    if (plan->cell_arena || nnz == 0 || plan->n_b == 0)
-        return REMAP_OK;
     const int64_t n_b = plan->n_b;
     Owned own;
     size_t ws_bytes = 0;
@@ -711,15 +726,6 @@ int prepare_short_runs(remap_plan *plan, hipStream_t stream)
     A.max_row_nnz = plan->max_row_nnz;
     A.csr_pad = kCsrPad;
     const bool two_d = plan->n_dims == 2;
-    int32_t ty = two_d ? 32 : 1, tx = two_d ? 32 : 1024;
-    // small grids: smaller tiles, so that there still are a few hundred
-    // workgroups
-    while ((int64_t)ty * tx > 256 && n_b < (int64_t)128 * ty * tx) {
-        if (tx >= ty)
-            tx /= 2;
-        else
-            ty /= 2;
-    }
     int64_t h[3] = {0, 0, 0};
     for (;;) {
         rc = remap_patches_build(
@@ -738,28 +744,100 @@ int prepare_short_runs(remap_plan *plan, hipStream_t stream)
         REMAP_HIP_CHECK(hipStreamSynchronize(stream));
         // coarse -> fine (fewer than half as many staged source cells as
         // rows): 256-row patches (engine.RemapPlan.cell_patches)
-        const bool dst_heavy = ty * tx > 256 && 2 * h[1] < (int64_t)ty * tx;
-        if ((h[1] <= kCellUmax || ty * tx <= 16) && !dst_heavy)
+        const bool dst_heavy = dst_heavy_rule && ty * tx > 256 &&
+                               2 * h[1] < (int64_t)ty * tx;
+        if (fits((int64_t)ty * tx, h[1], h[2]) && !dst_heavy)
             break;
+        if (ty * tx == 1)
+            return REMAP_OK;   // nothing fits: the set stays empty
         if (tx >= ty && tx > 1)
             tx /= 2;
         else
             ty /= 2;
     }
-    plan->cell_arena = arena;
+    out.arena = arena;
     own.release(arena);
-    plan->cell_order =
-        two_d ? reinterpret_cast<int32_t *>(base + o_order) : nullptr;
-    plan->cell_ptr = reinterpret_cast<int32_t *>(base + o_ptr);
-    plan->cell_ucol = reinterpret_cast<int32_t *>(base + o_ucol);
-    plan->cell_rowptr = reinterpret_cast<int32_t *>(base + o_rowptr);
-    plan->cell_lidx = reinterpret_cast<int32_t *>(base + o_lidx);
-    plan->cell_val = reinterpret_cast<double *>(base + o_val);
-    plan->cell_rows = ty * tx;
-    plan->cell_umax = static_cast<int32_t>(h[1]);
-    plan->cell_emax = static_cast<int32_t>(h[2]);
-    plan->cell_patches = (n_b + plan->cell_rows - 1) / plan->cell_rows;
+    out.order = two_d ? reinterpret_cast<int32_t *>(base + o_order) : nullptr;
+    out.ptr = reinterpret_cast<int32_t *>(base + o_ptr);
+    out.ucol = reinterpret_cast<int32_t *>(base + o_ucol);
+    out.rowptr = reinterpret_cast<int32_t *>(base + o_rowptr);
+    out.lidx = reinterpret_cast<int32_t *>(base + o_lidx);
+    out.val = reinterpret_cast<double *>(base + o_val);
+    out.rows = ty * tx;
+    out.umax = static_cast<int32_t>(h[1]);
+    out.emax = static_cast<int32_t>(h[2]);
+    out.n = (n_b + out.rows - 1) / out.rows;
     plan->device_bytes += total;
+    return REMAP_OK;
+}
+
+int prepare_short_runs(remap_plan *plan, hipStream_t stream)
+{
+    // (a split plan: the mapping without its long rows' entries)
+    const int64_t nnz = plan->nnz - plan->long_nnz;
+    if (plan->cell_arena || nnz == 0 || plan->n_b == 0)
+        return REMAP_OK;
+    const int64_t n_b = plan->n_b;
+    const bool two_d = plan->n_dims == 2;
+    int32_t ty = two_d ? 32 : 1, tx = two_d ? 32 : 1024;
+    // small grids: smaller tiles, so that there still are a few hundred
+    // workgroups
+    while ((int64_t)ty * tx > 256 && n_b < (int64_t)128 * ty * tx) {
+        if (tx >= ty)
+            tx /= 2;
+        else
+            ty /= 2;
+    }
+    remap_plan::PatchSet cell;
+    int rc = build_patch_set(
+        plan, ty, tx,
+        [](int64_t rows, int64_t umax, int64_t) {
+            return umax <= kCellUmax || rows <= 16;
+        },
+        true, cell, stream);
+    if (rc != REMAP_OK)
+        return rc;
+    if (!cell.arena)
+        return REMAP_OK;
+    // mappings scheduled as row groups: the patch plans of the short LEVEL
+    // runs, (Time, nCells, 4 ... 15) -- engine.RemapPlan.run_cells /
+    // run_patches have the measurements
+    if (plan->sched.family == 10) {
+        rc = build_patch_set(
+            plan, two_d ? 16 : 1, two_d ? 16 : 256,
+            [](int64_t rows, int64_t umax, int64_t) {
+                return umax <= 510 || rows <= 16;
+            },
+            false, plan->run_cells, stream);
+        if (rc == REMAP_OK)
+            rc = build_patch_set(
+                plan, two_d ? 4 : 1, two_d ? 8 : 32,
+                [](int64_t rows, int64_t umax, int64_t emax) {
+                    return (umax + 1) * 1024 + emax * 12 + rows * 24 + 32 <=
+                               100 * 1024 ||
+                           rows <= 4;
+                },
+                false, plan->runs, stream);
+        if (rc != REMAP_OK) {
+            (void)hipFree(cell.arena);
+            if (plan->run_cells.arena)
+                (void)hipFree(plan->run_cells.arena);
+            plan->run_cells = remap_plan::PatchSet();
+            plan->runs = remap_plan::PatchSet();
+            return rc;
+        }
+    }
+    plan->cell_arena = cell.arena;
+    plan->cell_order = cell.order;
+    plan->cell_ptr = cell.ptr;
+    plan->cell_ucol = cell.ucol;
+    plan->cell_rowptr = cell.rowptr;
+    plan->cell_lidx = cell.lidx;
+    plan->cell_val = cell.val;
+    plan->cell_rows = cell.rows;
+    plan->cell_umax = cell.umax;
+    plan->cell_emax = cell.emax;
+    plan->cell_patches = cell.n;
     return REMAP_OK;
 }
 
@@ -807,7 +885,8 @@ void remap_plan_destroy(remap_plan *plan)
                     static_cast<void *>(plan->col),
                     static_cast<void *>(plan->val),
                     static_cast<void *>(plan->frac_b), plan->arena,
-                    plan->cell_arena,
+                    plan->cell_arena, plan->run_cells.arena,
+                    plan->runs.arena,
                     static_cast<void *>(plan->long_rowptr),
                     static_cast<void *>(plan->long_col),
                     static_cast<void *>(plan->long_val),
@@ -917,6 +996,35 @@ int remap_plan_apply(const remap_plan *plan, const remap_field *f,
         a.tune[0] = 7;
         a.tune[1] = 4;   // (workgroup persistent over a run of chunks:
                          // spmm_patchtime; engine.apply_strided)
+        a.flags |= REMAP_FLAG_TUNE_HINT;
+    } else if (s.family == 10 && f->n_batch > 1 && f->k_inner >= 4 &&
+               f->k_inner < 16 && f->n_batch * f->k_inner >= 64 &&
+               (f->k_inner <= 6 ? plan->run_cells.arena != nullptr
+                                : plan->runs.arena != nullptr)) {
+        // short LEVEL runs in several batches on a row-group mapping:
+        // 4 ... 6 levels a batch at a time on 256-row patches
+        // (spmm_patchtime<..., RUNS>), 7 ... 15 on small LDS patches
+        // (family 5) -- engine.apply_strided
+        const remap_plan::PatchSet &q =
+            f->k_inner <= 6 ? plan->run_cells : plan->runs;
+        a.row_order = q.order;
+        a.patch_ptr = q.ptr;
+        a.patch_ucol = q.ucol;
+        a.patch_rowptr = q.rowptr;
+        a.patch_lidx = q.lidx;
+        a.patch_val = q.val;
+        a.patch_rows = q.rows;
+        a.patch_umax = q.umax;
+        a.patch_emax = q.emax;
+        a.patch_row_bytes = 1024;
+        a.n_patches = q.n;
+        if (f->k_inner <= 6) {
+            a.tune[0] = 7;
+            a.tune[1] = 4;
+            a.tune[2] = 2;
+        } else {
+            a.tune[0] = 5;
+        }
         a.flags |= REMAP_FLAG_TUNE_HINT;
     } else if (s.family != 0) {
         a.row_order = s.row_order;

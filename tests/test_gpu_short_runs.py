@@ -468,3 +468,70 @@ def test_plan_handle_large_grid_takes_the_large_patches(dev):
                            torch.nan_to_num(want, nan=-2.0).reshape(-1))
     finally:
         lib.remap_plan_destroy(handle)
+
+
+def test_plan_handle_short_level_runs(dev):
+    """The opaque C plan handle on a row-group mapping, `(Time, nCells, L)`
+    with 4 <= L < 16: once `remap_plan_prepare_short_runs` has run it takes
+    the same routes as the Python layer (batch-at-a-time kernel up to 6
+    levels, small LDS patches beyond) -- the oracle's bits, masked and not,
+    before and after preparing; 16 levels keep the row groups."""
+    import ctypes
+    from oracle import oracle
+    from pyremap_amd import engine
+    grid = (50, 80)
+    m, plan, csr, frac_b, choice = _problem(dev, grid)
+    assert choice['family'] == 'rowgroup'
+    mm = m.numpy()
+    lib = engine.load_library()
+    handle = ctypes.c_void_p()
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    dims = (ctypes.c_int64 * 2)(*grid)
+
+    def host(a, t):
+        return np.ascontiguousarray(a, dtype=t).ctypes.data
+
+    assert lib.remap_plan_create(
+        m.n_b, m.n_a, len(mm['S']), host(mm['row'], np.int32),
+        host(mm['col'], np.int32), host(mm['S'], np.float64), 1,
+        host(mm['frac_b'], np.float64), 1, dims, 2, stream,
+        ctypes.byref(handle)) == 0, lib.remap_last_error()
+    rng = np.random.default_rng(3)
+    try:
+        for prepared in (False, True):
+            if prepared:
+                assert lib.remap_plan_prepare_short_runs(handle, stream) == 0
+            for T, L in ((20, 4), (13, 6), (11, 7), (9, 10), (5, 15),
+                         (4, 16)):
+                for dtype in (np.float64, np.float32):
+                    x = rng.standard_normal((T, m.n_a, L)).astype(dtype)
+                    x[:, rng.random(m.n_a) < 0.15, :] = np.nan
+                    for masked in (False, True):
+                        arg = np.ma.masked_array(x, np.isnan(x)) if masked \
+                            else x
+                        want = np.ma.filled(oracle.remap_numpy_array(
+                            csr, frac_b, grid, arg, [1],
+                            0.1 if masked else None), np.nan)
+                        xd = torch.from_numpy(x).to(dev)
+                        y = torch.empty((T, m.n_b, L), dtype=torch.float64,
+                                        device=dev)
+                        f = engine._Field()
+                        f.X, f.Y = xd.data_ptr(), y.data_ptr()
+                        f.x_dtype = engine.DTYPE_F32 if dtype == np.float32 \
+                            else engine.DTYPE_F64
+                        f.mode = engine.MODE_MASKED if masked \
+                            else engine.MODE_FRACB
+                        f.threshold = 0.1 if masked else 0.0
+                        f.n_batch, f.k_inner = T, L
+                        f.x_row_stride, f.x_batch_stride = L, m.n_a * L
+                        f.y_row_stride, f.y_batch_stride = L, m.n_b * L
+                        assert lib.remap_plan_apply(
+                            handle, ctypes.byref(f), stream) == 0, \
+                            lib.remap_last_error()
+                        torch.cuda.synchronize()
+                        assert_bitwise(
+                            y.cpu().numpy().reshape(want.shape), want,
+                            f'prepared {prepared} ({T}, n, {L}) '
+                            f'{dtype.__name__} masked {masked}')
+    finally:
+        lib.remap_plan_destroy(handle)
