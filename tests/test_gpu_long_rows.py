@@ -464,3 +464,42 @@ def test_plan_handle_applies_long_rows_apart(dev, which):
                             f'{masked} prepared {prepared}')
     finally:
         lib.remap_plan_destroy(handle)
+
+
+def test_unsorted_long_rows_keep_the_lanes_across_rows_kernel(dev):
+    """Family 11 walks a row's entries window by window and needs them sorted
+    by source cell.  A CSR handed over with UNSORTED rows (a caller's own
+    arrays: `RemapPlan(...)` takes them as they are; scipy sums in the order
+    it is given, so do the kernels) gets no family-11 plan: the long rows
+    stay on family 7, and the results are the oracle's on that very order."""
+    from oracle import oracle
+    from pyremap_amd import engine
+    mm, n_a, n_b, dims = _ragged_long_map(seed=31)
+    sorted_plan = engine.RemapPlan.from_triplets(
+        mm['row'], mm['col'], mm['S'], mm['frac_b'], n_a, n_b, device=dev)
+    rowptr, col, val = (t.copy() for t in sorted_plan.to_host_csr())
+    rng = np.random.default_rng(1)
+    for r in range(n_b):       # shuffle inside every long row
+        s, e = int(rowptr[r]), int(rowptr[r + 1])
+        if e - s > 96:
+            perm = rng.permutation(e - s)
+            col[s:e] = col[s:e][perm]
+            val[s:e] = val[s:e][perm]
+    pad = engine.CSR_PAD
+    plan = engine.RemapPlan(
+        n_a, n_b, torch.from_numpy(rowptr).to(dev),
+        torch.from_numpy(np.concatenate([col, np.zeros(pad, col.dtype)]))
+        .to(dev),
+        torch.from_numpy(np.concatenate([val, np.zeros(pad)])).to(dev),
+        torch.from_numpy(mm['frac_b']).to(dev))
+    plan.auto_schedule(dims)
+    assert plan._split is not None and plan._split[1]._wave is None
+    assert sorted_plan.auto_schedule(dims) and \
+        sorted_plan._split[1]._wave is not None
+    csr = oracle.OracleCSR(rowptr, col, val, (n_b, n_a))
+    x = rng.standard_normal((n_a, 64))
+    want = np.ma.filled(oracle.remap_numpy_array(csr, mm['frac_b'], dims, x,
+                                                 [0], None), np.nan)
+    got = engine.remap_tensor(plan, dims, torch.from_numpy(x).to(dev), [0],
+                              engine.MODE_FRACB)
+    assert_bitwise(got.cpu().numpy(), want, 'unsorted long rows')
