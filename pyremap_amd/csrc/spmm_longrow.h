@@ -21,9 +21,9 @@
 //             entry -- without a trip to memory in it.
 // 1 440 rows x K / TT waves fill the chip; a 362-entry row takes ~3 us.
 // LDS per wave: TT x entries x 8 bytes -- every staged value is used
-// once, so for MANY fields the LDS capacity becomes the bound and family 7
-// (which stages the source cells 256 rows share once) takes over
-// (engine.apply_strided).
+// once, so for MANY fields the LDS capacity becomes the bound and the
+// families that stage what neighbouring long rows SHARE take over: 11
+// (spmm_longwave.h, 17-128 fields) and 7 (more) -- engine.apply_strided.
 //
 // `A` holds the long rows only: its row r is work slot r; row_order[r] (if
 // given) names the row of Y / frac_b / mask_out it writes.
