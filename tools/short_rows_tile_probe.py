@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
-"""The SHORT rows of the pole-capped 1 deg -> 0.5 deg bilinear map
-(config1_esmf) through the LDS patch kernel (family 5) on patch plans of
-several tile sizes: us per launch replayed from a hipGraph, (n, K) fields.
-GPU box only."""
+"""A mapping scheduled as LDS patches (family 5) -- by default the SHORT rows
+of the pole-capped 1 deg -> 0.5 deg bilinear map, config1_esmf -- on patch
+plans of several tile sizes: us per launch replayed from a hipGraph, (n, K)
+fields.  GPU box only.
+
+    python tools/short_rows_tile_probe.py [workload [K,K,...]]"""
 import json
 import os
 import sys
@@ -17,13 +19,16 @@ from pyremap_amd import engine, synthetic  # noqa: E402
 
 def main():
     dev = torch.device('cuda', 0)
-    m = synthetic.make_config('config1_esmf', device=dev)
+    workload = sys.argv[1] if len(sys.argv) > 1 else 'config1_esmf'
+    ks = [int(v) for v in sys.argv[2].split(',')] if len(sys.argv) > 2 \
+        else [64, 128, 512]
+    m = synthetic.make_config(workload, device=dev)
     plan = engine.RemapPlan.from_triplets(m.row, m.col, m.S, m.frac_b, m.n_a,
                                           m.n_b, index_base=1, device=dev)
     print(json.dumps(plan.auto_schedule(m.dst_dims), default=str))
-    short = plan._split[0]
+    short = plan._split[0] if plan._split else plan
     print('shipped', short.patches['tile'], short.patches['umax'])
-    for K in (64, 128, 512):
+    for K in ks:
         x = torch.randn((m.n_a, K), device=dev, dtype=torch.float64)
         y = engine.remap_tensor(short, m.dst_dims, x, [0], engine.MODE_FRACB)
         ref = y.clone()
