@@ -9,7 +9,9 @@ for bit against the oracle.  Round 3: the source cells numbered along the
 raster, as an MPAS mesh, or at random; `(Time, n)` and `(Time, n, 1..7)`
 fields (the lanes-across-rows kernels); the shard also in its PACKED column
 space on `X[ucols]`; every third seed through a 2- or 3-"device"
-MultiDeviceRemap.
+MultiDeviceRemap.  Round 4: half the seeds also through the opaque C plan
+handle (remap_plan_create / _apply, with and without
+remap_plan_prepare_short_runs) -- its own routing against the same oracle.
 
     python tools/fuzz_medium.py [seconds=480] [first_seed=0]
 """
@@ -29,6 +31,59 @@ from oracle import oracle  # noqa: E402
 from pyremap_amd import engine, synthetic  # noqa: E402
 
 LEVELS = [7, 16, 33, 48, 60, 61, 64, 65, 72, 80, 100, 101, 127, 130]
+
+
+class Handle:
+    """The opaque C plan handle (remap_plan_create / _apply / _destroy) on
+    the same triplets: its own routing (C++) against the same oracle."""
+
+    def __init__(self, m, dev, prepare):
+        import ctypes
+        self.ct = ctypes
+        self.lib = engine.load_library()
+        self.dev = dev
+        self.n_a, self.n_b = m.n_a, m.n_b
+        row = np.ascontiguousarray(m.row.cpu().numpy(), dtype=np.int32)
+        col = np.ascontiguousarray(m.col.cpu().numpy(), dtype=np.int32)
+        S = np.ascontiguousarray(m.S.cpu().numpy(), dtype=np.float64)
+        fb = np.ascontiguousarray(m.frac_b.cpu().numpy(), dtype=np.float64)
+        self.h = ctypes.c_void_p()
+        dims = (ctypes.c_int64 * 2)(*m.dst_dims)
+        rc = self.lib.remap_plan_create(
+            m.n_b, m.n_a, len(S), row.ctypes.data, col.ctypes.data,
+            S.ctypes.data, 1, fb.ctypes.data, 1, dims, 2, self._stream(),
+            ctypes.byref(self.h))
+        assert rc == 0, self.lib.remap_last_error()
+        if prepare:
+            assert self.lib.remap_plan_prepare_short_runs(
+                self.h, self._stream()) == 0, self.lib.remap_last_error()
+
+    def _stream(self):
+        return self.ct.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def apply(self, x, shape, axis, masked, thr):
+        lead = shape[:axis]
+        tail = shape[axis + 1:]
+        T = int(np.prod(lead)) if lead else 1
+        L = int(np.prod(tail)) if tail else 1
+        y = torch.empty(tuple(lead) + (self.n_b,) + tuple(tail),
+                        dtype=torch.float64, device=self.dev)
+        f = engine._Field()
+        f.X, f.Y = x.data_ptr(), y.data_ptr()
+        f.x_dtype = engine.DTYPE_F32 if x.dtype == torch.float32 \
+            else engine.DTYPE_F64
+        f.mode = engine.MODE_MASKED if masked else engine.MODE_FRACB
+        f.threshold = float(thr or 0.0)
+        f.n_batch, f.k_inner = T, L
+        f.x_row_stride, f.x_batch_stride = L, self.n_a * L
+        f.y_row_stride, f.y_batch_stride = L, self.n_b * L
+        rc = self.lib.remap_plan_apply(self.h, self.ct.byref(f),
+                                       self._stream())
+        assert rc == 0, self.lib.remap_last_error()
+        return y
+
+    def close(self):
+        self.lib.remap_plan_destroy(self.h)
 
 
 def one(seed, dev):
@@ -78,6 +133,8 @@ def one(seed, dev):
     src2d = None
     if kind == 'bilinear':
         src2d = m.src_dims
+    handle = Handle(m, dev, prepare=bool(seed % 2)) if seed % 4 < 2 \
+        else None
     multi = None
     if seed % 3 == 0:
         from pyremap_amd.parallel import MultiDeviceRemap
@@ -157,6 +214,10 @@ def one(seed, dev):
                 f'{np.dtype(dtype).name} masked={masked} thr {thr}')
         assert tuple(y.shape) == ref.shape, what
         assert_bitwise(y.cpu().numpy(), ref, what)
+        if handle is not None:
+            yh = handle.apply(x, shape, axis, masked, thr)
+            assert_bitwise(yh.cpu().numpy().reshape(ref.shape), ref,
+                           what + ' plan handle')
         if case == 1:
             # the same through the host-array path (numpy in, numpy out)
             from pyremap_amd import host_path
@@ -184,6 +245,8 @@ def one(seed, dev):
             ym = engine.remap_tensor(multi, m.dst_dims, x, [axis], emode,
                                      threshold=thr or 0.0)
             assert_bitwise(ym.cpu().numpy(), ref, what + ' multi-device')
+    if handle is not None:
+        handle.close()
 
 
 def dataarray_level(seed, dev):
