@@ -751,7 +751,8 @@ BIG = ('headline', 'config4', 'config5')
 #: 5 in the bitwise and in the FMA mode, and the weak spots VERDICT.md names
 DEFAULT_ROWS = ('headline', 'config5', 'config5_fma', 'config5_masked',
                 'Time120_nCells', 'layout_T8_nCells_L60',
-                'layout_T48_nCells_L10', 'config1_esmf_pole_caps_K1',
+                'layout_T48_nCells_L10', 'layout_T120_nCells_L4',
+                'config1_esmf_pole_caps_K1',
                 'config1_esmf_pole_caps_K64', 'masked')
 
 
@@ -799,6 +800,9 @@ def extras_todo(args, world):
         # short level runs (10 soil / ice layers): small LDS patches
         ('layout_T48_nCells_L10', dict(name='config3', layout='tnl',
                                        K=480, times=48), 30),
+        # ... 4 levels: the batch-at-a-time lanes-across-rows kernel
+        ('layout_T120_nCells_L4', dict(name='config3', layout='tnl',
+                                       K=480, times=120), 30),
         ('masked', dict(name='config3', mode='masked'), 50),
     ]
     if not args.all_workloads:
