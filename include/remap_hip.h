@@ -312,7 +312,9 @@ typedef struct remap_apply_args {
      *                             rows of A are sorted by column
      * tune[1] doubles per lane per tile (1 or 2); family 10: waves per
      *         workgroup (1, 2; else 4); family 2: entries of a row fetched
-     *         together (1, 4 or 8)
+     *         together (1, 4 or 8); family 5: threads per workgroup on
+     *         64-column chunks (512 or 1024; 0: by the length of the work
+     *         list)
      * tune[2] K tiles per wave (1, 2 or 4)
      * tune[3] consecutive rows per wave
      * tune[4] block -> work map: 1 = as dispatched, 2 = XCD-contiguous

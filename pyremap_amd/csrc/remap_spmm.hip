@@ -193,26 +193,34 @@ typedef void (*patch_fn)(const KParams, const uint32_t, const int32_t *,
                          const int32_t, const int32_t, const int32_t,
                          const int64_t);
 
-template <typename XT, int WC, bool DMA>
+template <typename XT, int WC, bool DMA, int BLOCK = kPatchBlock>
 patch_fn pick_patch_wc(int mode, bool fma)
 {
     switch (mode) {
     case REMAP_MODE_RAW:
-        return fma ? spmm_patch<XT, REMAP_MODE_RAW, true, WC, DMA>
-                   : spmm_patch<XT, REMAP_MODE_RAW, false, WC, DMA>;
+        return fma ? spmm_patch<XT, REMAP_MODE_RAW, true, WC, DMA, BLOCK>
+                   : spmm_patch<XT, REMAP_MODE_RAW, false, WC, DMA, BLOCK>;
     case REMAP_MODE_FRACB:
-        return fma ? spmm_patch<XT, REMAP_MODE_FRACB, true, WC, DMA>
-                   : spmm_patch<XT, REMAP_MODE_FRACB, false, WC, DMA>;
+        return fma ? spmm_patch<XT, REMAP_MODE_FRACB, true, WC, DMA, BLOCK>
+                   : spmm_patch<XT, REMAP_MODE_FRACB, false, WC, DMA, BLOCK>;
     default:
-        return fma ? spmm_patch<XT, REMAP_MODE_MASKED, true, WC, DMA>
-                   : spmm_patch<XT, REMAP_MODE_MASKED, false, WC, DMA>;
+        return fma ? spmm_patch<XT, REMAP_MODE_MASKED, true, WC, DMA, BLOCK>
+                   : spmm_patch<XT, REMAP_MODE_MASKED, false, WC, DMA, BLOCK>;
     }
 }
 
 // wc = columns per K-chunk (128 / 64); dma = 16-byte LDS-DMA pieces of
-// float64 rows (else through registers, converting f32 on the way)
-patch_fn pick_patch(bool f32, int mode, bool fma, int wc, bool dma)
+// float64 rows (else through registers, converting f32 on the way); block =
+// threads per workgroup (1 024; 512 for 64-column chunks only)
+patch_fn pick_patch(bool f32, int mode, bool fma, int wc, bool dma,
+                    int block = kPatchBlock)
 {
+    if (block == 512 && wc == 64) {
+        if (f32)
+            return pick_patch_wc<float, 64, false, 512>(mode, fma);
+        return dma ? pick_patch_wc<double, 64, true, 512>(mode, fma)
+                   : pick_patch_wc<double, 64, false, 512>(mode, fma);
+    }
     if (f32)
         return wc == 64 ? pick_patch_wc<float, 64, false>(mode, fma)
                         : pick_patch_wc<float, 128, false>(mode, fma);
@@ -948,7 +956,20 @@ int run_patch(const remap_apply_args *a, const Call &c, KParams p,
                                          a->patch_rows, row_bytes);
     if (lds_bytes < 1024)
         lds_bytes = 1024;
-    patch_fn pf = pick_patch(c.f32, a->mode, c.fma, wc, c.dma16);
+    // 64-column chunks (K <= 64, odd strides) on a work list of several
+    // rounds: 512-thread workgroups -- four per CU instead of two, so that a
+    // workgroup's gather (three dependent trips) finds three others
+    // computing.  The short rows of 1 deg -> 0.5 deg bilinear (2 025
+    // patches of 128 rows), us per launch 1 024 / 512 threads: K = 64 37.0 /
+    // 32.4, K = 48 33.3 / 30.1, K = 32 31.7 / 27.3; a work list of ONE round
+    // (QU240 -> 1 deg: 253 patches) loses: 12.2 / 15.7.  tune[1] = 512 /
+    // 1024 forces one or the other.
+    const bool small_blocks =
+        a->tune[1] == 512 || (a->tune[1] != 1024 && grid >= 4 * 256);
+    const int block = (wc == 64 && small_blocks && a->patch_rows <= 512)
+                          ? 512
+                          : kPatchBlock;
+    patch_fn pf = pick_patch(c.f32, a->mode, c.fma, wc, c.dma16, block);
     REMAP_HIP_CHECK(diag_lds_throttle(a, reinterpret_cast<const void *>(pf),
                                       lds_bytes));
     if (lds_bytes > 64 * 1024)
@@ -956,7 +977,7 @@ int run_patch(const remap_apply_args *a, const Call &c, KParams p,
             reinterpret_cast<const void *>(pf),
             hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     hipLaunchKernelGGL(pf, dim3(static_cast<uint32_t>(grid)),
-                       dim3(kPatchBlock), lds_bytes, stream, p, a->flags,
+                       dim3(block), lds_bytes, stream, p, a->flags,
                        a->patch_rowptr, a->patch_val, a->patch_lidx,
                        a->patch_ptr, a->patch_ucol, a->row_order, a->frac_b,
                        a->patch_rows, a->patch_umax, a->patch_emax,

@@ -65,8 +65,9 @@ __host__ __device__ inline uint32_t patch_lds_bytes(int umax, int emax,
 // once per ENTRY -- config 4: 44 staged rows for 2 300 entries per patch) and
 // writes them to LDS.  With WC = 64 that takes any stride and alignment:
 // (Time, nCells, 61 levels) on a bilinear map.
-template <typename XT, int MODE, bool FMA, int WC, bool DMA>
-__global__ __launch_bounds__(kPatchBlock) void spmm_patch(
+template <typename XT, int MODE, bool FMA, int WC, bool DMA,
+          int BLOCK = kPatchBlock>
+__global__ __launch_bounds__(BLOCK) void spmm_patch(
     const KParams p, const uint32_t flags,
     const int32_t *__restrict__ prow, const double *__restrict__ pval,
     const int32_t *__restrict__ plidx, const int32_t *__restrict__ pptr,
@@ -75,6 +76,7 @@ __global__ __launch_bounds__(kPatchBlock) void spmm_patch(
     const int32_t umax, const int32_t emax, const int64_t n_patches)
 {
     static_assert(!DMA || sizeof(XT) == 8, "the DMA moves float64 rows");
+    constexpr int kWaves = BLOCK / kWave;   // waves of the workgroup
     constexpr int VEC = WC / kWave;           // elements per lane
     constexpr int kRowBytes = WC * 8;         // staged bytes per row (f64)
     constexpr int kRowsPerDma = 1024 / kRowBytes;  // rows per DMA instruction
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(kPatchBlock) void spmm_patch(
     int32_t el[kPre];
 #pragma unroll
     for (int k = 0; k < kPre; ++k) {
-        const int t = tid + k * kPatchBlock;
+        const int t = tid + k * BLOCK;
         ev[k] = 0.0;
         el[k] = 0;
         if (t < n_e) {
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(kPatchBlock) void spmm_patch(
     const XT *__restrict__ X = static_cast<const XT *>(p.X);
     if constexpr (DMA) {
         for (int j = wave * kRowsPerDma; j < U;
-             j += kPatchWaves * kRowsPerDma) {
+             j += kWaves * kRowsPerDma) {
             // rows of the group that do not exist: fetch the first again
             // (they land behind the list, inside its last KiB: the row
             // region is a whole number of KiB, see patch_lds_bytes)
@@ -193,11 +195,11 @@ __global__ __launch_bounds__(kPatchBlock) void spmm_patch(
         // register staging, four rows in flight per wave; a lane stages
         // the very columns it computes (converted to float64)
         constexpr int kAhead = 4;
-        for (int j = wave; j < U; j += kPatchWaves * kAhead) {
+        for (int j = wave; j < U; j += kWaves * kAhead) {
             gvec_t v[kAhead];
 #pragma unroll
             for (int q = 0; q < kAhead; ++q) {
-                const int jq = j + q * kPatchWaves;
+                const int jq = j + q * kWaves;
                 int32_t c = ucol[u0 + (jq < U ? jq : j)];
                 REMAP_DIAG_COL(p, c);
                 v[q] = load_x<XT, VEC>(X + static_cast<int64_t>(c) * p.ldx +
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(kPatchBlock) void spmm_patch(
             }
 #pragma unroll
             for (int q = 0; q < kAhead; ++q) {
-                const int jq = j + q * kPatchWaves;
+                const int jq = j + q * kWaves;
                 if (jq < U) {
                     xvec_t d;
                     if constexpr (VEC == 1) {
@@ -222,13 +224,13 @@ __global__ __launch_bounds__(kPatchBlock) void spmm_patch(
     }
 #pragma unroll
     for (int k = 0; k < kPre; ++k) {
-        const int t = tid + k * kPatchBlock;
+        const int t = tid + k * BLOCK;
         if (t < n_e) {
             lds_val[t] = ev[k];
             lds_lidx[t] = el[k];
         }
     }
-    for (int t = tid + kPre * kPatchBlock; t < n_e; t += kPatchBlock) {
+    for (int t = tid + kPre * BLOCK; t < n_e; t += BLOCK) {
         lds_val[t] = pval[e0 + t];
         lds_lidx[t] = plidx[e0 + t];
     }
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(kPatchBlock) void spmm_patch(
             if constexpr (MODE == REMAP_MODE_FRACB && !PLAIN)
                 nx_fb = lds_fb[wave];
         }
-        for (int r = wave; r < nrows; r += kPatchWaves) {
+        for (int r = wave; r < nrows; r += kWaves) {
             const int64_t ybase =
                 (static_cast<int64_t>(__builtin_amdgcn_readfirstlane(
                      static_cast<int32_t>(nx.ybase >> 32)))
@@ -285,10 +287,10 @@ __global__ __launch_bounds__(kPatchBlock) void spmm_patch(
             const int s = __builtin_amdgcn_readfirstlane(nx.s);
             const int e = __builtin_amdgcn_readfirstlane(nx.e);
             const double fb_row = nx_fb;
-            if (r + kPatchWaves < nrows) {
-                nx = lds_hdr[r + kPatchWaves];
+            if (r + kWaves < nrows) {
+                nx = lds_hdr[r + kWaves];
                 if constexpr (MODE == REMAP_MODE_FRACB && !PLAIN)
-                    nx_fb = lds_fb[r + kPatchWaves];
+                    nx_fb = lds_fb[r + kWaves];
             }
             double acc[1][VEC];
             double den[1][VEC];

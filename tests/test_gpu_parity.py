@@ -547,7 +547,7 @@ def test_patch_kernel_bitwise(dev, tile, K, row_bytes):
                              x_row_stride=K, x_batch_stride=0,
                              y_row_stride=K, y_batch_stride=0, mode=emode,
                              threshold=0.1, mask_out=mask,
-                             tune=[5, 0, 0, 0, 0, 0, 0, 0])
+                             tune=[5, 512 if K == 64 else 0, 0, 0, 0, 0, 0, 0])
         if emode == engine.MODE_RAW:
             ref = oracle.csr_matvecs(csr, np.nan_to_num(x) * 0 + x)
             ref_mask = np.zeros_like(ref, dtype=bool)
@@ -600,12 +600,16 @@ def test_patch_kernel_f32_and_odd_strides(dev, shape, axes, dtype):
                 big = torch.empty(xd.numel() + 1, dtype=xd.dtype, device=dev)
                 big[1:] = xd.reshape(-1)
                 xd = big[1:].reshape(shape)
-            y = engine.remap_tensor(
-                plan, m.dst_dims, xd, axes,
-                engine.MODE_MASKED if masked else engine.MODE_FRACB,
-                threshold=0.05, tune=[5])
-            assert_bitwise(y.cpu().numpy(), ref,
-                           f'{shape} {dtype.__name__} {view} {masked}')
+            # (tune[1] = 512: the 512-thread workgroups long work lists of
+            # 64-column chunks take; ignored by the 128-column chunks)
+            for tune in ([5], [5, 512]):
+                y = engine.remap_tensor(
+                    plan, m.dst_dims, xd, axes,
+                    engine.MODE_MASKED if masked else engine.MODE_FRACB,
+                    threshold=0.05, tune=tune)
+                assert_bitwise(y.cpu().numpy(), ref,
+                               f'{shape} {dtype.__name__} {view} {masked} '
+                               f'{tune}')
 
 
 def test_patch_kernel_layouts_and_fallbacks(dev):
