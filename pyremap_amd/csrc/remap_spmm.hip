@@ -746,9 +746,25 @@ bool longwave_usable(const remap_apply_args *a, const Call &c)
            c.n_rows > (a->n_patches - 1) * (int64_t)a->patch_rows;
 }
 
+// Does the LDS patch kernel (family 5) take a call of K fields?  Its time is
+// flat in K up to one 64-column chunk, the lane-per-(row, k) kernel's grows
+// with K: us per launch, lane-per-(row, k) (K <= 32) or scalar-cache rows /
+// LDS patches, at K = 12, 16, 24, 32, 48 -- 1 deg -> 0.5 deg bilinear (2 025
+// patches): 22 / 26, 28 / 27, 41 / 28, 53 / 28, 71 / 29; config 4's map (52 K
+// patches): 2 807 / 2 177, 3 717 / 2 167, 5 625 / 2 316, 7 145 / 2 357,
+// 9 681 / 2 806; QU240 -> 1 deg (253 patches, ONE round of workgroups): 6.4
+// / 11.9, 7.4 / 11.6, 10.1 / 12.2, 12.4 / 12.5, 17.2 / 12.9.
+bool patch_serves(const remap_apply_args *a, const Call &c)
+{
+    return c.patch_ok &&
+           (c.K > 32 || (c.K >= 16 && a->n_patches >= 1024));
+}
+
 // REMAP_FLAG_TUNE_HINT: can the preferred family serve this call?
 bool hint_usable(const remap_apply_args *a, const Call &c)
 {
+    if (a->tune[0] == 5 && !short_runs(a))
+        return patch_serves(a, c);
     if (a->tune[0] == 7 && a->tune[2] == 2)
         return runs_usable(a, c);
     if (a->tune[0] == 7)
@@ -793,12 +809,12 @@ int automatic_family(const remap_apply_args *a, const Call &c)
     // bilinear map at K = 1: 10.1 vs 10.1 us -- so it stays opt-in
     if (a->x_src_fold != 0)
         return 4;
+    if (!short_runs(a) && patch_serves(a, c))
+        return 5;
     if (c.K <= 32)
         return 2;
     if (short_runs(a))
         return 4;
-    if (c.patch_ok && c.K >= 64)
-        return 5;
     return a->A.csr_pad >= 8 ? 6 : 1;
 }
 
