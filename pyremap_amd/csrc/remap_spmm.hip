@@ -765,6 +765,14 @@ bool hint_usable(const remap_apply_args *a, const Call &c)
 {
     if (a->tune[0] == 5 && !short_runs(a))
         return patch_serves(a, c);
+    // the row groups against the lane-per-(row, k) kernel at few fields
+    // (tools/mid_k_probe.py; us per launch, lane-per / groups): config 3 K =
+    // 24 50.6 / 52.9, 32 61.7 / 52.7; headline 24 384 / 402, 32 452 / 406;
+    // config 5 (8-row groups, 12 entries per row) 16 2 157 / 1 967, 24
+    // 3 102 / 2 020, 32 3 779 / 2 026
+    if (a->tune[0] == 10 && !short_runs(a))
+        return c.group_ok && c.small_offsets &&
+               (c.K >= 28 || (c.K >= 16 && a->group_rows == 8));
     if (a->tune[0] == 7 && a->tune[2] == 2)
         return runs_usable(a, c);
     if (a->tune[0] == 7)
