@@ -756,8 +756,12 @@ bool longwave_usable(const remap_apply_args *a, const Call &c)
 // / 11.9, 7.4 / 11.6, 10.1 / 12.2, 12.4 / 12.5, 17.2 / 12.9.
 bool patch_serves(const remap_apply_args *a, const Call &c)
 {
+    // (float32 fields and the masked mode cross later on the shorter list:
+    // 1 deg -> 0.5 deg at K = 16, lane-per / patches: f32 24.7 / 28.9, masked
+    // 27.0 / 37.0; at K = 24: 35.7 / 28.6 and 38.9 / 37.3)
     return c.patch_ok &&
-           (c.K > 32 || (c.K >= 16 && a->n_patches >= 1024));
+           (c.K > 32 || (c.K >= 24 && a->n_patches >= 1024) ||
+            (c.K >= 16 && a->n_patches >= 8192));
 }
 
 // REMAP_FLAG_TUNE_HINT: can the preferred family serve this call?

@@ -6,7 +6,7 @@ conservative ones), the scalar-cache rows and the lane-per-(row, k) kernel
 forced.  What `remap_spmm.hip: patch_serves` and the row groups' rule in
 `hint_usable` rest on.  GPU box only.
 
-    python tools/mid_k_probe.py [workload ...]
+    python tools/mid_k_probe.py [f32] [masked] [workload ...]
 """
 import json
 import os
@@ -22,8 +22,12 @@ from pyremap_amd import engine, synthetic  # noqa: E402
 
 def main():
     dev = torch.device('cuda', 0)
-    workloads = sys.argv[1:] or ['config1_esmf', 'config2', 'config4',
-                                 'config3', 'headline', 'config5']
+    argv = sys.argv[1:]
+    dtype = torch.float32 if 'f32' in argv else torch.float64
+    mode = engine.MODE_MASKED if 'masked' in argv else engine.MODE_FRACB
+    workloads = [a for a in argv if a not in ('f32', 'masked')] or \
+        ['config1_esmf', 'config2', 'config4', 'config3', 'headline',
+         'config5']
     for wl in workloads:
         m = synthetic.make_config(wl, device=dev, locality='mesh')
         plan = engine.RemapPlan.from_triplets(m.row, m.col, m.S, m.frac_b,
@@ -33,14 +37,17 @@ def main():
         part = plan._split[0] if plan._split else plan
         hint = part.default_tune
         if isinstance(hint, dict):
-            hint = hint.get(engine.MODE_FRACB)
+            hint = hint.get(mode)
         scheduled = list(hint) if hint else \
             ([5] if part.patches is not None else [6])
         print(wl, choice.get('family'), scheduled, flush=True)
         for K in (4, 8, 12, 16, 24, 32, 40, 48, 63):
-            x = torch.randn((m.n_a, K), device=dev, dtype=torch.float64)
-            y = engine.remap_tensor(part, m.dst_dims, x, [0],
-                                    engine.MODE_FRACB)
+            x = torch.randn((m.n_a, K), device=dev,
+                            dtype=torch.float64).to(dtype)
+            if mode == engine.MODE_MASKED:
+                x[torch.rand(m.n_a, device=dev) < 0.2] = float('nan')
+            y = engine.remap_tensor(part, m.dst_dims, x, [0], mode,
+                                    threshold=0.1)
             ref = y.clone()
             row = {'wl': wl, 'K': K}
             # (the first variant is timed twice: the clock ramps)
@@ -48,8 +55,8 @@ def main():
                               ('scheduled', scheduled), ('rowscalar', [6]),
                               ('rowlane', [2])):
                 def run():
-                    engine.remap_tensor(part, m.dst_dims, x, [0],
-                                        engine.MODE_FRACB, out=y, tune=tune)
+                    engine.remap_tensor(part, m.dst_dims, x, [0], mode,
+                                        threshold=0.1, out=y, tune=tune)
                 try:
                     row[tag] = round(replay_us(run, calls=10, reps=3), 2)
                     assert torch.equal(torch.nan_to_num(y, nan=-2.5),
