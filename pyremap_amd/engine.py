@@ -974,8 +974,11 @@ class RemapPlan:
             # four 256-thread workgroups do them sooner than one of 1 024 --
             # 1 deg -> 0.5 deg bilinear, short rows, (12, n) 20.3 -> 17.3 us,
             # (120, n) float32 75.8 -> 71.9
+            # (only where the large patches are few -- 254 there; config 4's
+            # map, 29 K patches of 32 x 32, loses with the small ones: (32, n)
+            # 3.3 -> 5.7 ms)
             if q is not None and q['rows'] > 256 and \
-                    2 * q['umax'] < q['rows']:
+                    2 * q['umax'] < q['rows'] and q['n'] < 1024:
                 ty, tx = q['tile']
                 while ty * tx > 256:
                     ty, tx = (ty, tx // 2) if tx >= ty else (ty // 2, tx)
