@@ -580,8 +580,8 @@ int remap_plan_create(int64_t n_b, int64_t n_a, int64_t n_s,
  *   input (tests/test_interpolate.py:57-59; k_inner < 4 and n_batch > 1):
  *   builds the patch plan of the LDS-staged lanes-across-rows kernel (32 x 32
  *   tiles of the destination grid -- 16 x 16 on grids under 128 K cells and
- *   on coarse-to-fine maps of fewer than 1 024 such tiles -- halved until no patch references more than
- *   2 046 distinct source cells), which remap_plan_apply then uses for such
+ *   on coarse-to-fine maps of fewer than 1 024 such tiles -- halved until
+ *   no patch references more than 2 046 distinct source cells), which remap_plan_apply then uses for such
  *   fields.  Without it they take the unstaged lanes-across-rows kernel
  *   (2.5 x slower on EC30to60 -> 0.5 degree at Time = 120);
  *   (Time, nCells, 4 ... 15 levels) on mappings scheduled as row groups:
