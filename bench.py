@@ -109,6 +109,9 @@ def parse_args():
                     help="torch.distributed backend: 'nccl' (= RCCL, the "
                          "real thing) or 'gloo' to rehearse the N > 1 code "
                          "path with several ranks sharing one GPU")
+    ap.add_argument('--no-multi-rows', action='store_true',
+                    help='N > 1: skip the sharded headline / config 4 / '
+                         'config 5 rows of `multi_gpu.workloads`')
     ap.add_argument('--metric-first', action='store_true',
                     help='time the metric workload BEFORE the extras (A/B '
                          'of the idle-state effect; see the module docstring)')
@@ -225,12 +228,15 @@ def time_steps(launch, steps, warmup, dist):
         if marks:
             marks[i].record()     # diagnosis only: where the region's time is
     last.record()
-    # which clock state the region ran in: one wave spinning 20 us right
-    # behind it (outside the event pair and the wall time's launches)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    # which clock state the region ran in: one wave spinning 20 us behind it
+    # -- AFTER the wall clock has stopped: the probe (a fill + the spinning
+    # wave) is no remap work, and on a 1/8 row shard (~45 us a step) it was
+    # 3-5 % of the time `value` is computed from
     from pyremap_amd import engine
     mhz = engine.clock_probe(torch.cuda.current_device())
     torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
     if marks:
         prev = first
         gaps = []
@@ -433,10 +439,19 @@ def time_exchange(w, dist):
     x = w.fields[0]
     axis = 0 if w.layout == 'nk' else 1
     times = []
-    for _ in range(3):
+    # (tens of GB: once -- every rank's synthetic fields are the same bytes
+    # already, the broadcast is timed, not needed)
+    piece = x
+    if w.name in BIG and dist.get_backend() != 'nccl':
+        # the gloo rehearsal stages GPU tensors through the host: a 256 MB
+        # piece of the tens of GB exercises the call (the ranks' synthetic
+        # fields are the same bytes already)
+        piece = x.view(-1)[:1 << 25]
+        out['broadcast_note'] = 'gloo rehearsal: 256 MB piece only'
+    for _ in range(1 if w.name in BIG else 3):
         barrier(dist)
         t0 = time.perf_counter()
-        dist.broadcast(x, src=0)
+        dist.broadcast(piece, src=0)
         torch.cuda.synchronize()
         times.append((time.perf_counter() - t0) * 1e3)
     out['broadcast_ms'] = min(times)
@@ -445,7 +460,7 @@ def time_exchange(w, dist):
     out['backend'] = dist.get_backend()
     out['exchange'] = 'one broadcast of X + local gather of the packed ' \
         'rows, before the timed region'
-    for x in w.fields:            # every set's packed rows resident
+    for x in w.fields[1:]:        # every set's packed rows resident
         dist.broadcast(x, src=0)
     torch.cuda.synchronize()
     out['field_bytes'] = x.numel() * x.element_size()
@@ -750,10 +765,16 @@ BIG = ('headline', 'config4', 'config5')
 #: command has to stay short): north_star's target workload, BASELINE config
 #: 5 in the bitwise and in the FMA mode, and the weak spots VERDICT.md names
 DEFAULT_ROWS = ('headline', 'config5', 'config5_fma', 'config5_masked',
+                'config4', 'config2',
                 'Time120_nCells', 'layout_T8_nCells_L60',
                 'layout_T48_nCells_L10', 'layout_T120_nCells_L4',
                 'config1_esmf_pole_caps_K1',
                 'config1_esmf_pole_caps_K64', 'masked')
+
+#: N > 1: the sharded workloads BASELINE.json names for 8 GPUs (configs 4 and
+#: 5) and north_star's headline, one at a time (prepare -> exchange -> measure
+#: -> free); their rows land in `multi_gpu.workloads`
+MULTI_ROWS = ('headline', 'config4', 'config5')
 
 
 def extras_todo(args, world):
@@ -765,7 +786,12 @@ def extras_todo(args, world):
     if args.no_extra or args.workload != 'config3':
         return []
     if world > 1:
-        return [('masked', dict(name='config3', mode='masked'), 50)]
+        rows = [('masked', dict(name='config3', mode='masked'), 50)]
+        if args.shard == 'rows' and not args.no_multi_rows:
+            rows = [('headline', dict(name='headline', sets=1), 12),
+                    ('config4', dict(name='config4', sets=1), 6),
+                    ('config5', dict(name='config5', sets=1), 4)] + rows
+        return rows
     rows = [
         # north_star's target workload; BASELINE configs 5 and 4
         ('headline', dict(name='headline', sets=2), 12),
@@ -777,6 +803,8 @@ def extras_todo(args, world):
         ('config5_masked', dict(name='config5', sets=1, mode='masked',
                                 share='config5'), 4),
         ('config4', dict(name='config4', sets=1), 6),
+        # BASELINE config 2: one round of workgroups, microseconds
+        ('config2', dict(name='config2'), 50),
         ('config4_f32_fields', dict(name='config4', sets=1, dtype='f32'), 6),
         # the metric mapping in the raster numbering round 2 measured
         ('config3_raster_numbering',
@@ -841,7 +869,8 @@ def measure_big_extras(args, rank, world, dist, extra):
                 v = same_with(w, flags=kw.get('flags'), mode=kw.get('mode'))
             else:
                 if w is not None:
-                    w.launch = w.fields = w.outs = None
+                    w.launch = w.fields = w.outs = w.full_field = None
+                    w.remap = w.plan = w.full = None
                 w = None          # (freed before the next one is built)
                 gc.collect()
                 torch.cuda.empty_cache()
@@ -850,13 +879,15 @@ def measure_big_extras(args, rank, world, dist, extra):
             measure_extras([(tag, v, steps)], args, dist, extra,
                            long_last=False)
             v.launch = None                   # (launch closes over v)
+            v.full_field = None
             del v
         except Exception as exc:  # noqa: BLE001
             extra[tag] = {'error': f'{type(exc).__name__}: {exc}'}
         if isinstance(extra.get(tag), dict):
             extra[tag]['prepare_and_measure_s'] = time.perf_counter() - t0
     if w is not None:
-        w.launch = w.fields = w.outs = None
+        w.launch = w.fields = w.outs = w.full_field = None
+        w.remap = w.plan = w.full = None
     del w
     gc.collect()
     torch.cuda.empty_cache()
@@ -901,8 +932,46 @@ def measure_extras(ready, args, dist, extra, long_last=True):
             traffic, _ = load_traffic(w.name, w.K, w.mode, w.locality) \
                 if w.layout == 'nk' and w.dtype == 'f64' else (None, None)
             extra[tag]['traffic'] = traffic
+            if dist is not None and w.sharded:
+                # the slowest rank's kernel phase prices the WHOLE mapping's
+                # algorithmic bytes against N x 8 TB/s
+                tk = torch.tensor([r['kernel_ms_mean']], device='cuda',
+                                  dtype=torch.float64)
+                dist.all_reduce(tk, op=dist.ReduceOp.MAX)
+                phase = float(tk.item())
+                whole = w.full.algorithmic_bytes(
+                    w.K, 4 if w.dtype == 'f32' else 8, w.emode)
+                extra[tag]['multi'] = dict(
+                    kernel_phase_ms=phase, bytes_alg_whole_mapping=whole,
+                    frac_of_all_gpus=whole / (phase * 1e-3) / 1e9 /
+                    (HBM_PEAK_GBPS * dist.get_world_size()),
+                    packed_fraction=w.remap.packed_fraction(),
+                    broadcast_ms=(w.exchange or {}).get('broadcast_ms'),
+                    local_gather_ms=(w.exchange or {}).get(
+                        'local_gather_ms'),
+                    rows_this_rank=r['rows_this_rank'],
+                    nnz_this_rank=r['nnz_this_rank'])
         except Exception as exc:  # noqa: BLE001
             extra[tag] = {'error': f'{type(exc).__name__}: {exc}'}
+
+
+def multi_rows(extra):
+    """`multi_gpu.workloads`: `tag: [kernel-phase ms of the slowest rank,
+    fraction of N x 8 TB/s on the whole mapping's algorithmic bytes, packed
+    fraction of the source rows this rank holds]`."""
+    rows = {}
+    for tag in MULTI_ROWS:
+        e = extra.get(tag)
+        if not isinstance(e, dict):
+            continue
+        mm = e.get('multi')
+        if mm:
+            rows[tag] = [round(mm['kernel_phase_ms'], 5),
+                         round(mm['frac_of_all_gpus'], 4),
+                         round(mm['packed_fraction'], 4)]
+        elif 'error' in e:
+            rows[tag] = 'error: ' + e['error'][:60]
+    return rows
 
 
 def replay_short_extras(ready, extra):
@@ -1026,6 +1095,8 @@ def compose_line(args, res, world, ceiling, cpu, extra, pipelined,
                 'optional_measurements', 'packed_error')
         multi = {k: (rnd(v) if not isinstance(v, str) else v[:100])
                  for k, v in full_multi.items() if k in keep}
+        if multi_rows(extra):
+            multi['workloads'] = multi_rows(extra)
     else:
         full_multi = None
     family = KERNEL_OF_FAMILY.get(res['schedule'].get('family'), 'spmm_*')

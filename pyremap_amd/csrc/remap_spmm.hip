@@ -58,6 +58,7 @@ namespace {
 #include "spmm_stamps.h"
 #include "spmm_rowscalar.h"
 #include "spmm_rowgroup.h"
+#include "spmm_grouproll.h"
 #include "spmm_rowlane.h"
 #include "spmm_rowcell.h"
 #include "spmm_patchcell.h"
@@ -497,15 +498,54 @@ GroupFn<double>::type pick_rowgroup_lock(int mode)
 }
 #endif
 
+// the rolling form (spmm_grouproll.h): float64, two elements per lane
+template <int TILES, int G, int UNR>
+GroupFn<double>::type pick_grouproll_mode(int mode, bool fma)
+{
+    switch (mode) {
+    case REMAP_MODE_RAW:
+        return fma ? spmm_grouproll<double, TILES, REMAP_MODE_RAW, true, G,
+                                    UNR, 2>
+                   : spmm_grouproll<double, TILES, REMAP_MODE_RAW, false, G,
+                                    UNR, 2>;
+    case REMAP_MODE_FRACB:
+        return fma ? spmm_grouproll<double, TILES, REMAP_MODE_FRACB, true, G,
+                                    UNR, 2>
+                   : spmm_grouproll<double, TILES, REMAP_MODE_FRACB, false, G,
+                                    UNR, 2>;
+    default:
+        return fma ? spmm_grouproll<double, TILES, REMAP_MODE_MASKED, true, G,
+                                    UNR, 2>
+                   : spmm_grouproll<double, TILES, REMAP_MODE_MASKED, false,
+                                    G, UNR, 2>;
+    }
+}
+
+template <int G>
+GroupFn<double>::type pick_grouproll(int unr, int tiles, int mode, bool fma)
+{
+    if (unr == 6)
+        return tiles == 1 ? pick_grouproll_mode<1, G, 6>(mode, fma)
+                          : pick_grouproll_mode<2, G, 6>(mode, fma);
+    return tiles == 1 ? pick_grouproll_mode<1, G, 8>(mode, fma)
+                      : pick_grouproll_mode<2, G, 8>(mode, fma);
+}
+
 template <typename XT>
 int launch_rowgroup(const remap_apply_args *a, const KParams &p, int tiles,
                     int unr, int vec, int wpb, bool fma, int64_t grid,
-                    hipStream_t stream, bool lock = false)
+                    hipStream_t stream, bool lock = false, int roll = 0)
 {
     typename GroupFn<XT>::type fn =
         a->group_rows == 8
             ? pick_rowgroup_shape<XT, 8>(unr, tiles, vec, a->mode, fma)
             : pick_rowgroup_shape<XT, 4>(unr, tiles, vec, a->mode, fma);
+    if constexpr (std::is_same<XT, double>::value) {
+        if (roll && vec == 2)
+            fn = a->group_rows == 8
+                     ? pick_grouproll<8>(roll, tiles, a->mode, fma)
+                     : pick_grouproll<4>(roll, tiles, a->mode, fma);
+    }
 #ifdef REMAP_DIAG
     if constexpr (std::is_same<XT, double>::value) {
         if (lock)
@@ -953,10 +993,14 @@ int run_rowgroup(const remap_apply_args *a, const Call &c, KParams p,
         a->tune[4] != 1, grid);
     if (rc != REMAP_OK)
         return rc;
+    if (a->tune[4] == 3)   // the K-chunks of a row block side by side
+        p.xcd_map |= 2;
+    // tune[5] = 26 / 28: the rolling form, 6 / 8 union entries in flight
+    const int roll = a->tune[5] == 26 ? 6 : a->tune[5] == 28 ? 8 : 0;
     return c.f32 ? launch_rowgroup<float>(a, p, tiles, unr, vec, wpb, c.fma,
                                           grid, stream)
                  : launch_rowgroup<double>(a, p, tiles, unr, vec, wpb, c.fma,
-                                           grid, stream, lock);
+                                           grid, stream, lock, roll);
 }
 
 int run_patch(const remap_apply_args *a, const Call &c, KParams p,

@@ -81,8 +81,18 @@ __global__ __launch_bounds__(BLOCK) void spmm_rowgroup(
     if (L >= p.n_blocks)
         return;
     REMAP_CLOCK_BEGIN();
-    const int64_t chunk = L / p.n_rowblocks;
-    const int64_t rb = L - chunk * p.n_rowblocks;
+    // work list chunk-major (the K-chunks of a row block far apart: an XCD
+    // works on one chunk) or, xcd_map & 2, chunk-minor (the chunks of a row
+    // block side by side: its schedule is fetched once per XCD)
+    int64_t chunk, rb;
+    if (p.xcd_map & 2) {
+        const int64_t n_chunks = p.n_blocks / p.n_rowblocks;
+        rb = L / n_chunks;
+        chunk = L - rb * n_chunks;
+    } else {
+        chunk = L / p.n_rowblocks;
+        rb = L - chunk * p.n_rowblocks;
+    }
 
     int64_t xoff[TILES], yoff[TILES];
     bool act[TILES];

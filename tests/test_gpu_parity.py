@@ -1977,10 +1977,11 @@ def test_bench_multi_rank_line_and_a_hung_exchange(tmp_path):
     base = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
             '--nproc-per-node', '2', '--master-addr', '127.0.0.1']
     bench = [os.path.join(repo, 'bench.py'), '--gpus', '2', '--steps', '5',
-             '--warmup', '2', '--backend', 'gloo', '--no-extra']
+             '--warmup', '2', '--backend', 'gloo']
     # the third pass is plain `python bench.py --gpus 2 ...` with no launcher
     # around it: bench.py starts its ranks itself (as a child) and relays
-    # rank 0's line
+    # rank 0's line -- with the extras of an N > 1 run: the sharded headline,
+    # config 4 and config 5 (the workloads BASELINE.json names for 8 GPUs)
     for port, env_extra in (('29571', {}),
                             ('29572', {'BENCH_TEST_HANG': '1',
                                        'BENCH_OPTIONAL_TIMEOUT_S': '5'}),
@@ -1989,9 +1990,9 @@ def test_bench_multi_rank_line_and_a_hung_exchange(tmp_path):
         for name in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
             env.pop(name, None)
         cmd = [sys.executable] + bench if port is None else \
-            base + ['--master-port', port] + bench
+            base + ['--master-port', port] + bench + ['--no-extra']
         proc = subprocess.run(cmd, capture_output=True, text=True, env=env,
-                              timeout=600, cwd=str(tmp_path))
+                              timeout=900, cwd=str(tmp_path))
         hung = bool(env_extra)
         assert (proc.returncode != 0) == hung, proc.stderr[-2000:]
         last = proc.stdout.strip().splitlines()[-1]
@@ -2008,6 +2009,14 @@ def test_bench_multi_rank_line_and_a_hung_exchange(tmp_path):
         assert line['config']['locality'] == 'mesh'
         assert multi['packed_fraction_of_broadcast'] < 0.8
         assert ('optional_measurements' in multi) == hung
+        if port is None:
+            # [kernel-phase ms of the slowest rank, fraction of 2 x 8 TB/s,
+            # packed fraction of the source rows a rank holds]
+            rows = multi['workloads']
+            assert set(rows) == {'headline', 'config4', 'config5'}, rows
+            for tag, row in rows.items():
+                assert len(row) == 3 and row[0] > 0, (tag, row)
+                assert 0 < row[1] < 1 and 0 < row[2] <= 1, (tag, row)
         # everything else is in the side file the line names
         details = json.load(open(os.path.join(repo, line['details'])))
         assert details['line']['value'] == line['value']
