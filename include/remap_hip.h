@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define REMAP_ABI_VERSION 23
+#define REMAP_ABI_VERSION 24
 
 enum {
     REMAP_OK = 0,
@@ -99,7 +99,21 @@ enum {
      * one after the other in CSR order: a different association, within
      * 1e-13 relative of the default -- for callers that do not need the
      * bits.  Ignored by the other kernel families. */
-    REMAP_FLAG_TREE = 1u << 3
+    REMAP_FLAG_TREE = 1u << 3,
+    /* REMAP_MODE_MASKED, a HINT: the caller expects a source cell to be
+     * valid in all of the call's columns or missing in all of them (land, an
+     * ice shelf, no NaN at all in most of the field) rather than column by
+     * column (a 3-D field cut by bathymetry).  On mappings scheduled as
+     * 8-row groups (entry-rich: 2nd-order conservative) the normaliser
+     * `A . [not isnan X]` (remap_numpy.py:265) is then kept per ROW, with
+     * two K tiles per wave as in the frac_b mode; groups where the
+     * expectation fails are redone with per-lane normalisers inside the
+     * same launch.  Same bits with or without the flag, whatever the data;
+     * only the speed differs (config 5: 27.4 -> 22.0 ms with whole cells
+     * missing, 26.7 -> 35.3 with the flag set on a bathymetry mask).
+     * remap_scan_nan_kinds() tells the two apart on the device.  Ignored
+     * elsewhere. */
+    REMAP_FLAG_CELL_MASKS = 1u << 4
 };
 
 /* CSR weight matrix of shape (n_rows, n_cols) = (n_b, n_a), or a row shard of
@@ -261,7 +275,7 @@ typedef struct remap_apply_args {
     const int32_t *group_rid;   /* (device) n_groups * group_rows           */
     const double *group_frac;   /* (device) n_groups * group_rows           */
     int64_t n_groups;
-    int32_t group_rows;         /* G: 8 or 4                                */
+    int32_t group_rows;         /* G: 8 or 4 (16: float64, even strides)    */
     int32_t group_reserved;     /* must be 0                                */
     /* Optional device-side switch (NULL = always run): the launch does its
      * work only if the int32 at `gate` equals `gate_value` when the kernel
@@ -605,6 +619,21 @@ int remap_plan_apply(const remap_plan *plan, const remap_field *field,
  */
 int remap_scan_nan(const void *x, int32_t x_dtype, int64_t n, int32_t *flag,
                    void *stream);
+
+/*
+ * remap_scan_nan() with the KIND of the missing values (device int32[2],
+ * zeroed by the caller): kinds[0] |= 1 if x holds a NaN (what
+ * remap_scan_nan() reports); kinds[1] |= 1 if x holds a NaN, |= 2 if some
+ * aligned run of 16 bytes x 64 lanes (128 float64 / 256 float32 elements in
+ * memory order) holds NaNs AND numbers -- so kinds[1] is 0 (no NaN), 1 (NaNs
+ * in whole runs: whole cells of an (n_a, K) field missing) or 3 (NaNs
+ * column by column).  Three gated calls then cover remap_numpy.py:201-204
+ * on an entry-rich mapping: FRACB gated on kinds[0] == 0, MASKED with
+ * REMAP_FLAG_CELL_MASKS gated on kinds[1] == 1, MASKED without it gated on
+ * kinds[1] == 3.  A hint only: results never depend on it.
+ */
+int remap_scan_nan_kinds(const void *x, int32_t x_dtype, int64_t n,
+                         int32_t *kinds, void *stream);
 
 /*
  * The two device steps of a ROW SHARD's exchange (no counterpart in the

@@ -59,6 +59,7 @@ namespace {
 #include "spmm_rowscalar.h"
 #include "spmm_rowgroup.h"
 #include "spmm_grouproll.h"
+#include "spmm_groupmask.h"
 #include "spmm_rowlane.h"
 #include "spmm_rowcell.h"
 #include "spmm_patchcell.h"
@@ -534,15 +535,29 @@ GroupFn<double>::type pick_grouproll(int unr, int tiles, int mode, bool fma)
 template <typename XT>
 int launch_rowgroup(const remap_apply_args *a, const KParams &p, int tiles,
                     int unr, int vec, int wpb, bool fma, int64_t grid,
-                    hipStream_t stream, bool lock = false, int roll = 0)
+                    hipStream_t stream, bool lock = false, int roll = 0,
+                    bool cell_masks = false)
 {
     typename GroupFn<XT>::type fn =
         a->group_rows == 8
             ? pick_rowgroup_shape<XT, 8>(unr, tiles, vec, a->mode, fma)
             : pick_rowgroup_shape<XT, 4>(unr, tiles, vec, a->mode, fma);
     if constexpr (std::is_same<XT, double>::value) {
+        if (a->group_rows == 16)   // 2 x 8 tiles: float64, 2 per lane
+            fn = unr == 4 ? pick_rowgroup_tiles<double, 16, 4>(tiles, a->mode,
+                                                               fma)
+                          : pick_rowgroup_tiles<double, 16, 8>(tiles, a->mode,
+                                                               fma);
+        // REMAP_FLAG_CELL_MASKS, masked mode on 8-row groups: per-row
+        // normalisers while the validity of a source cell is the same in
+        // all of a wave's columns (spmm_groupmask.h), two K tiles per wave
+        if (cell_masks)
+            fn = fma ? spmm_groupmask<double, 2, true, 8, 8, 2>
+                     : spmm_groupmask<double, 2, false, 8, 8, 2>;
         if (roll && vec == 2)
-            fn = a->group_rows == 8
+            fn = a->group_rows == 16
+                     ? pick_grouproll<16>(roll, tiles, a->mode, fma)
+                 : a->group_rows == 8
                      ? pick_grouproll<8>(roll, tiles, a->mode, fma)
                      : pick_grouproll<4>(roll, tiles, a->mode, fma);
     }
@@ -677,7 +692,8 @@ int check_args(const remap_apply_args *a, Call &c)
                 c.n_rows > (a->n_patches - 1) * (int64_t)a->patch_rows;
     c.group_ok = a->group_meta && a->group_col && a->group_w &&
                  a->group_mask && a->group_rid && a->group_frac &&
-                 (a->group_rows == 8 || a->group_rows == 4) &&
+                 (a->group_rows == 8 || a->group_rows == 4 ||
+                  (a->group_rows == 16 && !c.f32 && c.can_vec2)) &&
                  a->group_reserved == 0 &&
                  a->n_groups ==
                      (c.n_rows + a->group_rows - 1) / a->group_rows;
@@ -939,6 +955,14 @@ int run_rowgroup(const remap_apply_args *a, const Call &c, KParams p,
     int tiles = a->tune[2];
     if (tiles == 0)
         tiles = c.f32 ? 2 : (c.K > 128 && c.K <= 224) ? 2 : 1;
+    // REMAP_FLAG_CELL_MASKS on 8-row groups: the per-row normaliser form
+    // (spmm_groupmask.h) with two K tiles per wave, whatever tune[2] says
+    const bool cell_masks =
+        (a->flags & REMAP_FLAG_CELL_MASKS) && a->mode == REMAP_MODE_MASKED &&
+        a->group_rows == 8 && !c.f32 && c.can_vec2 && c.K > 128 &&
+        a->tune[5] == 0;
+    if (cell_masks)
+        tiles = 2;
     if (tiles != 2 || c.K <= 128)
         tiles = 1;
     // odd strides or level counts: one element per lane and tile, two tiles.
@@ -952,6 +976,10 @@ int run_rowgroup(const remap_apply_args *a, const Call &c, KParams p,
     const int vec = (c.can_vec2 && !narrow) ? 2 : 1;
     if (vec == 1)
         tiles = c.K > 64 ? 2 : 1;
+    if (a->group_rows == 16 && vec != 2)
+        return fail(REMAP_ERR_UNSUPPORTED,
+                    "remap_apply_f64: 16-row groups serve float64 fields of "
+                    "more than 64 even-strided columns");
     int gpw = a->tune[3] > 0 ? a->tune[3] : 2;   // groups per wave
     // union entries in flight
     int unr = (a->tune[5] == 4 || a->tune[5] == 16) ? a->tune[5] : 8;
@@ -1000,7 +1028,8 @@ int run_rowgroup(const remap_apply_args *a, const Call &c, KParams p,
     return c.f32 ? launch_rowgroup<float>(a, p, tiles, unr, vec, wpb, c.fma,
                                           grid, stream)
                  : launch_rowgroup<double>(a, p, tiles, unr, vec, wpb, c.fma,
-                                           grid, stream, lock, roll);
+                                           grid, stream, lock, roll,
+                                           cell_masks && vec == 2);
 }
 
 int run_patch(const remap_apply_args *a, const Call &c, KParams p,
@@ -1591,7 +1620,7 @@ __global__ __launch_bounds__(kBlock) void stream_copy_kernel(
 // .any()` decides between the masked and the unmasked branch)
 // ---------------------------------------------------------------------------
 namespace {
-template <typename T>
+template <typename T, bool KINDS>
 __global__ __launch_bounds__(kBlock) void scan_nan_kernel(
     const T *__restrict__ x0, size_t n0, size_t head,
     int32_t *__restrict__ flag)
@@ -1605,29 +1634,53 @@ __global__ __launch_bounds__(kBlock) void scan_nan_kernel(
     const size_t n = n0 - head;
     const size_t nvec = n / PER;
     bool found = false;
+    bool mixed = false;   // KINDS: a wave's run holds NaNs and numbers
     if (blockIdx.x == 0 && threadIdx.x < head) {
         const T t = x0[threadIdx.x];
         found |= (t != t);
+        if constexpr (KINDS)
+            mixed = true;   // (peeled elements: no run to judge them by)
     }
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nvec;
          i += (size_t)gridDim.x * kBlock) {
         const vec_t v = __builtin_nontemporal_load(
             reinterpret_cast<const vec_t *>(x) + i);
+        bool some = false, every = true;
 #pragma unroll
-        for (int e = 0; e < PER; ++e)
-            found |= (v[e] != v[e]);
+        for (int e = 0; e < PER; ++e) {
+            some |= (v[e] != v[e]);
+            every &= (v[e] != v[e]);
+        }
+        found |= some;
+        if constexpr (KINDS) {
+            // the lanes of this wave hold one aligned run of 64 x 16 bytes
+            // (fewer at the buffer's end)
+            if (__ballot(some) != 0 && __ballot(every) != __ballot(true))
+                mixed = true;
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x < n - nvec * PER) {
         const T t = x[nvec * PER + threadIdx.x];
         found |= (t != t);
+        if constexpr (KINDS)
+            mixed = true;
     }
-    if (__any(found) && (threadIdx.x & (kWave - 1)) == 0)
-        atomicOr(flag, 1);
+    if constexpr (KINDS) {
+        const bool any = __any(found);
+        const bool mix = __any(mixed);
+        if (any && (threadIdx.x & (kWave - 1)) == 0) {
+            atomicOr(flag, 1);
+            atomicOr(flag + 1, mix ? 3 : 1);
+        }
+    } else {
+        if (__any(found) && (threadIdx.x & (kWave - 1)) == 0)
+            atomicOr(flag, 1);
+    }
 }
 }  // namespace
 
 int scan_nan(const void *x, int32_t dtype, int64_t n, int32_t *flag,
-             hipStream_t stream)
+             hipStream_t stream, bool kinds = false)
 {
     if (n < 0 || !flag || (n > 0 && !x))
         return fail(REMAP_ERR_ARG, "remap_scan_nan: bad argument");
@@ -1649,16 +1702,23 @@ int scan_nan(const void *x, int32_t dtype, int64_t n, int32_t *flag,
         grid = 1;
     if (grid > 256 * 64)
         grid = 256 * 64;   // grid-stride beyond 64 blocks per CU
-    if (dtype == REMAP_DTYPE_F64)
-        hipLaunchKernelGGL(scan_nan_kernel<double>, dim3((uint32_t)grid),
-                           dim3(kBlock), 0, stream,
+    if (dtype == REMAP_DTYPE_F64) {
+        void (*fn)(const double *, size_t, size_t, int32_t *) =
+            scan_nan_kernel<double, false>;
+        if (kinds)
+            fn = scan_nan_kernel<double, true>;
+        hipLaunchKernelGGL(fn, dim3((uint32_t)grid), dim3(kBlock), 0, stream,
                            static_cast<const double *>(x), (size_t)n, head,
                            flag);
-    else
-        hipLaunchKernelGGL(scan_nan_kernel<float>, dim3((uint32_t)grid),
-                           dim3(kBlock), 0, stream,
+    } else {
+        void (*fn)(const float *, size_t, size_t, int32_t *) =
+            scan_nan_kernel<float, false>;
+        if (kinds)
+            fn = scan_nan_kernel<float, true>;
+        hipLaunchKernelGGL(fn, dim3((uint32_t)grid), dim3(kBlock), 0, stream,
                            static_cast<const float *>(x), (size_t)n, head,
                            flag);
+    }
     REMAP_HIP_CHECK(hipGetLastError());
     return REMAP_OK;
 }
@@ -1746,6 +1806,13 @@ int remap_scan_nan(const void *x, int32_t x_dtype, int64_t n, int32_t *flag,
 {
     return remap::scan_nan(x, x_dtype, n, flag,
                            static_cast<hipStream_t>(stream));
+}
+
+int remap_scan_nan_kinds(const void *x, int32_t x_dtype, int64_t n,
+                         int32_t *kinds, void *stream)
+{
+    return remap::scan_nan(x, x_dtype, n, kinds,
+                           static_cast<hipStream_t>(stream), true);
 }
 
 int remap_stream_copy(void *dst, const void *src, size_t bytes, void *stream)

@@ -33,8 +33,9 @@ __global__ __launch_bounds__(kBlock) void spmm_grouproll(
     const int32_t *__restrict__ grid, const double *__restrict__ gfrac,
     const XT *__restrict__ X)
 {
-    static_assert(UNR <= 8 && UNR * G <= kWave,
-                  "a step's weights are one lane-load");
+    static_assert(UNR <= 8 && UNR * G <= 2 * kWave,
+                  "a step's weights are one or two lane-loads");
+    constexpr int NW = (UNR * G + kWave - 1) / kWave;
     typedef typename XVec<XT, VEC>::type xvec_t;
     typedef typename I32Vec<8>::type ivec_t;
     typedef typename I32Vec<G>::type rvec_t;
@@ -108,8 +109,8 @@ __global__ __launch_bounds__(kBlock) void spmm_grouproll(
         // the products of one union entry, member by member (spmm_rowgroup's
         // inner block; `idx` walks the step's lane-held weights)
         auto consume = [&](const int32_t bits, const xvec_t (&x_in)[TILES],
-                           const double my_w, int &idx) {
-            constexpr bool kHoist = MODE == REMAP_MODE_MASKED && G == 8;
+                           const double (&my_w)[NW], int &idx) {
+            constexpr bool kHoist = MODE == REMAP_MODE_MASKED && G >= 8;
             double xz[TILES][VEC], vf[TILES][VEC];
 #pragma unroll
             for (int t = 0; t < TILES; ++t)
@@ -129,7 +130,13 @@ __global__ __launch_bounds__(kBlock) void spmm_grouproll(
 #pragma unroll
             for (int m = 0; m < G; ++m) {
                 if (bits & (1 << m)) {
-                    const double a = readlane_f64(my_w, idx);
+                    double a;
+                    if constexpr (NW == 1)
+                        a = readlane_f64(my_w[0], idx);
+                    else
+                        a = idx < kWave
+                                ? readlane_f64(my_w[0], idx)
+                                : readlane_f64(my_w[1], idx - kWave);
                     ++idx;
 #pragma unroll
                     for (int t = 0; t < TILES; ++t)
@@ -159,7 +166,15 @@ __global__ __launch_bounds__(kBlock) void spmm_grouproll(
         // first step: columns, masks, weights, X
         ivec_t cv = *reinterpret_cast<const ivec_t *>(gcol + base);
         ivec_t mv = *reinterpret_cast<const ivec_t *>(gmask + base);
-        double w = gw[woff + lane];
+        // (the weights FIRST, here as in the loop: the wait counts at the
+        // loop's head are the tighter of its two entries' -- with the weights
+        // issued among the X loads the first product of EVERY step waited for
+        // all but three of the loads in flight)
+        double w[NW];
+#pragma unroll
+        for (int q = 0; q < NW; ++q)
+            w[q] = gw[woff + q * kWave + lane];
+        asm volatile("" ::: "memory");
         xvec_t xv[UNR][TILES];
         {
             const int n = (e - base) < UNR ? static_cast<int>(e - base) : UNR;
@@ -184,7 +199,10 @@ __global__ __launch_bounds__(kBlock) void spmm_grouproll(
 #pragma unroll
             for (int uu = 0; uu < UNR; ++uu)
                 cnt += __builtin_popcount(static_cast<uint32_t>(mv[uu]));
-            const double wn = gw[woff + cnt + lane];
+            double wn[NW];
+#pragma unroll
+            for (int q = 0; q < NW; ++q)
+                wn[q] = gw[woff + cnt + q * kWave + lane];
             asm volatile("" ::: "memory");
             int idx = 0;
 #pragma unroll
@@ -197,7 +215,9 @@ __global__ __launch_bounds__(kBlock) void spmm_grouproll(
                 asm volatile("" ::: "memory");
             }
             woff += cnt;
-            w = wn;
+#pragma unroll
+            for (int q = 0; q < NW; ++q)
+                w[q] = wn[q];
             mv = mvn;
             base = nbase;
         }

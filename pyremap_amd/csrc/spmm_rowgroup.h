@@ -51,6 +51,10 @@ template <>
 struct F64Vec<8> {
     typedef double type __attribute__((ext_vector_type(8), aligned(8)));
 };
+template <>
+struct F64Vec<16> {
+    typedef double type __attribute__((ext_vector_type(16), aligned(8)));
+};
 
 // LOCK (diagnostic build only, tune[5] >= 100; measured and NOT adopted, see
 // profiles/r03_analysis/lockstep.md): the waves of a workgroup -- the groups
@@ -70,7 +74,7 @@ __global__ __launch_bounds__(BLOCK) void spmm_rowgroup(
     const int32_t *__restrict__ grid, const double *__restrict__ gfrac,
     const XT *__restrict__ X)
 {
-    constexpr bool kPrefetch = (G == 8 && UNR <= 8);
+    constexpr bool kPrefetch = (G >= 8 && UNR <= 8);
     typedef typename XVec<XT, VEC>::type xvec_t;
     typedef typename I32Vec<UNR>::type ivec_t;
     typedef typename I32Vec<G>::type rvec_t;
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(BLOCK) void spmm_rowgroup(
                     // 4-row groups an entry has ~1.1 owners and the 4 extra
                     // VGPRs cost a wave per SIMD: left in the member blocks.
                     constexpr bool kHoist =
-                        MODE == REMAP_MODE_MASKED && G == 8;
+                        MODE == REMAP_MODE_MASKED && G >= 8;
                     double xz[TILES][VEC], vf[TILES][VEC];
 #pragma unroll
                     for (int t = 0; t < TILES; ++t)

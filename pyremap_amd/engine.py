@@ -29,6 +29,7 @@ MODE_MASKED = 2
 FLAG_FMA = 1
 FLAG_TUNE_HINT = 4
 FLAG_TREE = 8
+FLAG_CELL_MASKS = 16   # masked mode, a hint: validity is per source cell
 
 #: long rows apart (RemapPlan._split_long_rows): up to this many fields the
 #: long rows run one wave per (row, few columns) -- family 9 -- beyond it on
@@ -49,7 +50,7 @@ CELL_MAX_RUN = 4
 DTYPE_F64 = 0
 DTYPE_F32 = 1
 
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 #: readable pad entries kept behind col/val (remap_csr.csr_pad)
 CSR_PAD = 8
@@ -64,6 +65,7 @@ EXPORTS = (
     'remap_abi_version', 'remap_arch', 'remap_last_error',
     'remap_device_count', 'remap_apply_f64', 'remap_csr_from_coo_workspace',
     'remap_csr_from_coo', 'remap_stream_copy', 'remap_scan_nan',
+    'remap_scan_nan_kinds',
     'remap_groups_workspace', 'remap_groups_build',
     'remap_patches_workspace', 'remap_patches_build',
     'remap_schedule_sizes', 'remap_schedule_auto',
@@ -334,6 +336,10 @@ def load_library():
         ctypes.c_void_p]
     lib.remap_scan_nan.restype = ctypes.c_int
     lib.remap_scan_nan.argtypes = [ctypes.c_void_p, ctypes.c_int32,
+                                   ctypes.c_int64, ctypes.c_void_p,
+                                   ctypes.c_void_p]
+    lib.remap_scan_nan_kinds.restype = ctypes.c_int
+    lib.remap_scan_nan_kinds.argtypes = [ctypes.c_void_p, ctypes.c_int32,
                                    ctypes.c_int64, ctypes.c_void_p,
                                    ctypes.c_void_p]
     lib.remap_stream_copy.restype = ctypes.c_int
@@ -1010,8 +1016,8 @@ class RemapPlan:
         torch = _torch()
         lib = load_library()
         G = int(rows or self.GROUP)
-        if G not in (4, 8):
-            raise ValueError('row groups hold 4 or 8 rows')
+        if G not in (4, 8, 16):
+            raise ValueError('row groups hold 4, 8 or 16 rows')
         self.groups = None
         if self.nnz == 0 or self.n_b == 0:
             return None
@@ -1746,16 +1752,28 @@ def scan_nan(x, flag):
     """
     Asynchronously OR 1 into ``flag`` (int32 device tensor, zeroed by the
     caller) if the float32/float64 device tensor ``x`` holds a NaN: the
-    device half of ``remap_numpy.py:201-204``.
+    device half of ``remap_numpy.py:201-204``.  A ``flag`` of two elements
+    also receives the KIND of the missing values (``remap_scan_nan_kinds``):
+    ``flag[1]`` = 0 (no NaN), 1 (NaNs in whole aligned runs: whole cells of
+    an ``(n_a, K)`` field) or 3 (NaNs column by column).
     """
     torch = _torch()
     lib = load_library()
     if not x.is_contiguous():
         raise ValueError('scan_nan needs a contiguous tensor')
     dtype = {torch.float64: DTYPE_F64, torch.float32: DTYPE_F32}[x.dtype]
+    fn, name = (lib.remap_scan_nan_kinds, 'remap_scan_nan_kinds') \
+        if flag.numel() >= 2 else (lib.remap_scan_nan, 'remap_scan_nan')
     with torch.cuda.device(x.device):
-        _check(lib.remap_scan_nan(_ptr(x), dtype, x.numel(), _ptr(flag),
-                                  _stream_ptr(x.device)), 'remap_scan_nan')
+        _check(fn(_ptr(x), dtype, x.numel(), _ptr(flag),
+                  _stream_ptr(x.device)), name)
+
+
+def cell_mask_form(plan):
+    """Does ``plan`` run the masked mode faster with FLAG_CELL_MASKS when
+    whole cells are missing (8-row groups: entry-rich mappings)?"""
+    groups = getattr(plan, 'groups', None)
+    return bool(groups) and groups.get('rows') == 8
 
 
 def remap_tensor_auto_mode(plan, dst_grid_dims, field, remap_axes, threshold,
@@ -1764,7 +1782,8 @@ def remap_tensor_auto_mode(plan, dst_grid_dims, field, remap_axes, threshold,
     ``_remap_data_array``'s branch (``remap_numpy.py:201-204``) without a
     host round trip: the masked, renormalised result if ``field`` holds a
     NaN, the ``frac_b``-normalised one if not.  One scan, two gated launches
-    (the one whose gate is closed does nothing), nothing synchronises.
+    (the one whose gate is closed does nothing; three on entry-rich mappings,
+    whose masked branch has two forms), nothing synchronises.
     """
     torch = _torch()
     if hasattr(plan, 'shards'):
@@ -1780,9 +1799,23 @@ def remap_tensor_auto_mode(plan, dst_grid_dims, field, remap_axes, threshold,
                             MODE_MASKED if masked else MODE_FRACB,
                             threshold=threshold if masked else 0.0,
                             flags=flags, out=out)
+    X = field.contiguous()
+    if flag is None and cell_mask_form(plan):
+        # entry-rich mapping: the scan also tells whole missing cells from
+        # values missing column by column, and the masked branch comes in
+        # the form that suits (REMAP_FLAG_CELL_MASKS): three gated launches
+        kinds = torch.zeros(2, dtype=torch.int32, device=field.device)
+        scan_nan(X, kinds)
+        Y = remap_tensor(plan, dst_grid_dims, X, remap_axes, MODE_MASKED,
+                         threshold=threshold, flags=flags | FLAG_CELL_MASKS,
+                         out=out, gate=kinds[1:], gate_value=1)
+        Y = remap_tensor(plan, dst_grid_dims, X, remap_axes, MODE_MASKED,
+                         threshold=threshold, flags=flags, out=Y,
+                         gate=kinds[1:], gate_value=3)
+        return remap_tensor(plan, dst_grid_dims, X, remap_axes, MODE_FRACB,
+                            flags=flags, out=Y, gate=kinds, gate_value=0)
     if flag is None:
         flag = torch.zeros(1, dtype=torch.int32, device=field.device)
-    X = field.contiguous()
     scan_nan(X, flag)
     Y = remap_tensor(plan, dst_grid_dims, X, remap_axes, MODE_MASKED,
                      threshold=threshold, flags=flags, out=out, gate=flag,

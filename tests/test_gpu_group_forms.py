@@ -1,0 +1,210 @@
+"""
+The round-5 forms of kernel family 10 (row groups), every value against the
+oracle, bit for bit, through the C ABI:
+
+* `spmm_groupmask` (csrc/spmm_groupmask.h): the masked mode of the 8-row
+  groups with per-ROW normalisers while a source cell is valid or missing in
+  all of a wave's columns, and the general form for the groups where it is
+  not -- whole cells missing, single values missing, nothing missing, NaN /
+  Inf weights;
+* the chunk-minor work list (tune[4] = 3);
+* the rolling form (csrc/spmm_grouproll.h, tune[5] = 26 / 28);
+* 16-row groups (2 x 8 tiles).
+Reference arithmetic: remap_numpy.py:258-278.
+"""
+import numpy as np
+import pytest
+
+from helpers import assert_bitwise
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'these tests need an MI355X'
+    from pyremap_amd import engine
+    engine.load_library()
+    return torch.device('cuda', 0)
+
+
+def _problem(dev, rows, n_a=1500, dims=(38, 60), k=(6, 22), seed=5):
+    from oracle import oracle
+    from pyremap_amd import engine, synthetic
+    m = synthetic.conservative_map(n_a, dims, k[0], k[1], seed=seed,
+                                   signed=True, locality='mesh')
+    mm = m.numpy()
+    plan = engine.RemapPlan.from_triplets(
+        mm['row'], mm['col'], mm['S'], mm['frac_b'], m.n_a, m.n_b,
+        index_base=1, device=dev)
+    csr = oracle.coo_to_csr(mm['row'] - 1, mm['col'] - 1, mm['S'], m.n_b,
+                            m.n_a)
+    plan.build_groups(m.dst_dims, super_tile=32, rows=rows)
+    return m, mm, plan, csr
+
+
+def _check(plan, csr, frac_b, x, dev, mode, thr, tune, what, flags=0):
+    from oracle import oracle
+    from pyremap_amd import engine
+    xd = torch.from_numpy(x).to(dev)
+    y, mask = engine.remap_tensor(plan, None, xd, [0], mode, threshold=thr,
+                                  tune=tune, want_mask=True, flags=flags)
+    if mode == engine.MODE_RAW:
+        assert_bitwise(y.cpu().numpy(), oracle.csr_matvecs(csr, x), what)
+        return
+    ref, ref_mask = oracle.remap_flat(csr, frac_b, x,
+                                      mode == engine.MODE_MASKED, thr)
+    ref = ref.copy()
+    ref[ref_mask] = np.nan
+    assert_bitwise(y.cpu().numpy(), ref, what)
+    assert np.array_equal(mask.cpu().numpy().astype(bool), ref_mask), what
+
+
+def _fields(n_a, K, seed):
+    """(tag, field): nothing missing / whole cells / single values / both,
+    the first and the last cell and column among them."""
+    rng = np.random.default_rng(seed)
+    base = rng.standard_normal((n_a, K))
+    out = [('no NaN', base.copy())]
+    x = base.copy()
+    x[rng.random(n_a) < 0.25] = np.nan
+    x[0] = np.nan
+    out.append(('whole cells', x))
+    x = base.copy()
+    x[rng.random((n_a, K)) < 0.02] = np.nan
+    x[-1, -1] = np.nan
+    out.append(('single values', x))
+    x = base.copy()
+    x[rng.random(n_a) < 0.2] = np.nan
+    x[rng.random(n_a) < 0.05, K // 2:] = np.nan     # deep levels only
+    x[5, 0] = np.nan
+    out.append(('cells and levels', x))
+    return out
+
+
+@pytest.mark.parametrize('K', [130, 256, 300, 1024])
+def test_masked_groups_per_row_normaliser(dev, K):
+    """REMAP_FLAG_CELL_MASKS on 8-row groups -> spmm_groupmask, whatever is
+    missing; the same bits as without the flag."""
+    from pyremap_amd import engine
+    m, mm, plan, csr = _problem(dev, 8)
+    for tag, x in _fields(m.n_a, K, K):
+        for tune in ([10, 1, 2, 1], [10, 4, 2, 2, 3], [10, 1, 1, 1],
+                     [10, 1, 2, 1, 0, 9], None):
+            for flags in (engine.FLAG_CELL_MASKS, 0,
+                          engine.FLAG_CELL_MASKS | engine.FLAG_FMA):
+                if flags & engine.FLAG_FMA:
+                    continue      # (covered by test_cell_masks_fma_is_close)
+                _check(plan, csr, mm['frac_b'], x, dev, engine.MODE_MASKED,
+                       0.3, tune, f'{tag} K={K} tune={tune} flags={flags}',
+                       flags=flags)
+
+
+def test_cell_masks_fma_is_close(dev):
+    """REMAP_FLAG_FMA with REMAP_FLAG_CELL_MASKS: rtol 1e-13, same mask."""
+    from oracle import oracle
+    from pyremap_amd import engine
+    m, mm, plan, csr = _problem(dev, 8)
+    for tag, x in _fields(m.n_a, 512, 77):
+        xd = torch.from_numpy(x).to(dev)
+        y, mask = engine.remap_tensor(
+            plan, None, xd, [0], engine.MODE_MASKED, threshold=0.3,
+            want_mask=True,
+            flags=engine.FLAG_CELL_MASKS | engine.FLAG_FMA)
+        ref, ref_mask = oracle.remap_flat(csr, mm['frac_b'], x, True, 0.3)
+        got = y.cpu().numpy()
+        assert np.array_equal(mask.cpu().numpy().astype(bool), ref_mask), tag
+        ok = ~ref_mask
+        np.testing.assert_allclose(got[ok], ref[ok], rtol=1e-12, atol=1e-13)
+
+
+def test_scan_kinds_and_three_gated_launches(dev):
+    """remap_scan_nan_kinds tells whole missing cells from values missing
+    column by column; `remap_tensor_auto_mode` on an entry-rich mapping
+    enqueues the masked branch in both forms and the frac_b branch, each
+    gated -- the reference's result (remap_numpy.py:201-204, 258-278) for
+    every kind of field."""
+    from oracle import oracle
+    from pyremap_amd import engine
+    m, mm, plan, csr = _problem(dev, 8)
+    assert engine.cell_mask_form(plan)
+    want = {'no NaN': (0, 0), 'whole cells': (1, 1),
+            'single values': (1, 3), 'cells and levels': (1, 3)}
+    for tag, x in _fields(m.n_a, 384, 3):
+        xd = torch.from_numpy(x).to(dev)
+        kinds = torch.zeros(2, dtype=torch.int32, device=dev)
+        engine.scan_nan(xd, kinds)
+        assert tuple(kinds.tolist()) == want[tag], (tag, kinds.tolist())
+        one = torch.zeros(1, dtype=torch.int32, device=dev)
+        engine.scan_nan(xd, one)
+        assert int(one) == want[tag][0]
+        y = engine.remap_tensor_auto_mode(plan, m.dst_dims, xd, [0], 0.3)
+        masked = bool(np.isnan(x).any())
+        ref, ref_mask = oracle.remap_flat(csr, mm['frac_b'], x, masked, 0.3)
+        ref = ref.copy()
+        ref[ref_mask] = np.nan
+        assert_bitwise(y.cpu().numpy().reshape(m.n_b, -1), ref, tag)
+    # float32 fields: runs of 256 elements; a view that starts inside an
+    # allocation has its first elements peeled (judged "column by column")
+    x32 = np.random.default_rng(0).standard_normal((64, 256)).astype(
+        np.float32)
+    x32[3] = np.nan
+    kinds = torch.zeros(2, dtype=torch.int32, device=dev)
+    engine.scan_nan(torch.from_numpy(x32).to(dev), kinds)
+    assert tuple(kinds.tolist()) == (1, 1)
+    big = torch.from_numpy(np.concatenate([[0.0], x32.ravel().astype(
+        np.float64)])).to(dev)
+    kinds.zero_()
+    engine.scan_nan(big[1:], kinds)
+    assert tuple(kinds.tolist()) == (1, 3)
+
+
+def test_masked_groups_odd_weights_take_the_general_form(dev):
+    """A NaN or an Inf weight on a cell missing in every column: `a * 0.0` is
+    NaN there, so the skip of the fast form does not apply."""
+    from oracle import oracle
+    from pyremap_amd import engine, synthetic
+    m = synthetic.conservative_map(900, (24, 40), 6, 18, seed=9, signed=True,
+                                   locality='mesh')
+    mm = m.numpy()
+    S = mm['S'].copy()
+    S[7] = np.inf
+    S[1000] = np.nan
+    S[2000] = -np.inf
+    plan = engine.RemapPlan.from_triplets(
+        mm['row'], mm['col'], S, mm['frac_b'], m.n_a, m.n_b, index_base=1,
+        device=dev)
+    csr = oracle.coo_to_csr(mm['row'] - 1, mm['col'] - 1, S, m.n_b, m.n_a)
+    plan.build_groups(m.dst_dims, super_tile=32, rows=8)
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((m.n_a, 256))
+    x[rng.random(m.n_a) < 0.3] = np.nan
+    for c in (mm['col'][7], mm['col'][1000], mm['col'][2000]):
+        x[c - 1] = np.nan
+    for flags in (engine.FLAG_CELL_MASKS, 0):
+        _check(plan, csr, mm['frac_b'], x, dev, engine.MODE_MASKED, 0.1,
+               [10, 1, 2, 1], f'odd weights, flags {flags}', flags=flags)
+
+
+@pytest.mark.parametrize('rows', [4, 8, 16])
+@pytest.mark.parametrize('K', [130, 512])
+def test_group_forms_bitwise(dev, rows, K):
+    """Rolling form, chunk-minor list, 16-row groups: three modes each."""
+    from pyremap_amd import engine
+    m, mm, plan, csr = _problem(dev, rows)
+    rng = np.random.default_rng(K + rows)
+    x = rng.standard_normal((m.n_a, K))
+    x[rng.random(m.n_a) < 0.15] = np.nan
+    x[rng.random((m.n_a, K)) < 0.01] = np.nan
+    tunes = [[10, 1, 2, 1], [10, 1, 1, 1, 3], [10, 4, 2, 2, 3]]
+    tunes += [[10, 1, 2, 1, 0, 28], [10, 1, 1, 1, 3, 26],
+              [10, 4, 2, 2, 0, 28], [10, 2, 1, 2, 0, 26]]
+    if rows == 16:
+        tunes.append([10, 1, 1, 1, 0, 4])
+    for tune in tunes:
+        for mode, thr in ((engine.MODE_FRACB, 0.0),
+                          (engine.MODE_MASKED, 0.2), (engine.MODE_RAW, 0.0)):
+            _check(plan, csr, mm['frac_b'], x, dev, mode, thr, tune,
+                   f'rows={rows} K={K} tune={tune} mode={mode}')

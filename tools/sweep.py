@@ -25,6 +25,9 @@ def main():
     ap.add_argument('--fields', type=int, default=None)
     ap.add_argument('--mode', default='fracb')
     ap.add_argument('--locality', default='raster')
+    ap.add_argument('--mask', default='cells',
+                    choices=['cells', 'levels', 'coast', 'few'],
+                    help='masked mode: which values are NaN')
     ap.add_argument('--tunes', default='0')
     ap.add_argument('--flags', default='0')
     ap.add_argument('--rounds', type=int, default=7)
@@ -63,7 +66,20 @@ def main():
           for _ in range(args.sets)]
     if args.mode == 'masked':
         for x in xs:
-            x[torch.rand(m.n_a, device=dev) < 0.25, :] = float('nan')
+            if args.mask == 'cells':      # whole cells missing (land)
+                x[torch.rand(m.n_a, device=dev) < 0.25, :] = float('nan')
+            elif args.mask == 'levels':
+                # (Time, level) columns, 64 levels: a cell is missing below
+                # its own depth (bathymetry) -- validity differs by lane
+                depth = torch.randint(8, 65, (m.n_a, 1), device=dev)
+                lev = (torch.arange(K + args.x_pad, device=dev) % 64)[None]
+                x[lev >= depth] = float('nan')
+            elif args.mask == 'coast':
+                # land = one corner of the source numbering (a contiguous
+                # fifth of the cells): most groups see no NaN at all
+                x[: m.n_a // 5, :] = float('nan')
+            elif args.mask == 'few':
+                x[torch.rand(m.n_a, device=dev) < 0.001, :] = float('nan')
     ys = [torch.empty((plan.n_b, K + args.y_pad), device=dev,
                       dtype=torch.float64)
           for _ in range(args.sets)]
