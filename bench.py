@@ -739,10 +739,14 @@ def pcie_inclusive(args):
     return out
 
 
-def load_traffic(name, K, mode, locality='mesh'):
+def load_traffic(name, K, mode, locality='mesh', family=None):
     """PMC-measured HBM bytes per launch, from a committed rocprofv3 run
     (`traffic_<workload>_mesh.json` for the mesh numbering, the round-2
-    files `traffic_<workload>.json` for the raster numbering)."""
+    files `traffic_<workload>.json` for the raster numbering).  The file is
+    a CONSTANT of the library it was measured on: it carries that library's
+    ABI version and the kernel's symbol, and is refused (traffic: null) when
+    either differs from what runs now -- a later kernel must not go on
+    quoting an earlier kernel's counters."""
     suffix = {'raster': '', 'mesh': '_mesh'}.get(locality)
     if suffix is None:
         return None, None
@@ -754,6 +758,12 @@ def load_traffic(name, K, mode, locality='mesh'):
     with open(path) as f:
         t = json.load(f)
     if t.get('K') != K or t.get('mode') != mode:
+        return None, None
+    from pyremap_amd import engine
+    if t.get('abi_version') != engine.ABI_VERSION:
+        return None, None
+    kernel = KERNEL_OF_FAMILY.get(family)
+    if kernel is not None and kernel not in (t.get('kernel') or ''):
         return None, None
     return t.get('hbm_bytes_per_launch'), t.get('source')
 
@@ -948,7 +958,9 @@ def measure_extras(ready, args, dist, extra, long_last=True):
             extra[tag]['read_frac_of_peak'] = r['bytes_alg_read'] / (
                 r['kernel_ms_mean'] * 1e-3) / 1e9 / HBM_PEAK_GBPS
             # (the committed counter traffic is that of the (n_a, K) layout)
-            traffic, _ = load_traffic(w.name, w.K, w.mode, w.locality) \
+            traffic, _ = load_traffic(
+                w.name, w.K, w.mode, w.locality,
+                (r.get('schedule') or {}).get('family')) \
                 if w.layout == 'nk' and w.dtype == 'f64' else (None, None)
             extra[tag]['traffic'] = traffic
             if dist is not None and w.sharded:
@@ -1098,8 +1110,9 @@ def compose_line(args, res, world, ceiling, cpu, extra, pipelined,
     content (everything else).
     """
     K = res['K']
-    traffic, traffic_src = load_traffic(args.workload, K, res['mode'],
-                                        args.locality)
+    traffic, traffic_src = load_traffic(
+        args.workload, K, res['mode'], args.locality,
+        (res.get('schedule') or {}).get('family'))
     kernel_ms = res.get('kernel_ms_mean_max_rank', res['kernel_ms_mean'])
     achieved = res['bytes_alg'] / (kernel_ms * 1e-3) / 1e9
     multi = None

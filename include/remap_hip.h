@@ -57,6 +57,14 @@ extern "C" {
 
 #define REMAP_ABI_VERSION 24
 
+/* The library is built with -fvisibility=hidden: the entry points declared
+ * here, and nothing else, are its dynamic symbols. */
+#if defined(__GNUC__) || defined(__clang__)
+#define REMAP_API __attribute__((visibility("default")))
+#else
+#define REMAP_API
+#endif
+
 enum {
     REMAP_OK = 0,
     REMAP_ERR_ARG = -1,         /* bad argument (NULL, negative size, ...)  */
@@ -365,18 +373,18 @@ typedef struct remap_apply_args {
 } remap_apply_args;
 
 /* ABI / build information */
-int remap_abi_version(void);
-const char *remap_arch(void);       /* "gfx950" */
-const char *remap_last_error(void); /* thread-local, never NULL */
+REMAP_API int remap_abi_version(void);
+REMAP_API const char *remap_arch(void);       /* "gfx950" */
+REMAP_API const char *remap_last_error(void); /* thread-local, never NULL */
 
 /* Number of visible HIP devices, or a negative REMAP_ERR_HIP. */
-int remap_device_count(void);
+REMAP_API int remap_device_count(void);
 
 /*
  * Apply the weights (asynchronous on `stream`).  Replaces
  * remap_numpy.py:258-278 (and, through the strides, :254-256 and :280-295).
  */
-int remap_apply_f64(const remap_apply_args *args, void *stream);
+REMAP_API int remap_apply_f64(const remap_apply_args *args, void *stream);
 
 /*
  * COO -> CSR on the device: scipy's `csr_matrix((S, (row, col)))` of
@@ -392,9 +400,9 @@ int remap_apply_f64(const remap_apply_args *args, void *stream);
  * All outputs are written asynchronously on `stream`.  Query the workspace
  * size first; the workspace is plain device memory owned by the caller.
  */
-int remap_csr_from_coo_workspace(int64_t nnz, int64_t n_rows,
+REMAP_API int remap_csr_from_coo_workspace(int64_t nnz, int64_t n_rows,
                                  size_t *bytes_out);
-int remap_csr_from_coo(int64_t n_rows, int64_t n_cols, int64_t nnz,
+REMAP_API int remap_csr_from_coo(int64_t n_rows, int64_t n_cols, int64_t nnz,
                        const int32_t *row, const int32_t *col,
                        const double *S, int32_t index_base,
                        int64_t *rowptr_out, int32_t *col_out,
@@ -425,8 +433,9 @@ int remap_csr_from_coo(int64_t n_rows, int64_t n_cols, int64_t nnz,
  *   group_rid, group_frac  (device) n_groups * G
  *   n_union_out  (device) one int64: union entries actually used
  */
+REMAP_API
 int remap_groups_workspace(int64_t n_rows, int64_t nnz, size_t *bytes_out);
-int remap_groups_build(const remap_csr *A, const double *frac_b,
+REMAP_API int remap_groups_build(const remap_csr *A, const double *frac_b,
                        int32_t group_rows, const int64_t *grid_dims,
                        int64_t row_offset, int32_t super_tile,
                        int32_t *row_order_out, int64_t *group_meta,
@@ -453,8 +462,9 @@ int remap_groups_build(const remap_csr *A, const double *frac_b,
  *                 patch_row_bytes) and to decide whether the tile fits
  * Asynchronous on `stream`; nothing is allocated.
  */
+REMAP_API
 int remap_patches_workspace(int64_t n_rows, int64_t nnz, size_t *bytes_out);
-int remap_patches_build(const remap_csr *A, const int64_t *grid_dims,
+REMAP_API int remap_patches_build(const remap_csr *A, const int64_t *grid_dims,
                         int64_t row_offset, int32_t tile_y, int32_t tile_x,
                         int32_t *row_order_out, int32_t *patch_ptr,
                         int32_t *patch_ucol, int32_t *patch_rowptr,
@@ -513,9 +523,10 @@ typedef struct remap_schedule {
     size_t arena_used;           /* bytes of the arena the schedule occupies */
 } remap_schedule;
 
+REMAP_API
 int remap_schedule_sizes(int64_t n_rows, int64_t nnz, size_t *arena_bytes,
                          size_t *workspace_bytes);
-int remap_schedule_auto(const remap_csr *A, const double *frac_b,
+REMAP_API int remap_schedule_auto(const remap_csr *A, const double *frac_b,
                         const int64_t *grid_dims, int32_t n_dims,
                         int64_t row_offset, void *arena, size_t arena_bytes,
                         void *workspace, size_t workspace_bytes,
@@ -582,7 +593,7 @@ typedef struct remap_field {
     uint32_t flags;              /* REMAP_FLAG_FMA, REMAP_FLAG_TREE          */
 } remap_field;
 
-int remap_plan_create(int64_t n_b, int64_t n_a, int64_t n_s,
+REMAP_API int remap_plan_create(int64_t n_b, int64_t n_a, int64_t n_s,
                       const int32_t *row, const int32_t *col, const double *S,
                       int32_t index_base, const double *frac_b,
                       int32_t host_input, const int64_t *dst_grid_dims,
@@ -606,9 +617,11 @@ int remap_plan_create(int64_t n_b, int64_t n_a, int64_t n_s,
  * memory (remap_plan_apply never does) and synchronises `stream`; a second
  * call does nothing.
  */
-int remap_plan_prepare_short_runs(remap_plan *plan, void *stream);
-void remap_plan_destroy(remap_plan *plan);
+REMAP_API int remap_plan_prepare_short_runs(remap_plan *plan, void *stream);
+REMAP_API void remap_plan_destroy(remap_plan *plan);
+REMAP_API
 int remap_plan_query(const remap_plan *plan, remap_plan_info *info_out);
+REMAP_API
 int remap_plan_apply(const remap_plan *plan, const remap_field *field,
                      void *stream);
 
@@ -617,6 +630,7 @@ int remap_plan_apply(const remap_plan *plan, const remap_field *field,
  * elements of x (device, REMAP_DTYPE_*, element-aligned) is a NaN.
  * Asynchronous on `stream`; the device half of remap_numpy.py:201-204.
  */
+REMAP_API
 int remap_scan_nan(const void *x, int32_t x_dtype, int64_t n, int32_t *flag,
                    void *stream);
 
@@ -632,7 +646,7 @@ int remap_scan_nan(const void *x, int32_t x_dtype, int64_t n, int32_t *flag,
  * REMAP_FLAG_CELL_MASKS gated on kinds[1] == 1, MASKED without it gated on
  * kinds[1] == 3.  A hint only: results never depend on it.
  */
-int remap_scan_nan_kinds(const void *x, int32_t x_dtype, int64_t n,
+REMAP_API int remap_scan_nan_kinds(const void *x, int32_t x_dtype, int64_t n,
                          int32_t *kinds, void *stream);
 
 /*
@@ -656,12 +670,13 @@ int remap_scan_nan_kinds(const void *x, int32_t x_dtype, int64_t n,
  *   buffer that travels to the shard's GPU; strides in BYTES.
  * Both asynchronous on `stream`; nothing is allocated.
  */
-int remap_pack_columns_workspace(int64_t n_cols, size_t *bytes_out);
+REMAP_API int remap_pack_columns_workspace(int64_t n_cols, size_t *bytes_out);
+REMAP_API
 int remap_pack_columns(const int32_t *col, int64_t nnz, int64_t n_cols,
                        int32_t *col_out, int32_t *ucols_out,
                        int64_t *n_ucols_out, int64_t *bad_out,
                        void *workspace, size_t workspace_bytes, void *stream);
-int remap_gather_rows(const void *src, int64_t n_batch,
+REMAP_API int remap_gather_rows(const void *src, int64_t n_batch,
                       int64_t src_batch_stride_bytes,
                       int64_t src_row_stride_bytes, const int32_t *rows,
                       int64_t n_rows, int64_t row_bytes, void *dst,
@@ -671,6 +686,7 @@ int remap_gather_rows(const void *src, int64_t n_batch,
  * Device-to-device streaming copy of `bytes` (16 B per lane, grid-stride):
  * the box's achievable HBM ceiling, reported beside the roofline numbers.
  */
+REMAP_API
 int remap_stream_copy(void *dst, const void *src, size_t bytes, void *stream);
 
 /*
@@ -683,6 +699,7 @@ int remap_stream_copy(void *dst, const void *src, size_t bytes, void *stream);
  * kernel such as the LDS patch kernel runs 5.2 or 6.4 ms per launch on
  * config 4 depending on it).  Measurement only.
  */
+REMAP_API
 int remap_clock_probe(int64_t *ticks_out, int32_t micros, void *stream);
 
 #ifdef __cplusplus

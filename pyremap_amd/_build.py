@@ -35,7 +35,8 @@ def is_stale():
     if not os.path.exists(LIB_PATH):
         return True
     built = os.path.getmtime(LIB_PATH)
-    deps = sources() + [os.path.join(INCLUDE, 'remap_hip.h')] + \
+    deps = sources() + [os.path.join(INCLUDE, 'remap_hip.h'),
+                        os.path.join(CSRC, 'libremap_hip.map')] + \
         [os.path.join(CSRC, f) for f in os.listdir(CSRC)
          if f.endswith('.h')]
     return any(os.path.getmtime(d) > built for d in deps)
@@ -59,8 +60,12 @@ def build_library(force=False, verbose=False):
     # minute: hundreds of kernel instantiations), then one link
     obj_dir = os.path.join(LIB_DIR, 'obj')
     os.makedirs(obj_dir, exist_ok=True)
+    # -fvisibility=hidden: the library's dynamic symbols are the REMAP_API
+    # entry points of include/remap_hip.h and nothing else (no mangled
+    # remap::... helpers, no kernel stubs)
     common = [hipcc, '-O3', '-std=c++17', f'--offload-arch={ARCH}',
-              '-ffp-contract=off', '-fPIC', f'-I{INCLUDE}', f'-I{CSRC}']
+              '-ffp-contract=off', '-fPIC', '-fvisibility=hidden',
+              f'-I{INCLUDE}', f'-I{CSRC}']
     headers = [os.path.join(INCLUDE, 'remap_hip.h')] + \
         [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
     newest_header = max(os.path.getmtime(h) for h in headers)
@@ -86,8 +91,9 @@ def build_library(force=False, verbose=False):
         raise RuntimeError('hipcc failed:\n' + '\n'.join(failed))
     objs = [os.path.join(obj_dir, os.path.basename(src) + '.o')
             for src in sources()]
-    cmd = [hipcc, f'--offload-arch={ARCH}', '-fPIC', '-shared', '-o',
-           LIB_PATH] + objs
+    cmd = [hipcc, f'--offload-arch={ARCH}', '-fPIC', '-shared',
+           '-Wl,--version-script=' + os.path.join(CSRC, 'libremap_hip.map'),
+           '-o', LIB_PATH] + objs
     if verbose:
         print(' '.join(cmd))
     proc = subprocess.run(cmd, stdout=subprocess.PIPE,

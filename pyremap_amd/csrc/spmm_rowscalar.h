@@ -35,6 +35,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc_sized(
                                              bytes, 0x00020000);
 }
 
+// cache policy of the X loads (the builtin's aux operand: bit 0 sc0, bit 1
+// nt, bit 4 sc1).  0 in the product; tools/build_diag.py xaux<N> builds the
+// A/B variants (profiles/r05_analysis/config5_forms.md)
+#ifndef REMAP_X_AUX
+#define REMAP_X_AUX 0
+#endif
+
 template <typename XT, int VEC>
 __device__ __forceinline__ typename XVec<XT, VEC>::type load_x_buf(
     __amdgpu_buffer_rsrc_t r, uint32_t byte_off)
@@ -42,13 +49,16 @@ __device__ __forceinline__ typename XVec<XT, VEC>::type load_x_buf(
     typedef typename XVec<XT, VEC>::type xvec_t;
     if constexpr (sizeof(xvec_t) == 16) {
         return __builtin_bit_cast(
-            xvec_t, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+            xvec_t, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0,
+                                                          REMAP_X_AUX));
     } else if constexpr (sizeof(xvec_t) == 8) {
         return __builtin_bit_cast(
-            xvec_t, __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 0));
+            xvec_t, __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0,
+                                                         REMAP_X_AUX));
     } else {
         return __builtin_bit_cast(
-            xvec_t, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+            xvec_t, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0,
+                                                         REMAP_X_AUX));
     }
 }
 

@@ -37,6 +37,26 @@ def test_library_loads_and_exports_every_symbol():
     assert lib.remap_arch() == b'gfx950'
 
 
+def test_library_exports_nothing_but_the_header(tmp_path):
+    """`nm -D`: the dynamic symbols the library DEFINES are the REMAP_API
+    entry points of include/remap_hip.h, exactly -- no mangled remap::...
+    helper, no kernel launch stub (built with -fvisibility=hidden)."""
+    import shutil
+    import subprocess
+    from pyremap_amd import _build, engine
+    engine.load_library()
+    nm = shutil.which('nm') or '/opt/rocm/lib/llvm/bin/llvm-nm'
+    out = subprocess.run([nm, '-D', '--defined-only', _build.LIB_PATH],
+                         capture_output=True, text=True, check=True).stdout
+    defined = sorted(line.split()[-1] for line in out.splitlines()
+                     if line.strip())
+    # (toolchain-made symbols of every shared object aside)
+    defined = [d for d in defined if d not in ('_init', '_fini', '_edata',
+                                               '_end', '__bss_start')]
+    assert defined == _header_functions(), \
+        sorted(set(defined) ^ set(_header_functions()))
+
+
 def test_struct_layout_matches_header():
     """Field order of the ctypes mirror == field order in the header."""
     from pyremap_amd import engine

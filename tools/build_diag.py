@@ -9,6 +9,8 @@ Build the DIAGNOSTIC variants of libremap_hip.so (never the product):
                                         stamps (tools/stamps.py)
     python tools/build_diag.py plain    -DREMAP_PLAIN_STORES  write-back instead of
                                         non-temporal Y stores (an A/B)
+    python tools/build_diag.py xaux2    -DREMAP_X_AUX=2  cache policy of the X
+                                        loads (1 sc0, 2 nt, 16 sc1, 17, 3 ...)
     python tools/build_diag.py ceiling  tools/hbm_ceiling.hip -> executable
 
 Outputs go to tools/_build/ (git-ignored; they still travel to the GPU box).
@@ -41,8 +43,11 @@ def main():
                  '-o', os.path.join(OUT, 'hbm_ceiling'),
                  os.path.join(ROOT, 'tools', 'hbm_ceiling.hip')])
             continue
-        define = {'diag': '-DREMAP_DIAG', 'stamps': '-DREMAP_STAMPS',
-                  'plain': '-DREMAP_PLAIN_STORES'}[w]
+        if w.startswith('xaux'):   # cache policy of the X loads (A/B)
+            define = f'-DREMAP_X_AUX={int(w[4:])}'
+        else:
+            define = {'diag': '-DREMAP_DIAG', 'stamps': '-DREMAP_STAMPS',
+                      'plain': '-DREMAP_PLAIN_STORES'}[w]
         run([hipcc, '-O3', '-std=c++17', f'--offload-arch={_build.ARCH}',
              '-ffp-contract=off', '-fPIC', '-shared', define,
              f'-I{_build.INCLUDE}', f'-I{_build.CSRC}', '-o',

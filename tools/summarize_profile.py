@@ -22,6 +22,8 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 
+from pyremap_amd.engine import ABI_VERSION  # noqa: E402
+
 
 def newest(paths):
     """gpurun MERGES a run's files into gpurun_out/: files of earlier runs
@@ -178,6 +180,7 @@ def main():
                 fetch_size_raw_kib=pmc['FETCH_SIZE'][0],
                 write_size_raw_kib=pmc['WRITE_SIZE'][0],
                 kernel=pmc['FETCH_SIZE'][4],
+                abi_version=ABI_VERSION,
                 kernel_ms_mean_under_pmc=cfg['roofline']['kernel_ms_mean']
                 if cfg else None,
                 source=f'profiles/{tag}_summary.md: rocprofv3 --pmc '
