@@ -247,6 +247,152 @@ class OnDevice:
         return data
 
 
+#: a Dataset's variables of one shape and dtype, each at most this large,
+#: travel and are remapped TOGETHER (remap_host_batch), at most
+#: BATCH_TOTAL_BYTES of them at a time
+BATCH_VAR_BYTES = 16 << 20
+BATCH_TOTAL_BYTES = 256 << 20
+
+
+class PendingBatch:
+    """Several same-shaped arrays remapped as ONE stacked array
+    (:func:`remap_host_batch`): :meth:`result` waits for the one download and
+    returns the list of result arrays -- views of one pinned buffer, which
+    returns to torch's pool when the last of them is collected."""
+
+    def __init__(self, event, out, pinned):
+        self._event, self._out, self._pinned = event, out, pinned
+        self._done = None
+        self._guard = weakref.finalize(self, _release_pinned, pinned)
+
+    def result(self):
+        if self._done is None:
+            self._event.synchronize()
+            self._guard.detach()
+            whole = self._out.numpy()
+            weakref.finalize(whole, _release_pinned, self._pinned)
+            self._done = [whole[v] for v in range(whole.shape[0])]
+            self._out = None
+        return self._done
+
+
+def remap_host_batch(plan, dst_grid_dims, arrays, remap_axes, *, mode,
+                     threshold=None, flags=0):
+    """
+    ``[remap_host_array(a, ...).result() for a in arrays]`` for host arrays
+    of ONE shape and dtype -- the dozens of ``(Time = 1, nCells)`` variables
+    of a climatology Dataset, each a few microseconds of device work behind
+    ~150 us of per-call host work (reference: the per-variable loop of
+    ``remap_numpy.py:42-55``) -- as one stacked array: V uploads into one
+    device buffer, the reference's per-variable ``isnan(values).any()``
+    (``:201-204``) as one device reduction and ONE read-back of V flags, one
+    launch per run of variables that take the same branch, one download.
+    The values of every variable are those of its own call, bit for bit:
+    a variable is a set of whole batches of the stacked launch, and every
+    kernel family sums a row's entries in the same order.
+    ``mode``: ``'fracb'`` or ``'auto'``.  Returns a :class:`PendingBatch`.
+    """
+    torch = engine.require_gpu()
+    device = plan.device
+    arrays = [_as_uploadable(a) for a in arrays]
+    shape, dtype = arrays[0].shape, arrays[0].dtype
+    if any(a.shape != shape or a.dtype != dtype for a in arrays):
+        raise ValueError('remap_host_batch: arrays of one shape and dtype')
+    if mode not in ('fracb', 'auto'):
+        raise ValueError(f'unknown mode {mode!r}')
+    if mode == 'auto' and threshold is None:
+        raise ValueError('the masked branch needs a threshold')
+    V, nd = len(arrays), len(shape)
+    axes = [int(a) % nd for a in remap_axes]
+    lead = min(axes)
+    dst_shape = [int(d) for d in dst_grid_dims] \
+        if dst_grid_dims is not None and plan.n_b == plan.n_b_global \
+        else [plan.n_b]
+    out_shape = [V] + list(shape[:lead]) + dst_shape + \
+        [int(shape[ax]) for ax in range(lead, nd) if ax not in axes]
+    stacked_axes = [a + 1 for a in axes]
+    # sub-batches on three streams: the variables of sub-batch s + 1 travel
+    # up while those of s are computed and travel down (PCIe is full duplex)
+    n_sub = 1 if V < 8 else min(4, V // 4)
+    bounds = [V * k // n_sub for k in range(n_sub + 1)]
+    up, down = _side_streams(device)
+    with torch.cuda.device(device):
+        main = torch.cuda.current_stream(device)
+        x_d = torch.empty((V,) + tuple(shape), device=device,
+                          dtype=torch.from_numpy(arrays[0][:0]).dtype)
+        y_d = torch.empty(out_shape, dtype=torch.float64, device=device)
+        out_h, pinned = _host_buffer(out_shape, torch.float64)
+        try:
+            up.wait_stream(main)
+            down.wait_stream(main)
+            # a copy from pageable memory holds its host thread until it is
+            # staged (1.9 MB: ~40 us): a feeder thread issues the uploads,
+            # this one the launches and downloads of what has arrived
+            arrivals = queue.Queue()
+
+            def uploader():
+                try:
+                    with torch.cuda.device(device), torch.cuda.stream(up):
+                        for k in range(n_sub):
+                            for v in range(bounds[k], bounds[k + 1]):
+                                x_d[v].copy_(torch.from_numpy(arrays[v]),
+                                             non_blocking=True)
+                            ev = torch.cuda.Event()
+                            ev.record(up)
+                            arrivals.put(ev)
+                except BaseException as exc:   # noqa: BLE001 - handed over
+                    arrivals.put(exc)
+
+            feeder = threading.Thread(target=uploader, daemon=True)
+            feeder.start()
+            for k in range(n_sub):
+                lo, hi = bounds[k], bounds[k + 1]
+                uploaded = arrivals.get()
+                if isinstance(uploaded, BaseException):
+                    feeder.join()
+                    raise uploaded
+                main.wait_event(uploaded)
+                if mode == 'fracb':
+                    engine.remap_tensor(plan, dst_grid_dims, x_d[lo:hi],
+                                        stacked_axes, engine.MODE_FRACB,
+                                        flags=flags, out=y_d[lo:hi])
+                else:
+                    # which variables hold a NaN: one reduction, one
+                    # read-back (it waits for this sub-batch's uploads --
+                    # they are needed anyway)
+                    has = torch.isnan(x_d[lo:hi].view(hi - lo, -1)).any(
+                        dim=1).cpu().tolist()
+                    v0 = 0
+                    while v0 < hi - lo:
+                        v1 = v0 + 1
+                        while v1 < hi - lo and has[v1] == has[v0]:
+                            v1 += 1
+                        engine.remap_tensor(
+                            plan, dst_grid_dims, x_d[lo + v0:lo + v1],
+                            stacked_axes,
+                            engine.MODE_MASKED if has[v0] else
+                            engine.MODE_FRACB,
+                            threshold=float(threshold) if has[v0] else 0.0,
+                            flags=flags, out=y_d[lo + v0:lo + v1])
+                        v0 = v1
+                ev = torch.cuda.Event()
+                ev.record(main)
+                down.wait_event(ev)
+                with torch.cuda.stream(down):
+                    out_h[lo:hi].copy_(y_d[lo:hi], non_blocking=True)
+            feeder.join()
+            x_d.record_stream(up)
+            y_d.record_stream(down)
+            event = torch.cuda.Event()
+            event.record(down)
+            # (the caller's stream sees the batch finished as well)
+            main.wait_event(event)
+        except BaseException:
+            _release_pinned(pinned)
+            raise
+    return PendingBatch(event, out_h, pinned)
+
+
 def remap_host_array(plan, dst_grid_dims, values, remap_axes, *, mode,
                      threshold=None, want_mask=False, flags=0,
                      host_mask=None, keep_on_device=False):

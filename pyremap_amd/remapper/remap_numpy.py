@@ -347,6 +347,70 @@ def _start_data_array(da, remapper, renormalization_threshold,
     return finish
 
 
+def _batches(remapper, ds, names):
+    """
+    ``{name: [names of its batch]}`` for the variables that are remapped
+    TOGETHER (``host_path.remap_host_batch``): at least two variables with
+    the same dims, shape and dtype, each at most ``BATCH_VAR_BYTES`` --
+    a climatology file's dozens of ``(Time, nCells)`` fields.  One device,
+    host arrays; everything else keeps the per-variable pipeline.
+    """
+    plan = getattr(remapper, '_matrix', None)
+    if getattr(remapper, '_process_group', None) is not None or \
+            plan is None or hasattr(plan, 'shards'):
+        return {}
+    groups = {}
+    src_dims = remapper.src_descriptor.dims
+    for name in names:
+        da = ds[name]
+        values = da.values
+        if not isinstance(values, np.ndarray) or values.dtype.kind not in \
+                'fiub' or values.nbytes > host_path.BATCH_VAR_BYTES or \
+                values.size == 0:
+            continue
+        hit = [dim in src_dims for dim in da.dims]
+        if sum(hit) != len(src_dims):
+            continue
+        dtype = values.dtype if values.dtype in (np.float32, np.float64) \
+            else np.dtype(np.float64)
+        groups.setdefault((tuple(da.dims), values.shape, dtype.str),
+                          []).append(name)
+    out = {}
+    for members in groups.values():
+        per = max(1, ds[members[0]].values.nbytes)
+        cap = max(2, host_path.BATCH_TOTAL_BYTES // per)
+        for i in range(0, len(members), cap):
+            part = members[i:i + cap]
+            if len(part) >= 2:
+                for name in part:
+                    out[name] = part
+    return out
+
+
+def _start_batch(ds, names, remapper, renormalization_threshold):
+    """``{name: finish}`` as :func:`_start_data_array` gives them, for the
+    variables of one batch: one stacked upload / launch / download."""
+    first = ds[names[0]]
+    remap_axes, _, _ = _plan_data_array(first, remapper)
+    pending = host_path.remap_host_batch(
+        remapper._matrix, remapper._ds_map.dst_grid_dims,
+        [ds[name].values for name in names], remap_axes,
+        mode='fracb' if renormalization_threshold is None else 'auto',
+        threshold=renormalization_threshold, flags=remapper.engine_flags)
+    out = {}
+    for index, name in enumerate(names):
+        da = ds[name]
+        _, dims, coords = _plan_data_array(da, remapper)
+        make = _array_class(da).from_dict
+
+        def finish(index=index, dims=dims, coords=coords, make=make,
+                   attrs=da.attrs, name=name):
+            return make({'coords': coords, 'attrs': attrs, 'dims': dims,
+                         'data': pending.result()[index], 'name': name})
+        out[name] = finish
+    return out
+
+
 class _LookAhead:
     """
     ``Dataset.map`` calls its function one variable at a time; this keeps the
@@ -360,12 +424,21 @@ class _LookAhead:
         self.threshold, self.depth = threshold, depth
         self.started = {}
         self.position = 0
+        self.batches = _batches(remapper, ds, self.names)
 
     def _start_up_to(self, last):
         while self.position <= min(last, len(self.names) - 1):
             name = self.names[self.position]
-            self.started[name] = _start_data_array(
-                self.ds[name], self.remapper, self.threshold)
+            if name not in self.started:
+                batch = self.batches.get(name)
+                if batch is not None:
+                    # small variables of one shape: together (the whole
+                    # batch starts with its first member)
+                    self.started.update(_start_batch(
+                        self.ds, batch, self.remapper, self.threshold))
+                else:
+                    self.started[name] = _start_data_array(
+                        self.ds[name], self.remapper, self.threshold)
             self.position += 1
 
     def __call__(self, da, *unused):

@@ -208,3 +208,83 @@ def test_group_forms_bitwise(dev, rows, K):
                           (engine.MODE_MASKED, 0.2), (engine.MODE_RAW, 0.0)):
             _check(plan, csr, mm['frac_b'], x, dev, mode, thr, tune,
                    f'rows={rows} K={K} tune={tune} mode={mode}')
+
+
+# ---------------------------------------------------------------------------
+# A Dataset's small variables of one shape: remapped together
+# (host_path.remap_host_batch; reference: the per-variable loop of
+# remap_numpy.py:42-55)
+# ---------------------------------------------------------------------------
+def test_dataset_small_variables_are_batched_bitwise(dev, monkeypatch):
+    from oracle import oracle
+    from pyremap_amd import DataArray, Dataset, Remapper, host_path, synthetic
+    from pyremap_amd.remapper import remap_numpy as rn
+    m = synthetic.conservative_map(900, (20, 36), 2, 7, seed=12,
+                                   locality='mesh')
+    mm = m.numpy()
+    csr = oracle.coo_to_csr(mm['row'] - 1, mm['col'] - 1, mm['S'], m.n_b,
+                            m.n_a)
+
+    class Desc:
+        pass
+    src, dst = Desc(), Desc()
+    src.dims, src.dim_sizes = ['nCells'], [m.n_a]
+    dst.dims, dst.dim_sizes = ['lat', 'lon'], list(m.dst_dims)
+    dst.coords, dst.mesh_name = {}, 'toy'
+    r = Remapper.from_triplets(mm['row'], mm['col'], mm['S'], mm['frac_b'],
+                               src, dst, device=dev)
+    rng = np.random.default_rng(4)
+    ds = Dataset()
+    fields = {}
+    for v in range(9):
+        x = rng.standard_normal((1, m.n_a))
+        if v in (1, 2, 5, 8):
+            x[:, rng.random(m.n_a) < 0.2] = np.nan
+        fields[f'v{v}'] = x
+        ds[f'v{v}'] = DataArray(x, dims=('Time', 'nCells'),
+                                attrs={'units': f'u{v}'})
+    x3 = rng.standard_normal((3, m.n_a, 4)).astype(np.float32)
+    x3[1, 7, 2] = np.nan
+    ds['deep_a'] = DataArray(x3, dims=('Time3', 'nCells', 'nLev'))
+    ds['deep_b'] = DataArray(x3[::-1].copy(),
+                             dims=('Time3', 'nCells', 'nLev'))
+    ds['count'] = DataArray(rng.integers(0, 9, (1, m.n_a)),
+                            dims=('Time', 'nCells'))
+    ds['scalar'] = DataArray(np.arange(3.0), dims=('Time3',))
+    calls = []
+    real = host_path.remap_host_batch
+
+    def spy(plan, dims, arrays, axes, **kw):
+        calls.append(len(arrays))
+        return real(plan, dims, arrays, axes, **kw)
+    monkeypatch.setattr(host_path, 'remap_host_batch', spy)
+    for thr in (0.05, None):
+        calls.clear()
+        out = r.remap_numpy(ds, thr)
+        # (Time, nCells): the nine float64 fields and the integer one (it is
+        # upcast as scipy upcasts it) together; the two float32 3-D fields too
+        assert sorted(calls) == [2, 10], calls
+        assert list(out.data_vars) == list(ds.data_vars)
+        for name in ds.data_vars:
+            da = ds[name]
+            got = out[name]
+            if name == 'scalar':
+                assert np.array_equal(got.values, da.values)
+                continue
+            assert got.attrs == da.attrs
+            # the same variable on its own: the per-variable pipeline
+            alone = rn._remap_data_array(da, r, thr)
+            assert list(got.dims) == list(alone.dims)
+            assert_bitwise(got.values, alone.values, f'{name} thr={thr}')
+            x = np.asarray(da.values, dtype=np.float64)
+            axis = da.dims.index('nCells')
+            flat = np.moveaxis(x, axis, 0).reshape(m.n_a, -1)
+            masked = thr is not None and bool(np.isnan(flat).any())
+            ref, ref_mask = oracle.remap_flat(csr, mm['frac_b'], flat,
+                                              masked, thr or 0.0)
+            ref = ref.copy()
+            ref[ref_mask] = np.nan
+            want = np.moveaxis(ref.reshape((m.n_b,) + tuple(
+                s for a, s in enumerate(x.shape) if a != axis)), 0, axis)
+            want = want.reshape(got.values.shape)
+            assert_bitwise(got.values, want, f'{name} thr={thr} vs oracle')
