@@ -156,6 +156,12 @@ typedef struct remap_csr {
  * while consecutive steps use them; the rows of a step are dealt to 8
  * compute waves, `rows_per_wave` each.  Every row still adds its entries in
  * ascending column order: results are unchanged.
+ * The schedule is TRUSTED: the library checks the scalar fields only.  At
+ * most 64 arrival pairs per step, arrival slots below ring_slots / 2, record
+ * offsets and meta blocks inside meta_slot_bytes are the builder's to keep
+ * (pyremap_amd/strips.py does, tests/test_strips_cpu.py replays it); a
+ * schedule that breaks them makes the LDS-DMA write outside the ring.  Build
+ * it with pyremap_amd.strips.build_strips or leave `strips` NULL.
  */
 typedef struct remap_strips {
     int64_t n_units;
@@ -573,6 +579,10 @@ typedef struct remap_plan_info {
     int32_t group_rows;
     double ratio;
     size_t device_bytes;         /* device memory the plan holds             */
+    int32_t cell_patch_rows;     /* rows per patch of the lanes-across-rows
+                                  * plan remap_plan_prepare_short_runs built
+                                  * (0: not built)                           */
+    int32_t reserved;
 } remap_plan_info;
 
 typedef struct remap_field {

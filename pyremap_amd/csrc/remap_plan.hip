@@ -727,6 +727,7 @@ int build_patch_set(remap_plan *plan, int32_t ty, int32_t tx, Fits fits,
     A.csr_pad = kCsrPad;
     const bool two_d = plan->n_dims == 2;
     int64_t h[3] = {0, 0, 0};
+    bool to_256 = false;
     for (;;) {
         rc = remap_patches_build(
             &A, two_d ? plan->grid_dims : nullptr, 0, ty, tx,
@@ -746,10 +747,16 @@ int build_patch_set(remap_plan *plan, int32_t ty, int32_t tx, Fits fits,
         // rows): 256-row patches (engine.RemapPlan.cell_patches)
         // ... where such large patches are few (a map with tens of
         // thousands of them keeps them: config 4's, (32, n) 3.3 vs 5.7 ms)
-        const bool dst_heavy =
-            dst_heavy_rule && ty * tx > 256 && 2 * h[1] < (int64_t)ty * tx &&
-            (n_b + (int64_t)ty * tx - 1) / ((int64_t)ty * tx) < 1024;
-        if (fits((int64_t)ty * tx, h[1], h[2]) && !dst_heavy)
+        // (decided ONCE, on the first plan that fits -- as
+        // engine.RemapPlan.cell_patches decides it -- and then straight
+        // down to <= 256 rows: re-deciding at every halving stopped at 512
+        // rows where the halved plan no longer looked "few")
+        const bool ok = fits((int64_t)ty * tx, h[1], h[2]);
+        if (ok && !to_256 && dst_heavy_rule && ty * tx > 256 &&
+            2 * h[1] < (int64_t)ty * tx &&
+            (n_b + (int64_t)ty * tx - 1) / ((int64_t)ty * tx) < 1024)
+            to_256 = true;
+        if (ok && (!to_256 || ty * tx <= 256))
             break;
         if (ty * tx == 1)
             return REMAP_OK;   // nothing fits: the set stays empty
@@ -926,6 +933,8 @@ int remap_plan_query(const remap_plan *plan, remap_plan_info *info_out)
     info_out->group_rows = plan->sched.group_rows;
     info_out->ratio = plan->sched.ratio;
     info_out->device_bytes = plan->device_bytes;
+    info_out->cell_patch_rows = plan->cell_rows;
+    info_out->reserved = 0;
     return REMAP_OK;
 }
 

@@ -38,7 +38,10 @@
 //    the chunk-major work list, so the ~nnz/n_a re-touches of a source row by
 //    neighbouring destination rows hit that XCD's L2 instead of going back
 //    to Infinity Cache / HBM eight times.
+#include <cstdlib>
 #include <type_traits>
+
+#include <hip/hip_ext.h>
 
 #include "remap_common.h"
 
@@ -707,8 +710,8 @@ int check_args(const remap_apply_args *a, Call &c)
                  st->meta_slot_bytes > 0 && st->meta_slot_bytes % 1024 == 0 &&
                  st->waves >= 1 && st->waves + st->depth <= 16 &&
                  (int64_t)(st->ring_slots + 2) * kStripRowBytes +
-                         (int64_t)(st->depth + 1) * st->meta_slot_bytes <=
-                     (int64_t)kPatchLdsMax &&
+                         (int64_t)(st->depth + 1) * st->meta_slot_bytes +
+                         256 <= (int64_t)kPatchLdsMax &&
                  st->unit_steps && st->arr_ptr && st->arr_src &&
                  st->arr_slot && st->meta_ptr && st->meta &&
                  // the whole mapping, float64, one batch of contiguous
@@ -1309,9 +1312,14 @@ int run_strip(const remap_apply_args *a, const Call &c, KParams p,
     case 5: fn = pick_strip_mode<5>(a->mode, c.fma); break;
     default: fn = pick_strip_mode<6>(a->mode, c.fma); break;
     }
+    // + 256 bytes of slack: the compute waves read a row's records sixteen
+    // at a time (lane l: record l % 16) whatever the row holds -- on the
+    // last row of a block that fills its meta slot the look-ahead read runs
+    // up to 192 bytes past the block; the values are never used, the
+    // addresses stay inside the allocation
     const uint32_t lds_bytes =
         static_cast<uint32_t>(st->ring_slots + 2) * kStripRowBytes +
-        static_cast<uint32_t>(st->depth + 1) * st->meta_slot_bytes;
+        static_cast<uint32_t>(st->depth + 1) * st->meta_slot_bytes + 256;
     if (lds_bytes > 64 * 1024)
         REMAP_HIP_CHECK(hipFuncSetAttribute(
             reinterpret_cast<const void *>(fn),
@@ -1458,6 +1466,22 @@ int run_longwave(const remap_apply_args *a, const Call &c, KParams p,
             reinterpret_cast<const void *>(fn),
             hipFuncAttributeMaxDynamicSharedMemorySize,
             static_cast<int>(lds_bytes)));
+#ifdef REMAP_DIAG
+    // (experiment, diagnostic build: the long rows' launch without the AQL
+    // barrier bit -- hipExtAnyOrderLaunch -- so that it may overlap the short
+    // rows' launch in front of it; hip_ext.h says gfx9 ignores the flag)
+    if (getenv("REMAP_ANY_ORDER")) {
+        hipExtLaunchKernelGGL(
+            fn, dim3(static_cast<uint32_t>(grid)),
+            dim3(static_cast<uint32_t>(a->patch_rows) * kWave), lds_bytes,
+            stream, nullptr, nullptr, hipExtAnyOrderLaunch, p, a->flags,
+            a->patch_rowptr, a->patch_val, a->patch_lidx, a->patch_ptr,
+            a->patch_ucol, a->row_order, a->frac_b, a->patch_rows,
+            a->patch_umax, static_cast<int32_t>(epitch), a->n_patches);
+        REMAP_HIP_CHECK(hipGetLastError());
+        return REMAP_OK;
+    }
+#endif
     hipLaunchKernelGGL(fn, dim3(static_cast<uint32_t>(grid)),
                        dim3(static_cast<uint32_t>(a->patch_rows) * kWave),
                        lds_bytes, stream, p, a->flags, a->patch_rowptr,

@@ -180,6 +180,8 @@ __global__ __launch_bounds__(kWave) void spmm_longrow(const KParams p,
     }
     const int64_t o = i * p.ldy + static_cast<int64_t>(b) * p.bsy + k;
     __builtin_nontemporal_store(y, p.Y + o);
+#ifndef REMAP_STAMPS   // (there mask_out is the stamps buffer)
     if (p.mask_out)
         p.mask_out[o] = ok ? 0 : 1;
+#endif
 }

@@ -65,9 +65,9 @@ __device__ __forceinline__ double lds_read_f64(uint32_t addr)
 // Sixteen records of a batch (one per lane in `off` / `w`, replicated in the
 // four 16-lane rows): ALL the LDS reads first, then the products added in
 // order.  FULL: every record counts.  Otherwise records [j0, j1) count
-// (window borders, row tails): the others are read all the same -- wherever
-// their (512-byte aligned) offsets point; LDS reads beyond the allocation
-// return 0 -- and their sums dropped behind a wave-uniform test.
+// (window borders, row tails): the others are read all the same -- the
+// caller points them at the window's first cell -- and their sums dropped
+// behind a wave-uniform test.
 template <int MODE, bool FMA, bool FULL>
 struct LongBatch {
     template <int J>
@@ -107,6 +107,7 @@ struct LongBatch {
                                                double &acc, double &den)
     {
         double x[16];
+        dpp_settle(off, mine, w);
         reads<0>(off, mine, x);
         // (left alone hipcc keeps three reads ahead of the sums; sixteen
         // measured the same -- the sums are issue-bound -- and cost nothing)
@@ -292,9 +293,16 @@ __global__ __launch_bounds__(kPatchBlock) void spmm_longwave(
             if (n_in == 16)
                 LongBatch<MODE, FMA, true>::run(co, cw, mine, 0, 16, acc,
                                                 den);
-            else if (n_in > 0)
-                LongBatch<MODE, FMA, false>::run(co, cw, mine, j0, j0 + n_in,
-                                                 acc, den);
+            else if (n_in > 0) {
+                // records that do not count (before j0, beyond the window or
+                // the row) read the window's first cell: every address stays
+                // inside the buffer, their sums are dropped
+                const bool counts = l16 >= j0 && l16 < j0 + n_in;
+                LongBatch<MODE, FMA, false>::run(
+                    counts ? co
+                           : static_cast<uint32_t>(lo) * kLongCellBytes,
+                    cw, mine, j0, j0 + n_in, acc, den);
+            }
             s += n_in;
             if (j0 + n_in < m)
                 break;   // the rest of the row lies beyond this window

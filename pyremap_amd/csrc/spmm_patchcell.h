@@ -164,8 +164,10 @@ __global__ __launch_bounds__(kCellBlock) void spmm_patchcell(
             }
             const int64_t o = i * p.ldy + yo[t];
             __builtin_nontemporal_store(y, p.Y + o);
+#ifndef REMAP_STAMPS   // (there mask_out is the stamps buffer)
             if (p.mask_out)
                 p.mask_out[o] = ok ? 0 : 1;
+#endif
         }
     }
 }
@@ -216,6 +218,7 @@ __global__ __launch_bounds__(BLOCK) void spmm_patchtime(
     const int64_t L = logical_block(p);
     if (L >= p.n_blocks)
         return;
+    REMAP_CLOCK_BEGIN();
     (void)flags;
     (void)ell_base;
     const int64_t group = L / n_patches;   // runs of chunks: the slow index
@@ -375,8 +378,10 @@ __global__ __launch_bounds__(BLOCK) void spmm_patchtime(
                     const int64_t o =
                         i * p.ldy + static_cast<int64_t>(b) * p.bsy + k;
                     __builtin_nontemporal_store(y, p.Y + o);
+#ifndef REMAP_STAMPS   // (there mask_out is the stamps buffer)
                     if (p.mask_out)
                         p.mask_out[o] = ok ? 0 : 1;
+#endif
                 }
             }
         }
@@ -396,10 +401,13 @@ __global__ __launch_bounds__(BLOCK) void spmm_patchtime(
                     const int64_t o =
                         static_cast<int64_t>(rid_lds[r]) * p.ldy + ob + k;
                     __builtin_nontemporal_store(out[q], p.Y + o);
+#ifndef REMAP_STAMPS   // (there mask_out is the stamps buffer)
                     if (p.mask_out)
                         p.mask_out[o] = okb[q];
+#endif
                 }
             }
         }
     }
+    REMAP_CLOCK_END();
 }

@@ -59,6 +59,20 @@ __device__ __forceinline__ void strip_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// The DPP read hazard: a DPP instruction must not read a VGPR a VALU
+// instruction wrote less than 2 wait states before it, and LLVM's hazard
+// recogniser does not look into inline asm (which is how the DPP operations
+// below are issued).  Every batch passes its DPP operands through this once:
+// whatever wrote them, two wait states lie between that and the first DPP
+// read.  (A `v_cndmask` put in front of `strip_addr` in round 5 did produce
+// wrong sums on the device before this; tools/dpp_hazard_scan.py checks
+// every DPP site of the built library.)
+__device__ __forceinline__ void dpp_settle(uint32_t &off, uint32_t &lane8,
+                                           double &w)
+{
+    asm volatile("s_nop 1" : "+v"(off), "+v"(lane8), "+v"(w));
+}
+
 // lane j of every 16-lane row, to all lanes of that row (DPP row_newbcast)
 template <int J>
 __device__ __forceinline__ uint32_t strip_addr(uint32_t off, uint32_t lane8)
@@ -121,6 +135,7 @@ struct StripBatch {
                                                double &den)
     {
         double x[16];
+        dpp_settle(off, lane8, w);
         reads<0>(off, lds, lane8, x);
         sums<0>(w, x, acc, den);
     }

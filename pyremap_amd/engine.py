@@ -199,6 +199,8 @@ class _PlanInfo(ctypes.Structure):     # struct remap_plan_info
         ('group_rows', ctypes.c_int32),
         ('ratio', ctypes.c_double),
         ('device_bytes', ctypes.c_size_t),
+        ('cell_patch_rows', ctypes.c_int32),
+        ('reserved', ctypes.c_int32),
     ]
 
 

@@ -535,3 +535,53 @@ def test_plan_handle_short_level_runs(dev):
                             f'{dtype.__name__} masked {masked}')
     finally:
         lib.remap_plan_destroy(handle)
+
+
+@pytest.mark.parametrize('case', ['fine_to_coarse', 'coarse_to_fine',
+                                  'coarse_to_fine_many'])
+def test_plan_handle_and_python_agree_on_the_cell_patches(dev, case):
+    """`remap_plan_prepare_short_runs` (C) and `RemapPlan.cell_patches`
+    (Python) build the lanes-across-rows patch plan by ONE rule -- the tile
+    halved until it fits; on a coarse -> fine map whose large patches are
+    few, straight down to <= 256 rows, decided once: the same rows per patch
+    on both sides (`remap_plan_info.cell_patch_rows`)."""
+    import ctypes
+    from pyremap_amd import engine, synthetic
+    if case == 'fine_to_coarse':
+        m = synthetic.conservative_map(120000, (300, 480), 3, 7, seed=2,
+                                       device=dev, locality='mesh')
+    else:
+        # bilinear from a coarse grid: ~4 entries per row, few source cells
+        # per patch (a 600-patch and a 2 400-patch case either side of the
+        # "few large patches" rule)
+        src = (150, 256) if case == 'coarse_to_fine' else (300, 512)
+        dst = (src[0] * 4, src[1] * 4)
+        m = synthetic.bilinear_map(src, dst, device=dev)
+    mm = m.numpy()
+    lib = engine.load_library()
+    handle = ctypes.c_void_p()
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    dims = (ctypes.c_int64 * 2)(*m.dst_dims)
+
+    def host(a, t):
+        return np.ascontiguousarray(a, dtype=t).ctypes.data
+
+    assert lib.remap_plan_create(
+        m.n_b, m.n_a, len(mm['S']), host(mm['row'], np.int32),
+        host(mm['col'], np.int32), host(mm['S'], np.float64), 1,
+        host(mm['frac_b'], np.float64), 1, dims, 2, stream,
+        ctypes.byref(handle)) == 0, lib.remap_last_error()
+    try:
+        assert lib.remap_plan_prepare_short_runs(handle, stream) == 0, \
+            lib.remap_last_error()
+        info = engine._PlanInfo()
+        assert lib.remap_plan_query(handle, ctypes.byref(info)) == 0
+        plan = engine.RemapPlan.from_triplets(
+            m.row, m.col, m.S, m.frac_b, m.n_a, m.n_b, index_base=1,
+            device=dev)
+        plan.auto_schedule(m.dst_dims)
+        q = plan.cell_patches()
+        assert info.cell_patch_rows == q['rows'], \
+            (case, info.cell_patch_rows, q['rows'], q['tile'], q['umax'])
+    finally:
+        lib.remap_plan_destroy(handle)

@@ -9,6 +9,9 @@ TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$ROOT"
 mkdir -p gpurun_out
+# the DPP read hazard (inline-asm DPP operations: LLVM does not check them)
+python tools/dpp_hazard_scan.py > gpurun_out/dpp_hazard_scan.log 2>&1 || { cat gpurun_out/dpp_hazard_scan.log; echo "FAIL: DPP hazard"; exit 1; }
+tail -1 gpurun_out/dpp_hazard_scan.log
 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1
 echo "pytest exit $?" >> gpurun_out/pytest_gpu.log
 tail -3 gpurun_out/pytest_gpu.log
@@ -40,3 +43,12 @@ for f in sorted(glob.glob('gpurun_out/bench_*.json')) + \
     except Exception as e:   # noqa: BLE001
         print(f, 'ERR', e)
 PY
+# the committed summary must be younger than the kernels it describes
+SUM=profiles/${TAG}_summary.md
+if [ -f "$SUM" ] && command -v git > /dev/null && [ -d .git ]; then
+  KERN=$(git log -1 --format=%ct -- pyremap_amd/csrc 2>/dev/null || echo 0)
+  SUMT=$(git log -1 --format=%ct -- "$SUM" 2>/dev/null || echo 0)
+  if [ "${SUMT:-0}" -lt "${KERN:-0}" ]; then
+    echo "FAIL: $SUM is older than the last commit under pyremap_amd/csrc: regenerate it (tools/summarize_profile.py $TAG ...)"; exit 1
+  fi
+fi
