@@ -600,7 +600,8 @@ typedef struct remap_field {
     uint8_t *mask_out;           /* (device) or NULL                         */
     const int32_t *gate;         /* (device) or NULL: see remap_apply_args   */
     int32_t gate_value;
-    uint32_t flags;              /* REMAP_FLAG_FMA, REMAP_FLAG_TREE          */
+    uint32_t flags;              /* REMAP_FLAG_FMA, REMAP_FLAG_TREE,
+                                  * REMAP_FLAG_CELL_MASKS                    */
 } remap_field;
 
 REMAP_API int remap_plan_create(int64_t n_b, int64_t n_a, int64_t n_s,

@@ -12,6 +12,10 @@ space on `X[ucols]`; every third seed through a 2- or 3-"device"
 MultiDeviceRemap.  Round 4: half the seeds also through the opaque C plan
 handle (remap_plan_create / _apply, with and without
 remap_plan_prepare_short_runs) -- its own routing against the same oracle.
+Round 5: masks of whole cells / of columns / both; every masked case also
+with REMAP_FLAG_CELL_MASKS and through remap_tensor_auto_mode (scan + gated
+launches); a Dataset of same-shaped variables (batched) == variable by
+variable.
 
     python tools/fuzz_medium.py [seconds=480] [first_seed=0]
 """
@@ -193,12 +197,22 @@ def one(seed, dev):
         arg, thr = field, None
         if masked:
             cells = rng.random(m.n_a) < 0.2
+            # round 5: whole cells missing as often as values missing from
+            # some column on (the per-row and the per-lane form of the
+            # masked mode on entry-rich maps, spmm_groupmask.h), and both
+            whole = rng.random()
             if axis == 0:
-                field[cells, shape[1] // 2:] = np.nan
+                if whole < 0.6:
+                    field[rng.random(m.n_a) < 0.15] = np.nan
+                if whole > 0.4:
+                    field[cells, shape[1] // 2:] = np.nan
             elif len(shape) == 2:
                 field[shape[0] // 2:, cells] = np.nan
             else:
-                field[:, cells, shape[2] // 2:] = np.nan
+                if whole < 0.5:
+                    field[:, rng.random(m.n_a) < 0.15] = np.nan
+                if whole > 0.3:
+                    field[:, cells, shape[2] // 2:] = np.nan
             thr = float(rng.choice([0.0, 0.05, 0.5]))
             arg = np.ma.masked_array(field, mask=np.isnan(field))
         ref = oracle.remap_numpy_array(csr, frac_b, m.dst_dims, arg, [axis],
@@ -214,6 +228,17 @@ def one(seed, dev):
                 f'{np.dtype(dtype).name} masked={masked} thr {thr}')
         assert tuple(y.shape) == ref.shape, what
         assert_bitwise(y.cpu().numpy(), ref, what)
+        if masked:
+            # the hint changes the kernel form, never the bits; and the
+            # device-side choice (scan + gated launches) is the reference's
+            yf = engine.remap_tensor(plan, m.dst_dims, x, [axis], emode,
+                                     threshold=thr or 0.0,
+                                     flags=engine.FLAG_CELL_MASKS)
+            assert_bitwise(yf.cpu().numpy(), ref, what + ' cell-masks hint')
+            if np.isnan(field).any():
+                ya = engine.remap_tensor_auto_mode(plan, m.dst_dims, x,
+                                                   [axis], thr)
+                assert_bitwise(ya.cpu().numpy(), ref, what + ' auto mode')
         if handle is not None:
             yh = handle.apply(x, shape, axis, masked, thr)
             assert_bitwise(yh.cpu().numpy().reshape(ref.shape), ref,
@@ -317,6 +342,29 @@ def dataarray_level(seed, dev):
         assert list(out.dims) == want_dims, what
         assert out.values.dtype == np.float64, what
         assert_bitwise(out.values, ref, what)
+    # round 5: a Dataset of several same-shaped variables (travel and are
+    # remapped together, host_path.remap_host_batch) == each on its own
+    from pyremap_amd import Dataset
+    from pyremap_amd.remapper import remap_numpy as rn
+    lead = [('Time', int(rng.integers(1, 4)))] if rng.random() < 0.7 else []
+    tail = [('nLev', int(rng.integers(1, 6)))] if rng.random() < 0.4 else []
+    dims = lead + list(zip(src_dims, m.src_dims)) + tail
+    names = [d[0] for d in dims]
+    shape = [int(d[1]) for d in dims]
+    ds = Dataset()
+    for v in range(int(rng.integers(2, 12))):
+        data = rng.standard_normal(shape).astype(
+            rng.choice(['f8', 'f8', 'f4']))
+        if rng.random() < 0.5:
+            data[rng.random(shape) < 0.1] = np.nan
+        ds[f'v{v}'] = DataArray(data, dims=names)
+    thr = None if rng.random() < 0.4 else float(rng.choice([0.0, 0.1, 0.6]))
+    out = r.remap_numpy(ds, thr)
+    for name in ds.data_vars:
+        alone = rn._remap_data_array(ds[name], r, thr)
+        assert list(out[name].dims) == list(alone.dims)
+        assert_bitwise(out[name].values, alone.values,
+                       f'seed {seed} Dataset {name} {shape} thr {thr}')
 
 
 def main():
