@@ -1090,6 +1090,10 @@ def print_line(line):
 OPTIONAL_TIMEOUT_S = int(os.environ.get('BENCH_OPTIONAL_TIMEOUT_S', 150))
 
 
+#: ... and the sharded tens-of-GB workloads of an N > 1 run
+BIG_TIMEOUT_S = int(os.environ.get('BENCH_BIG_TIMEOUT_S', 420))
+
+
 #: the line's size limit (the driver keeps the last 8 KB of stdout)
 LINE_LIMIT = 4096
 
@@ -1263,8 +1267,12 @@ def main():
     t = mark('prepare_metric_workload_s', t)
     ready = prepare_extras(args, rank, world, dist, extra, big=False)
     t = mark('prepare_small_extras_s', t)
-    measure_big_extras(args, rank, world, dist, extra)
-    t = mark('big_extras_s', t)
+    if world == 1:
+        measure_big_extras(args, rank, world, dist, extra)
+        t = mark('big_extras_s', t)
+    # (N > 1: the sharded tens-of-GB workloads run AFTER the metric is in
+    # hand, under the watchdog -- their broadcasts move 15-30 GB over a
+    # fabric no test could exercise)
     ceiling = copy_ceiling(device)
     t = mark('copy_ceiling_s', t)
     pipelined = None
@@ -1305,8 +1313,8 @@ def main():
             if rank == 0:
                 late = dict(res['exchange'] or {})
                 late['optional_measurements'] = (
-                    f'timed out after {OPTIONAL_TIMEOUT_S} s: packed / '
-                    f'pipelined exchange did not return')
+                    'timed out: the packed / pipelined exchange or a '
+                    'sharded extra workload did not return')
                 res['exchange'] = late
                 line, details = compose_line(
                     args, res, world, ceiling, None, extra, None,
@@ -1326,6 +1334,19 @@ def main():
         barrier(dist)
         watchdog.cancel()
         t = mark('exchange_measurements_s', t)
+        # the sharded headline / config 4 / config 5 (multi_gpu.workloads),
+        # under a watchdog of their own
+        if world > 1:
+            watchdog = threading.Timer(BIG_TIMEOUT_S, bail)
+            watchdog.daemon = True
+            watchdog.start()
+            measure_big_extras(args, rank, world, dist, extra)
+            barrier(dist)
+            watchdog.cancel()
+            t = mark('big_extras_s', t)
+    elif world > 1:
+        measure_big_extras(args, rank, world, dist, extra)
+        t = mark('big_extras_s', t)
     del ready
 
     cpu = None
