@@ -952,6 +952,7 @@ def measure_extras(ready, args, dist, extra, long_last=True):
                         warmup=2 if w.name in BIG else 5)
             extra[tag] = {k: r[k] for k in EXTRA_KEYS}
             extra[tag]['steps'] = steps
+            extra[tag]['flags'] = w.flags
             extra[tag]['dtype'] = w.dtype
             extra[tag]['times'] = getattr(w, 'times', 8)
             extra[tag]['frac_of_peak'] = r['achieved_GBps'] / HBM_PEAK_GBPS
@@ -1018,6 +1019,11 @@ def kernel_of(e):
     """The kernel a workload's launches ran (for the side file)."""
     sched = e.get('schedule') or {}
     family = KERNEL_OF_FAMILY.get(sched.get('family'), 'spmm_*')
+    if family == 'spmm_rowgroup' and e.get('mode') == 'masked' and \
+            (e.get('flags') or 0) & 16 and sched.get('rows_per_group') == 8 \
+            and e['K'] > 128:
+        family = 'spmm_groupmask (REMAP_FLAG_CELL_MASKS)'
+
     if sched.get('long_rows'):
         return family + ' + spmm_patchcell (long rows apart)'
     if e['layout'] == 'tn':
