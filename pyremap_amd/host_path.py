@@ -389,6 +389,10 @@ def remap_host_batch(plan, dst_grid_dims, arrays, remap_axes, *, mode,
             main.wait_event(event)
         except BaseException:
             _release_pinned(pinned)
+            try:           # (the feeder ends by itself: its list is finite)
+                feeder.join(timeout=10.0)
+            except NameError:
+                pass
             raise
     return PendingBatch(event, out_h, pinned)
 
