@@ -59,12 +59,19 @@ def main():
         for tag, p, tune in (('default', plan, None),
                              ('batch_at_a_time', forced, None),
                              ('lds_patches_4x8', old, [5]),
-                             ('row_groups', plan, [10, 0, 0, 1, 0])):
+                             ('row_groups', plan, [10, 0, 0, 1, 0]),
+                             ('rowlane', plan, [2]),
+                             ('rowcell', plan, [4]),
+                             ('rowscalar', plan, [6])):
             def run(i):
                 engine.remap_tensor(p, m.dst_dims, xs[i % 3], [1],
                                     engine.MODE_FRACB, tune=tune,
                                     out=ys[i % 3])
-            ms = timed(run)
+            try:
+                ms = timed(run)
+            except engine.EngineError as exc:
+                row[tag + '_error'] = str(exc)[:60]
+                continue
             if ref is None:
                 ref = ys[0].clone()
             else:
