@@ -345,8 +345,15 @@ typedef struct remap_apply_args {
      *         list)
      * tune[2] K tiles per wave (1, 2 or 4)
      * tune[3] consecutive rows per wave
-     * tune[4] block -> work map: 1 = as dispatched, 2 = XCD-contiguous
-     * tune[5] family 10: union entries in flight per wave (8; or 4, 16)
+     * tune[4] block -> work map: 1 = as dispatched, 2 = XCD-contiguous;
+     *         family 10 also 3 = XCD-contiguous with the K-chunks of a row
+     *         block side by side in the work list (the schedule of a group
+     *         is fetched once per XCD: what remap_schedule_auto picks for
+     *         entry-rich mappings)
+     * tune[5] family 10: union entries in flight per wave (8; or 4, 16);
+     *         26 / 28: the rolling form with 6 / 8 in flight (float64, even
+     *         strides; spmm_grouproll.h: measured, not chosen); 9: keep the
+     *         per-lane masked form under REMAP_FLAG_CELL_MASKS
      * tune[6..7] reserved, must be 0 (a -DREMAP_DIAG build of the library,
      *         tools/build_diag.py, reads bottleneck-analysis switches from
      *         them; this build rejects them) */

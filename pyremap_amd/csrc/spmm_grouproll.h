@@ -24,6 +24,14 @@
 // without refills (a conditional refill would bring the joins back).
 // The sums are those of spmm_rowgroup, entry by entry, member by member, in
 // ascending column order: same bits.
+//
+// MEASURED (round 5, profiles/r05_analysis/config5_forms.md), and NOT chosen
+// by any schedule: config 5 24.2-25.2 ms against 21.9-22.9 (+10 %), config 3
+// +2-5 %, headline -1 %, config 5 masked with one K tile -3 %.  The waits are
+// exact and the fabric reads fall (42 against 58 GB), but a CU's L1 already
+// has its miss queue full (72 requests in flight): loads queued behind a
+// wave's own earlier loads lengthen the queue, they do not fill it.  Kept
+// behind tune[5] = 26 / 28 (6 / 8 union entries in flight).
 // ---------------------------------------------------------------------------
 template <typename XT, int TILES, int MODE, bool FMA, int G, int UNR, int VEC>
 __global__ __launch_bounds__(kBlock) void spmm_grouproll(
