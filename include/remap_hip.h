@@ -644,6 +644,22 @@ int remap_plan_apply(const remap_plan *plan, const remap_field *field,
                      void *stream);
 
 /*
+ * `_remap_data_array` in one call (remap_numpy.py:201-204 + :223-297): scan
+ * the field for NaNs on the device and enqueue the masked, renormalised
+ * branch (threshold = field->threshold) and the frac_b branch, each gated on
+ * what the scan finds -- nothing synchronises, nothing is allocated, the
+ * sequence is hipGraph-capturable.  `field->X` must be ONE contiguous buffer
+ * of `x_elems` elements (what is scanned); `field->mode` and `field->gate` are
+ * ignored; `kinds` is a device int32[2] the call zeroes and fills (see
+ * remap_scan_nan_kinds).  On a mapping scheduled as 8-row groups the masked
+ * branch is enqueued in both of its forms (REMAP_FLAG_CELL_MASKS): three
+ * gated launches instead of two.
+ */
+REMAP_API
+int remap_plan_apply_auto(const remap_plan *plan, const remap_field *field,
+                          int64_t x_elems, int32_t *kinds, void *stream);
+
+/*
  * OR 1 into *flag (device int32, zeroed by the caller) if any of the n
  * elements of x (device, REMAP_DTYPE_*, element-aligned) is a NaN.
  * Asynchronous on `stream`; the device half of remap_numpy.py:201-204.

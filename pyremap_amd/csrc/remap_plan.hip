@@ -1135,4 +1135,44 @@ int remap_plan_apply(const remap_plan *plan, const remap_field *f,
     return remap_apply_f64(&b, stream);
 }
 
+int remap_plan_apply_auto(const remap_plan *plan, const remap_field *f,
+                          int64_t x_elems, int32_t *kinds, void *stream)
+{
+    if (!plan || !f || !kinds || x_elems < 0)
+        return remap::fail(REMAP_ERR_ARG,
+                           "remap_plan_apply_auto: bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    REMAP_HIP_CHECK(hipMemsetAsync(kinds, 0, 2 * sizeof(int32_t), s));
+    int rc = remap_scan_nan_kinds(f->X, f->x_dtype, x_elems, kinds, stream);
+    if (rc != REMAP_OK)
+        return rc;
+    remap_field g = *f;
+    // the masked branch (remap_numpy.py:262-266) ...
+    g.mode = REMAP_MODE_MASKED;
+    const bool two_forms =
+        plan->sched.family == 10 && plan->sched.group_rows == 8;
+    if (two_forms) {
+        // ... per-row normalisers where the NaNs fill whole cells, per-lane
+        // ones where they do not
+        g.gate = kinds + 1;
+        g.gate_value = 1;
+        g.flags = f->flags | REMAP_FLAG_CELL_MASKS;
+        if ((rc = remap_plan_apply(plan, &g, stream)) != REMAP_OK)
+            return rc;
+        g.gate_value = 3;
+        g.flags = f->flags & ~static_cast<uint32_t>(REMAP_FLAG_CELL_MASKS);
+    } else {
+        g.gate = kinds;
+        g.gate_value = 1;
+    }
+    if ((rc = remap_plan_apply(plan, &g, stream)) != REMAP_OK)
+        return rc;
+    // ... and the frac_b branch (:268-274) when the field holds no NaN
+    g.mode = REMAP_MODE_FRACB;
+    g.gate = kinds;
+    g.gate_value = 0;
+    g.flags = f->flags & ~static_cast<uint32_t>(REMAP_FLAG_CELL_MASKS);
+    return remap_plan_apply(plan, &g, stream);
+}
+
 }  // extern "C"

@@ -70,7 +70,8 @@ EXPORTS = (
     'remap_patches_workspace', 'remap_patches_build',
     'remap_schedule_sizes', 'remap_schedule_auto',
     'remap_plan_create', 'remap_plan_destroy', 'remap_plan_query',
-    'remap_plan_apply', 'remap_pack_columns_workspace', 'remap_pack_columns',
+    'remap_plan_apply', 'remap_plan_apply_auto',
+    'remap_pack_columns_workspace', 'remap_pack_columns',
     'remap_gather_rows', 'remap_plan_prepare_short_runs',
     'remap_clock_probe',
 )
@@ -323,6 +324,10 @@ def load_library():
     lib.remap_plan_apply.restype = ctypes.c_int
     lib.remap_plan_apply.argtypes = [ctypes.c_void_p,
                                      ctypes.POINTER(_Field), ctypes.c_void_p]
+    lib.remap_plan_apply_auto.restype = ctypes.c_int
+    lib.remap_plan_apply_auto.argtypes = [
+        ctypes.c_void_p, ctypes.POINTER(_Field), ctypes.c_int64,
+        ctypes.c_void_p, ctypes.c_void_p]
     lib.remap_pack_columns_workspace.restype = ctypes.c_int
     lib.remap_pack_columns_workspace.argtypes = [
         ctypes.c_int64, ctypes.POINTER(ctypes.c_size_t)]

@@ -288,3 +288,63 @@ def test_dataset_small_variables_are_batched_bitwise(dev, monkeypatch):
                 s for a, s in enumerate(x.shape) if a != axis)), 0, axis)
             want = want.reshape(got.values.shape)
             assert_bitwise(got.values, want, f'{name} thr={thr} vs oracle')
+
+
+@pytest.mark.parametrize('rich', [True, False])
+def test_plan_handle_apply_auto(dev, rich):
+    """`remap_plan_apply_auto`: `_remap_data_array`'s NaN branch and
+    `_remap_numpy_array` in ONE C call (scan + gated launches; three of them
+    on an entry-rich mapping) -- the reference's result for every kind of
+    field (remap_numpy.py:201-204, 258-278)."""
+    import ctypes
+    from oracle import oracle
+    from pyremap_amd import engine, synthetic
+    m = synthetic.conservative_map(1500, (38, 60), *((6, 22) if rich
+                                                     else (1, 6)),
+                                   seed=5, signed=rich, locality='mesh')
+    mm = m.numpy()
+    csr = oracle.coo_to_csr(mm['row'] - 1, mm['col'] - 1, mm['S'], m.n_b,
+                            m.n_a)
+    lib = engine.load_library()
+    handle = ctypes.c_void_p()
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    dims = (ctypes.c_int64 * 2)(*m.dst_dims)
+
+    def host(a, t):
+        return np.ascontiguousarray(a, dtype=t).ctypes.data
+
+    assert lib.remap_plan_create(
+        m.n_b, m.n_a, len(mm['S']), host(mm['row'], np.int32),
+        host(mm['col'], np.int32), host(mm['S'], np.float64), 1,
+        host(mm['frac_b'], np.float64), 1, dims, 2, stream,
+        ctypes.byref(handle)) == 0, lib.remap_last_error()
+    try:
+        info = engine._PlanInfo()
+        assert lib.remap_plan_query(handle, ctypes.byref(info)) == 0
+        assert (info.group_rows == 8) == rich
+        K = 384
+        kinds = torch.full((2,), 7, dtype=torch.int32, device=dev)
+        for tag, x in _fields(m.n_a, K, 11):
+            xd = torch.from_numpy(x).to(dev)
+            y = torch.full((m.n_b, K), 5.0, dtype=torch.float64, device=dev)
+            f = engine._Field()
+            f.X, f.Y = xd.data_ptr(), y.data_ptr()
+            f.x_dtype, f.mode = engine.DTYPE_F64, 99      # (mode is ignored)
+            f.n_batch, f.k_inner = 1, K
+            f.x_row_stride, f.x_batch_stride = K, 0
+            f.y_row_stride, f.y_batch_stride = K, 0
+            f.threshold = 0.3
+            assert lib.remap_plan_apply_auto(
+                handle, ctypes.byref(f), xd.numel(), kinds.data_ptr(),
+                stream) == 0, lib.remap_last_error()
+            torch.cuda.synchronize()
+            masked = bool(np.isnan(x).any())
+            ref, ref_mask = oracle.remap_flat(csr, mm['frac_b'], x, masked,
+                                              0.3)
+            ref = ref.copy()
+            ref[ref_mask] = np.nan
+            assert_bitwise(y.cpu().numpy(), ref, f'{tag} rich={rich}')
+            want = {'no NaN': (0, 0), 'whole cells': (1, 1)}.get(tag, (1, 3))
+            assert tuple(kinds.tolist()) == want, (tag, kinds.tolist())
+    finally:
+        lib.remap_plan_destroy(handle)
