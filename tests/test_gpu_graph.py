@@ -180,5 +180,29 @@ def test_plan_handle_launches_are_capturable(dev):
             csr, mm['frac_b'], (40, 60), h, [1], None), np.nan)
         assert_bitwise(y.cpu().numpy().reshape(30, 40, 60), want,
                        'plan handle replayed')
+        # `remap_plan_apply_auto` (memset of the flags, the scan, the gated
+        # launches) is capturable too: one capture, replayed on a field
+        # without NaNs and on one with (the branch is taken on the device)
+        kinds = torch.zeros(2, dtype=torch.int32, device=dev)
+        f.threshold = 0.2
+        graph2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph2):
+            s = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            assert lib.remap_plan_apply_auto(
+                handle, ctypes.byref(f), x.numel(), kinds.data_ptr(),
+                s) == 0, lib.remap_last_error()
+        for with_nan in (False, True, False):
+            h = np.random.default_rng(3).standard_normal((30, m.n_a))
+            if with_nan:
+                h[:, ::7] = np.nan
+            x.copy_(torch.from_numpy(h))
+            graph2.replay()
+            torch.cuda.synchronize()
+            arg = np.ma.masked_array(h, np.isnan(h)) if with_nan else h
+            want = np.ma.filled(oracle.remap_numpy_array(
+                csr, mm['frac_b'], (40, 60), arg, [1], 0.2), np.nan)
+            assert_bitwise(y.cpu().numpy().reshape(30, 40, 60), want,
+                           f'apply_auto replayed, NaNs: {with_nan}')
+            assert int(kinds[0]) == int(with_nan)
     finally:
         lib.remap_plan_destroy(handle)
