@@ -551,12 +551,6 @@ int launch_rowgroup(const remap_apply_args *a, const KParams &p, int tiles,
                                                                fma)
                           : pick_rowgroup_tiles<double, 16, 8>(tiles, a->mode,
                                                                fma);
-        // REMAP_FLAG_CELL_MASKS, masked mode on 8-row groups: per-row
-        // normalisers while the validity of a source cell is the same in
-        // all of a wave's columns (spmm_groupmask.h), two K tiles per wave
-        if (cell_masks)
-            fn = fma ? spmm_groupmask<double, 2, true, 8, 8, 2>
-                     : spmm_groupmask<double, 2, false, 8, 8, 2>;
         if (roll && vec == 2)
             fn = a->group_rows == 16
                      ? pick_grouproll<16>(roll, tiles, a->mode, fma)
@@ -564,6 +558,13 @@ int launch_rowgroup(const remap_apply_args *a, const KParams &p, int tiles,
                      ? pick_grouproll<8>(roll, tiles, a->mode, fma)
                      : pick_grouproll<4>(roll, tiles, a->mode, fma);
     }
+    // REMAP_FLAG_CELL_MASKS, masked mode on 8-row groups: per-row
+    // normalisers while the validity of a source cell is the same in all of
+    // a wave's columns (spmm_groupmask.h), two K tiles per wave; float32
+    // fields too (their per-lane form holds 170 VGPRs: 2 waves per SIMD)
+    if (cell_masks && !roll)
+        fn = fma ? spmm_groupmask<XT, 2, true, 8, 8, 2>
+                 : spmm_groupmask<XT, 2, false, 8, 8, 2>;
 #ifdef REMAP_DIAG
     if constexpr (std::is_same<XT, double>::value) {
         if (lock)
@@ -962,8 +963,7 @@ int run_rowgroup(const remap_apply_args *a, const Call &c, KParams p,
     // (spmm_groupmask.h) with two K tiles per wave, whatever tune[2] says
     const bool cell_masks =
         (a->flags & REMAP_FLAG_CELL_MASKS) && a->mode == REMAP_MODE_MASKED &&
-        a->group_rows == 8 && !c.f32 && c.can_vec2 && c.K > 128 &&
-        a->tune[5] == 0;
+        a->group_rows == 8 && c.can_vec2 && c.K > 128 && a->tune[5] == 0;
     if (cell_masks)
         tiles = 2;
     if (tiles != 2 || c.K <= 128)
@@ -1029,7 +1029,8 @@ int run_rowgroup(const remap_apply_args *a, const Call &c, KParams p,
     // tune[5] = 26 / 28: the rolling form, 6 / 8 union entries in flight
     const int roll = a->tune[5] == 26 ? 6 : a->tune[5] == 28 ? 8 : 0;
     return c.f32 ? launch_rowgroup<float>(a, p, tiles, unr, vec, wpb, c.fma,
-                                          grid, stream)
+                                          grid, stream, false, 0,
+                                          cell_masks && vec == 2)
                  : launch_rowgroup<double>(a, p, tiles, unr, vec, wpb, c.fma,
                                            grid, stream, lock, roll,
                                            cell_masks && vec == 2);

@@ -52,9 +52,10 @@ def _check(plan, csr, frac_b, x, dev, mode, thr, tune, what, flags=0):
     y, mask = engine.remap_tensor(plan, None, xd, [0], mode, threshold=thr,
                                   tune=tune, want_mask=True, flags=flags)
     if mode == engine.MODE_RAW:
-        assert_bitwise(y.cpu().numpy(), oracle.csr_matvecs(csr, x), what)
+        assert_bitwise(y.cpu().numpy(),
+                       oracle.csr_matvecs(csr, x.astype(np.float64)), what)
         return
-    ref, ref_mask = oracle.remap_flat(csr, frac_b, x,
+    ref, ref_mask = oracle.remap_flat(csr, frac_b, x.astype(np.float64),
                                       mode == engine.MODE_MASKED, thr)
     ref = ref.copy()
     ref[ref_mask] = np.nan
@@ -84,13 +85,16 @@ def _fields(n_a, K, seed):
     return out
 
 
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
 @pytest.mark.parametrize('K', [130, 256, 300, 1024])
-def test_masked_groups_per_row_normaliser(dev, K):
+def test_masked_groups_per_row_normaliser(dev, K, dtype):
     """REMAP_FLAG_CELL_MASKS on 8-row groups -> spmm_groupmask, whatever is
-    missing; the same bits as without the flag."""
+    missing; the same bits as without the flag; float32 fields too (read as
+    float32, summed in float64: scipy's upcast)."""
     from pyremap_amd import engine
     m, mm, plan, csr = _problem(dev, 8)
     for tag, x in _fields(m.n_a, K, K):
+        x = x.astype(dtype)
         for tune in ([10, 1, 2, 1], [10, 4, 2, 2, 3], [10, 1, 1, 1],
                      [10, 1, 2, 1, 0, 9], None):
             for flags in (engine.FLAG_CELL_MASKS, 0,
