@@ -290,32 +290,36 @@ cell_fn pick_patchtime_tt(int tt, int mode, bool fma)
                      : pick_patchtime_mode<XT, 8, BLOCK>(mode, fma);
 }
 
-// (Time, nCells, 4 ... 15): a batch at a time, 4 columns per chunk
-template <typename XT, int BLOCK>
+// (Time, nCells, 4 ... 15): a batch at a time, 4 or 8 columns per chunk
+template <typename XT, int BLOCK, int TT>
 cell_fn pick_patchruns_mode(int mode, bool fma)
 {
     switch (mode) {
     case REMAP_MODE_RAW:
-        return fma ? spmm_patchtime<XT, REMAP_MODE_RAW, true, 4, BLOCK, true>
-                   : spmm_patchtime<XT, REMAP_MODE_RAW, false, 4, BLOCK, true>;
+        return fma ? spmm_patchtime<XT, REMAP_MODE_RAW, true, TT, BLOCK, true>
+                   : spmm_patchtime<XT, REMAP_MODE_RAW, false, TT, BLOCK,
+                                    true>;
     case REMAP_MODE_FRACB:
-        return fma
-                   ? spmm_patchtime<XT, REMAP_MODE_FRACB, true, 4, BLOCK, true>
-                   : spmm_patchtime<XT, REMAP_MODE_FRACB, false, 4, BLOCK,
+        return fma ? spmm_patchtime<XT, REMAP_MODE_FRACB, true, TT, BLOCK,
+                                    true>
+                   : spmm_patchtime<XT, REMAP_MODE_FRACB, false, TT, BLOCK,
                                     true>;
     default:
-        return fma ? spmm_patchtime<XT, REMAP_MODE_MASKED, true, 4, BLOCK,
+        return fma ? spmm_patchtime<XT, REMAP_MODE_MASKED, true, TT, BLOCK,
                                     true>
-                   : spmm_patchtime<XT, REMAP_MODE_MASKED, false, 4, BLOCK,
+                   : spmm_patchtime<XT, REMAP_MODE_MASKED, false, TT, BLOCK,
                                     true>;
     }
 }
 
+// (8 columns per chunk -- one chunk per batch at L = 8 -- was built and
+// measured in round 5: slower at every L, 0.63 against 0.59 ms at L = 8, 0.83
+// against 0.68 at L = 10: twice the LDS image, half the workgroups per CU)
 template <typename XT>
 cell_fn pick_patchruns(int mode, bool fma, int block)
 {
-    return block == 256 ? pick_patchruns_mode<XT, 256>(mode, fma)
-                        : pick_patchruns_mode<XT, 512>(mode, fma);
+    return block == 256 ? pick_patchruns_mode<XT, 256, 4>(mode, fma)
+                        : pick_patchruns_mode<XT, 512, 4>(mode, fma);
 }
 
 template <typename XT>
@@ -754,6 +758,7 @@ KParams base_params(const remap_apply_args *a, const Call &c)
     p.n_rowblocks = p.n_blocks = p.blocks_per_xcd = 0;
     p.rows_per_wave = 0;
     p.xcd_map = 0;
+    p.x_pairs = 0;
     return p;
 }
 
@@ -1229,6 +1234,14 @@ int run_patchcell(const remap_apply_args *a, const Call &c, KParams p,
         cpw = ceil_div(ceil_div(n_chunks, groups), sub) * sub;
         groups = ceil_div(n_chunks, cpw);
         p.rows_per_wave = static_cast<int32_t>(cpw);
+    }
+    // short level runs of even length on even strides from a 16-byte (f32:
+    // 8-byte) aligned base: two elements per load (tune[5] = 1: one)
+    {
+        const size_t pair = (c.f32 ? sizeof(float) : sizeof(double)) * 2;
+        p.x_pairs = runs && ki % 2 == 0 && a->x_row_stride % 2 == 0 &&
+                    a->x_batch_stride % 2 == 0 && a->x_src_fold == 0 &&
+                    aligned(a->X, pair) && a->tune[5] != 1;
     }
     int64_t grid;
     const int rc = shape_grid(p, a->n_patches,

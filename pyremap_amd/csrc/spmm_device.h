@@ -32,6 +32,10 @@ struct KParams {
     int64_t src_outer;     // two non-adjacent source axes (src_fold != 0):
     uint32_t src_fold;     // cell a lives at (a / fold) * src_outer +
                            // (a % fold) * ldx; else at a * ldx
+    uint32_t x_pairs;      // family 7, short level runs: a cell's run is
+                           // 16-byte aligned pairs of elements (even run
+                           // length and strides, aligned base): two
+                           // elements per load
     const int32_t *__restrict__ gate;  // optional device-side switch: the
     int32_t gate_value;                // launch is a no-op unless *gate ==
                                        // gate_value (remap_apply_args.gate)

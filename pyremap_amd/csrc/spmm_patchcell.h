@@ -290,6 +290,30 @@ __global__ __launch_bounds__(BLOCK) void spmm_patchtime(
     auto load = [&](uint32_t c) {
         uint32_t cbatch, k0;
         place(c, cbatch, k0);
+        if constexpr (RUNS && TT % 2 == 0) {
+            // a cell's run in aligned PAIRS (the host checked: even run
+            // length and strides, 16-byte aligned base -- a run of 4 is two
+            // 16-byte loads instead of four 8-byte ones: half the
+            // instructions the texture addresser works through, the lines
+            // touched twice instead of four times)
+            if (p.x_pairs) {
+                typedef XT pair_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int t = 0; t < TT; t += 2) {
+                    const uint32_t k = k0 + t < ki ? k0 + t : 0u;
+                    const int64_t xo =
+                        static_cast<int64_t>(cbatch) * p.bsx + k;
+#pragma unroll
+                    for (int q = 0; q < NC; ++q) {
+                        const pair_t pr = *reinterpret_cast<const pair_t *>(
+                            X + cb[q] + xo);
+                        v[q][t] = pr[0];
+                        v[q][t + 1] = pr[1];
+                    }
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
             int64_t xo;

@@ -59,6 +59,7 @@ CELL_LDS_MAX = 160 * 1024
 _LONG_TT = None   # (experiments: fields per lane of the long-row launch)
 _LONG_WAVE_TT = None   # (tests: columns per wave of family 9, 0 = auto)
 _CELL_TUNE = None      # (tools/tn_probe.py: [TT, one-chunk kernel?] of family 7)
+_RUNS_TUNE = None      # (tools/runs_probe.py: the batch-at-a-time launch's tune)
 
 #: every symbol ``include/remap_hip.h`` declares
 EXPORTS = (
@@ -1509,7 +1510,7 @@ def apply_strided(plan, X, Y, *, n_batch, k_inner, x_row_stride,
         tune = [5]
         flags |= FLAG_TUNE_HINT
     elif cell == 'run_cells':
-        tune = [7, 4, 2]
+        tune = list(_RUNS_TUNE) if _RUNS_TUNE else [7, 4, 2]
         flags |= FLAG_TUNE_HINT
     elif cell:
         # 4 fields per lane and LDS image: the workgroup stays on its patch

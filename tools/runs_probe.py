@@ -57,12 +57,20 @@ def main():
         row = dict(L=L, T=T)
         ref = None
         for tag, p, tune in (('default', plan, None),
+                             ('batch_single_loads', forced, 'single'),
                              ('batch_at_a_time', forced, None),
                              ('lds_patches_4x8', old, [5]),
                              ('row_groups', plan, [10, 0, 0, 1, 0]),
                              ('rowlane', plan, [2]),
                              ('rowcell', plan, [4]),
                              ('rowscalar', plan, [6])):
+            # ('single': the batch-at-a-time kernel with one element per
+            # load -- round 4's form -- instead of aligned pairs)
+            engine._RUNS_TUNE = [7, 4, 2, 0, 0, 1] if tune == 'single' \
+                else None
+            if tune == 'single':
+                tune = None
+
             def run(i):
                 engine.remap_tensor(p, m.dst_dims, xs[i % 3], [1],
                                     engine.MODE_FRACB, tune=tune,
