@@ -1032,7 +1032,9 @@ int remap_plan_apply(const remap_plan *plan, const remap_field *f,
         a.n_patches = q.n;
         if (f->k_inner <= 6) {
             a.tune[0] = 7;
-            a.tune[1] = 4;
+            // 4 columns per chunk; 5 or 6 levels: 6 -- the batch is ONE
+            // chunk ((80, n, 6) 0.57 -> 0.47 ms; engine.apply_strided)
+            a.tune[1] = f->k_inner >= 5 ? 6 : 4;
             a.tune[2] = 2;
         } else {
             a.tune[0] = 5;

@@ -315,11 +315,22 @@ cell_fn pick_patchruns_mode(int mode, bool fma)
 // (8 columns per chunk -- one chunk per batch at L = 8 -- was built and
 // measured in round 5: slower at every L, 0.63 against 0.59 ms at L = 8, 0.83
 // against 0.68 at L = 10: twice the LDS image, half the workgroups per CU)
-template <typename XT>
-cell_fn pick_patchruns(int mode, bool fma, int block)
+template <typename XT, int TT>
+cell_fn pick_patchruns_block(int mode, bool fma, int block)
 {
-    return block == 256 ? pick_patchruns_mode<XT, 256, 4>(mode, fma)
-                        : pick_patchruns_mode<XT, 512, 4>(mode, fma);
+    return block == 256 ? pick_patchruns_mode<XT, 256, TT>(mode, fma)
+                        : pick_patchruns_mode<XT, 512, TT>(mode, fma);
+}
+
+template <typename XT>
+cell_fn pick_patchruns(int mode, bool fma, int block, int tt)
+{
+    // (8 / 10 / 12 columns per chunk -- the whole batch of 8 ... 12 levels
+    // one chunk, one LDS image -- were built and measured in round 5: no
+    // better than 4 per chunk and behind the 4 x 8 LDS patches at every such
+    // L; removed)
+    return tt == 6 ? pick_patchruns_block<XT, 6>(mode, fma, block)
+                   : pick_patchruns_block<XT, 4>(mode, fma, block);
 }
 
 template <typename XT>
@@ -759,6 +770,7 @@ KParams base_params(const remap_apply_args *a, const Call &c)
     p.rows_per_wave = 0;
     p.xcd_map = 0;
     p.x_pairs = 0;
+    p.y_pairs = 0;
     return p;
 }
 
@@ -1202,8 +1214,20 @@ int run_patchcell(const remap_apply_args *a, const Call &c, KParams p,
                     "remap_apply_f64: tune[2] = 2 (short runs, a batch at a "
                     "time) needs 4 <= k_inner < 16, several batches and a "
                     "patch plan of at most 512 rows / 1 022 cells per patch");
-    if (runs)
+    // columns per chunk of the batch-at-a-time kernel: 4, or tune[1] = 6
+    // where the LDS image(s) still fit (a batch that is ONE chunk needs one
+    // image, else two)
+    if (runs) {
+        const int want = a->tune[1];
         tt = 4;
+        if (want == 6) {
+            const int64_t images = ki <= want ? 1 : 2;
+            if ((int64_t)upitch * want * 8 * images + out_bytes <=
+                (int64_t)kPatchLdsMax)
+                tt = want;
+        }
+    }
+    const bool one_image = runs && ki <= tt;
     const int64_t sub = runs ? ceil_div(ki, tt) : 1;
     const int64_t n_chunks = runs ? a->n_batch * sub : ceil_div(c.K, tt);
     int64_t groups = 1, cpw = 1;
@@ -1215,7 +1239,8 @@ int run_patchcell(const remap_apply_args *a, const Call &c, KParams p,
         // 4 runs 0.121 / 0.149 ms; 16 x 16 patches (1 013 of 256 threads, 8
         // per CU) 1 / 2 / 4 runs 0.146 / 0.141 / 0.144.
         const int64_t lds_wg =
-            (int64_t)upitch * tt * 16 + (runs ? out_bytes : 0);
+            (int64_t)upitch * tt * (one_image ? 8 : 16) +
+            (runs ? out_bytes : 0);
         int64_t fit = 2048 / block;
         if (fit > (int64_t)kPatchLdsMax / lds_wg)
             fit = (int64_t)kPatchLdsMax / lds_wg;
@@ -1242,6 +1267,9 @@ int run_patchcell(const remap_apply_args *a, const Call &c, KParams p,
         p.x_pairs = runs && ki % 2 == 0 && a->x_row_stride % 2 == 0 &&
                     a->x_batch_stride % 2 == 0 && a->x_src_fold == 0 &&
                     aligned(a->X, pair) && a->tune[5] != 1;
+        p.y_pairs = runs && ki % 2 == 0 && a->y_row_stride % 2 == 0 &&
+                    a->y_batch_stride % 2 == 0 && aligned(a->Y, 16) &&
+                    a->tune[5] != 1;
     }
     int64_t grid;
     const int rc = shape_grid(p, a->n_patches,
@@ -1250,15 +1278,16 @@ int run_patchcell(const remap_apply_args *a, const Call &c, KParams p,
     if (rc != REMAP_OK)
         return rc;
     uint32_t lds_bytes =
-        static_cast<uint32_t>(upitch) * tt * 8u * (persistent ? 2u : 1u) +
+        static_cast<uint32_t>(upitch) * tt * 8u *
+            (persistent && !one_image ? 2u : 1u) +
         (runs ? static_cast<uint32_t>(out_bytes) : 0u);
     if (lds_bytes < 1024)
         lds_bytes = 1024;
     const int layout = a->patch_ell_base ? 1 : 0;
     const int launch_block = persistent ? block : kCellBlock;
     cell_fn fn =
-        runs ? (c.f32 ? pick_patchruns<float>(a->mode, c.fma, block)
-                      : pick_patchruns<double>(a->mode, c.fma, block))
+        runs ? (c.f32 ? pick_patchruns<float>(a->mode, c.fma, block, tt)
+                      : pick_patchruns<double>(a->mode, c.fma, block, tt))
         : persistent
             ? (c.f32 ? pick_patchtime<float>(tt, a->mode, c.fma, block)
                      : pick_patchtime<double>(tt, a->mode, c.fma, block))

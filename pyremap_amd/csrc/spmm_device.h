@@ -36,6 +36,7 @@ struct KParams {
                            // 16-byte aligned pairs of elements (even run
                            // length and strides, aligned base): two
                            // elements per load
+    uint32_t y_pairs;      // ... and the results leave two per store
     const int32_t *__restrict__ gate;  // optional device-side switch: the
     int32_t gate_value;                // launch is a no-op unless *gate ==
                                        // gate_value (remap_apply_args.gate)

@@ -232,8 +232,13 @@ __global__ __launch_bounds__(BLOCK) void spmm_patchtime(
     const uint32_t c0 = static_cast<uint32_t>(group) * cpw;
     const uint32_t c1 = c0 + cpw < n_chunks ? c0 + cpw : n_chunks;
     const XT *__restrict__ X = static_cast<const XT *>(p.X);
+    // RUNS with the whole batch in one chunk: ONE LDS image -- the barrier
+    // in front of the batch's stores already separates a chunk's sums from
+    // the next chunk's image (two images are for chunks that follow one
+    // another without it) -- half the LDS, more workgroups per CU
+    const bool one_image = RUNS && sub == 1;
     // RUNS: the batch's results [row][k], their mask bytes, the rows' ids
-    double *out = xs + 2 * TT * upitch;
+    double *out = xs + (one_image ? 1 : 2) * TT * upitch;
     int32_t *rid_lds = reinterpret_cast<int32_t *>(out + patch_rows * ki);
     uint8_t *okb = reinterpret_cast<uint8_t *>(rid_lds + patch_rows);
 
@@ -335,7 +340,7 @@ __global__ __launch_bounds__(BLOCK) void spmm_patchtime(
     if (c0 < c1)
         load(c0);
     for (uint32_t c = c0; c < c1; ++c) {
-        double *img = xs + ((c - c0) & 1) * (TT * upitch);
+        double *img = one_image ? xs : xs + ((c - c0) & 1) * (TT * upitch);
 #pragma unroll
         for (int q = 0; q < NC; ++q) {
             const int j = tid + q * BLOCK;
@@ -419,6 +424,26 @@ __global__ __launch_bounds__(BLOCK) void spmm_patchtime(
                 lds_barrier();
                 const int total = nrows * static_cast<int>(ki);
                 const int64_t ob = static_cast<int64_t>(cbatch) * p.bsy;
+                if (p.y_pairs) {
+                    // (even run length and strides, 16-byte aligned Y: two
+                    // results per store, half the store instructions)
+                    typedef double d2 __attribute__((ext_vector_type(2)));
+                    for (int q = 2 * tid; q < total; q += 2 * BLOCK) {
+                        const int r = q / static_cast<int>(ki);
+                        const int k = q - r * static_cast<int>(ki);
+                        const int64_t o =
+                            static_cast<int64_t>(rid_lds[r]) * p.ldy + ob + k;
+                        const d2 pr = *reinterpret_cast<const d2 *>(out + q);
+                        __builtin_nontemporal_store(
+                            pr, reinterpret_cast<d2 *>(p.Y + o));
+#ifndef REMAP_STAMPS   // (there mask_out is the stamps buffer)
+                        if (p.mask_out) {
+                            p.mask_out[o] = okb[q];
+                            p.mask_out[o + 1] = okb[q + 1];
+                        }
+#endif
+                    }
+                } else
                 for (int q = tid; q < total; q += BLOCK) {
                     const int r = q / static_cast<int>(ki);
                     const int k = q - r * static_cast<int>(ki);

@@ -1510,7 +1510,11 @@ def apply_strided(plan, X, Y, *, n_batch, k_inner, x_row_stride,
         tune = [5]
         flags |= FLAG_TUNE_HINT
     elif cell == 'run_cells':
-        tune = list(_RUNS_TUNE) if _RUNS_TUNE else [7, 4, 2]
+        # 4 columns per chunk of the batch-at-a-time kernel; with 5 or 6
+        # levels 6: the batch is ONE chunk (config 3's map, (80, n, 6):
+        # 0.57 -> 0.47 ms, (96, n, 5): 0.70 -> 0.67)
+        tune = list(_RUNS_TUNE) if _RUNS_TUNE else \
+            [7, 6 if k_inner >= 5 else 4, 2]
         flags |= FLAG_TUNE_HINT
     elif cell:
         # 4 fields per lane and LDS image: the workgroup stays on its patch
