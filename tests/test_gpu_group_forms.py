@@ -292,6 +292,15 @@ def test_dataset_small_variables_are_batched_bitwise(dev, monkeypatch):
                 s for a, s in enumerate(x.shape) if a != axis)), 0, axis)
             want = want.reshape(got.values.shape)
             assert_bitwise(got.values, want, f'{name} thr={thr} vs oracle')
+    # call after call (side streams, the feeder thread, the pinned result
+    # buffers are shared between calls): the same bits every time, also with
+    # earlier results still alive
+    keep = [r.remap_numpy(ds, 0.05) for _ in range(4)]
+    for other in keep[1:]:
+        for name in ds.data_vars:
+            assert_bitwise(np.asarray(other[name].values, dtype=np.float64),
+                           np.asarray(keep[0][name].values,
+                                      dtype=np.float64), f'repeat {name}')
 
 
 @pytest.mark.parametrize('rich', [True, False])
