@@ -981,3 +981,126 @@ def test_bench_line_drops_rows_rather_than_overflow():
     assert line['roofline']['workloads_truncated'] is True
     assert 'headline' in line['roofline']['workloads']
     assert len(details['workloads']) > 200
+
+
+# ---------------------------------------------------------------------------
+# round 5: the DPP hazard scanner, the stamped traffic files, the batches of a
+# Dataset's small variables (host logic, no GPU)
+# ---------------------------------------------------------------------------
+def test_dpp_hazard_scanner_sees_a_valu_writer_in_the_window():
+    """tools/dpp_hazard_scan.py: a VALU write of a DPP source less than two
+    wait states before the DPP read is reported; `s_nop 1` (or two other
+    instructions) in between clears it; a write of another register does
+    not count; a `v_cmpx` within five wait states does."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        'dpp_hazard_scan', os.path.join(REPO, 'tools', 'dpp_hazard_scan.py'))
+    scan = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(scan)
+    dpp = 'v_mov_b64_dpp v[6:7], v[2:3] row_newbcast:3 row_mask:0xf ' \
+          'bank_mask:0xf'
+    add = 'v_add_u32_dpp v9, v8, v70 row_newbcast:0 row_mask:0xf bank_mask:0xf'
+    sites, bad = scan.scan(['v_add_f64 v[2:3], v[2:3], v[4:5]', dpp])
+    assert sites == 1 and len(bad) == 1
+    assert scan.scan(['v_add_f64 v[2:3], v[2:3], v[4:5]', 's_nop 1',
+                      dpp]) == (1, [])
+    assert scan.scan(['v_add_f64 v[2:3], v[2:3], v[4:5]', 's_mov_b32 s0, 1',
+                      's_mov_b32 s1, 2', dpp]) == (1, [])
+    assert scan.scan(['v_add_f64 v[10:11], v[2:3], v[4:5]', dpp]) == (1, [])
+    assert len(scan.scan(['v_cndmask_b32_e32 v8, v8, v69, vcc',
+                          '; a comment', add])[1]) == 1
+    assert len(scan.scan(['v_cmpx_gt_u32_e32 8, v0', 's_nop 1', add])[1]) == 1
+    assert scan.scan(['.LBB0_1:', 'v_readlane_b32 s4, v8, 3', 's_nop 0',
+                      's_nop 0', add])[1] == []
+
+
+def test_traffic_files_are_refused_unless_stamped_for_this_library(tmp_path,
+                                                                   monkeypatch):
+    """bench.load_traffic: the committed PMC traffic is a constant of the
+    library it was measured on -- another ABI version or another kernel
+    family and `roofline.traffic` is null, not a stale number."""
+    import sys
+    sys.path.insert(0, REPO)
+    import bench
+    from pyremap_amd import engine
+    prof = tmp_path / 'profiles'
+    prof.mkdir()
+    rec = dict(workload='config3', K=512, mode='fracb',
+               hbm_bytes_per_launch=2.19e9, source='test',
+               kernel='remap::spmm_rowgroup<double, 1, 1, false, 4, 8, 2, '
+                      'false, 256>', abi_version=engine.ABI_VERSION)
+    path = prof / 'traffic_config3_mesh.json'
+    monkeypatch.setattr(bench, '_REPO', str(tmp_path))
+    path.write_text(json.dumps(rec))
+    assert bench.load_traffic('config3', 512, 'fracb', 'mesh',
+                              'rowgroup') == (2.19e9, 'test')
+    assert bench.load_traffic('config3', 512, 'fracb', 'mesh',
+                              'patch') == (None, None)
+    assert bench.load_traffic('config3', 256, 'fracb', 'mesh',
+                              'rowgroup') == (None, None)
+    path.write_text(json.dumps(dict(rec, abi_version=engine.ABI_VERSION - 1)))
+    assert bench.load_traffic('config3', 512, 'fracb', 'mesh',
+                              'rowgroup') == (None, None)
+    rec.pop('abi_version')
+    path.write_text(json.dumps(rec))
+    assert bench.load_traffic('config3', 512, 'fracb', 'mesh',
+                              'rowgroup') == (None, None)
+    # the committed files of this round are stamped for this library
+    real = json.load(open(os.path.join(REPO, 'profiles',
+                                       'traffic_config3_mesh.json')))
+    assert real['abi_version'] == engine.ABI_VERSION
+    assert 'spmm_rowgroup' in real['kernel']
+
+
+def test_a_datasets_small_variables_are_grouped_by_shape_and_dtype():
+    """remap_numpy._batches (reference: the per-variable loop of
+    remap_numpy.py:42-55): variables with the same dims, shape and upload
+    dtype travel together; big ones, lone ones, variables without (all) the
+    source dims and multi-device plans keep the per-variable pipeline."""
+    from pyremap_amd import DataArray, Dataset, host_path
+    from pyremap_amd.remapper import remap_numpy as rn
+
+    class Desc:
+        dims = ['nCells']
+
+    class Plan:
+        pass
+
+    class R:
+        src_descriptor = Desc()
+        _matrix = Plan()
+        _process_group = None
+    n = 50
+    ds = Dataset()
+    for v in range(5):
+        ds[f'a{v}'] = DataArray(np.zeros((1, n)), dims=('Time', 'nCells'))
+    ds['i'] = DataArray(np.zeros((1, n), dtype=np.int32),
+                        dims=('Time', 'nCells'))        # -> float64: with a*
+    ds['f'] = DataArray(np.zeros((1, n), dtype=np.float32),
+                        dims=('Time', 'nCells'))        # alone in its group
+    ds['b0'] = DataArray(np.zeros((2, n, 3)), dims=('T2', 'nCells', 'L'))
+    ds['b1'] = DataArray(np.zeros((2, n, 3)), dims=('T2', 'nCells', 'L'))
+    ds['other'] = DataArray(np.zeros(4), dims=('x',))
+    names = list(ds.data_vars)
+    got = rn._batches(R(), ds, names)
+    assert got['a0'] == ['a0', 'a1', 'a2', 'a3', 'a4', 'i']
+    assert got['i'] is got['a0'] and got['b0'] == ['b0', 'b1']
+    assert 'f' not in got and 'other' not in got
+    old = host_path.BATCH_VAR_BYTES, host_path.BATCH_TOTAL_BYTES
+    try:
+        host_path.BATCH_VAR_BYTES = 8 * n          # the 3-D ones are too big
+        assert 'b0' not in rn._batches(R(), ds, names)
+        host_path.BATCH_VAR_BYTES = old[0]
+        host_path.BATCH_TOTAL_BYTES = 3 * 8 * n    # three per batch
+        got = rn._batches(R(), ds, names)
+        assert got['a0'] == ['a0', 'a1', 'a2'] and got['a3'] == ['a3', 'a4',
+                                                                 'i']
+    finally:
+        host_path.BATCH_VAR_BYTES, host_path.BATCH_TOTAL_BYTES = old
+    multi = R()
+    multi._matrix = Plan()
+    multi._matrix.shards = []
+    assert rn._batches(multi, ds, names) == {}
+    grouped = R()
+    grouped._process_group = (None, 0)
+    assert rn._batches(grouped, ds, names) == {}
