@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define REMAP_ABI_VERSION 24
+#define REMAP_ABI_VERSION 25
 
 /* The library is built with -fvisibility=hidden: the entry points declared
  * here, and nothing else, are its dynamic symbols. */
@@ -353,7 +353,9 @@ typedef struct remap_apply_args {
      * tune[5] family 10: union entries in flight per wave (8; or 4, 16);
      *         26 / 28: the rolling form with 6 / 8 in flight (float64, even
      *         strides; spmm_grouproll.h: measured, not chosen); 9: keep the
-     *         per-lane masked form under REMAP_FLAG_CELL_MASKS
+     *         per-lane masked form under REMAP_FLAG_CELL_MASKS; 32: the
+     *         shared form (share_* below; tune[2] = K tiles per wave, 1 or
+     *         2; tune[3] = LDS reads ahead of the sums, 1 ... 4)
      * tune[6..7] reserved, must be 0 (a -DREMAP_DIAG build of the library,
      *         tools/build_diag.py, reads bottleneck-analysis switches from
      *         them; this build rejects them) */
@@ -383,6 +385,29 @@ typedef struct remap_apply_args {
      * NULL = absent), kernel family 8: the whole row range, float64 X, one
      * batch (n_batch == 1) of an even number of contiguous columns. */
     const remap_strips *strips;
+    /* Optional SHARED union lists on top of an 8-row group schedule (all
+     * NULL/0 = absent; ABI 25): share_waves (2 or 4) consecutive groups -- a
+     * 4 x 4 or 4 x 8 tile of the destination grid when the groups were built
+     * with super_tile = 4 or 8 -- form a SUPERGROUP served by one workgroup
+     * of share_waves waves.  share_col lists, per supergroup, the sorted
+     * union of the source rows its 8 * share_waves rows reference; bit
+     * 8 w + m of share_mask[u] says whether member m of the supergroup's
+     * w-th group owns union entry u; share_meta[2 s] is supergroup s's first
+     * union entry (entry n_super closes the lists; the odd slots are not
+     * read).  The weights are group_w of the 8-row schedule: its
+     * (group, entry, member) order is every wave's own contiguous stream.
+     * The workgroup sends each distinct source row of the supergroup ONCE
+     * from global memory into an LDS ring (LDS-DMA) and every wave adds the
+     * entries its own rows own from there (csrc/spmm_groupshare.h); a row
+     * still adds its entries in ascending column order, so results are
+     * unchanged.  Used by family 10 with tune[5] = 32 on float64 fields
+     * with even strides and more than 128 columns; built by
+     * remap_share_build.                                                   */
+    const int64_t *share_meta;  /* (device) 2 * (n_super + 1)               */
+    const int32_t *share_col;   /* (device) union entries (+ 256 readable)  */
+    const int32_t *share_mask;  /* (device) union entries (+ 256 readable)  */
+    int32_t share_waves;        /* 2 or 4                                   */
+    int32_t share_reserved;     /* must be 0                                */
 } remap_apply_args;
 
 /* ABI / build information */
@@ -437,6 +462,10 @@ REMAP_API int remap_csr_from_coo(int64_t n_rows, int64_t n_cols, int64_t nnz,
  *                2 x G/2 tiles of it, walked row-major inside super_tile x
  *                super_tile blocks (super_tile <= 0: over the whole grid)
  *   row_offset   index of A's first row in the whole grid (0 unless a shard)
+ *   share_waves  0, or (ABI 25, group_rows = 8) 2 / 4: the group tiles are
+ *                walked inside 4 x 4 / 4 x 8 tiles -- 2 / 4 consecutive
+ *                groups, the supergroups of remap_share_build -- and those
+ *                row-major inside the supertiles (a multiple of the tile)
  *   row_order_out (device, A.n_rows, may be NULL when grid_dims is NULL) the
  *                processing order the schedule assumes: pass it as
  *                remap_apply_args.row_order together with the schedule
@@ -451,11 +480,35 @@ int remap_groups_workspace(int64_t n_rows, int64_t nnz, size_t *bytes_out);
 REMAP_API int remap_groups_build(const remap_csr *A, const double *frac_b,
                        int32_t group_rows, const int64_t *grid_dims,
                        int64_t row_offset, int32_t super_tile,
+                       int32_t share_waves,
                        int32_t *row_order_out, int64_t *group_meta,
                        int32_t *group_col, int32_t *group_mask,
                        double *group_w, int32_t *group_rid,
                        double *group_frac, int64_t *n_union_out,
                        void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Build the SHARED union lists of the shared form of family 10
+ * (remap_apply_args.share_*; csrc/spmm_groupshare.h) on top of an 8-row
+ * group schedule remap_groups_build has made for the same rows: supergroup s
+ * = work slots [8 * share_waves * s, + 8 * share_waves) of that schedule
+ * (build it with the same share_waves, so that a supergroup is a 4 x 4 /
+ * 4 x 8 tile of the destination grid).  Asynchronous
+ * on `stream`; nothing is allocated; the workspace is the one
+ * remap_groups_workspace(A.n_rows, A.nnz) sizes.
+ *
+ *   group_rid    (device) the 8-row schedule's row of every work slot
+ *   share_meta   (device) 2 * (n_super + 1),  n_super = ceil(n_rows / (8 *
+ *                share_waves)); slot 2 s = first union entry of supergroup s
+ *   share_col, share_mask  (device) A.nnz + 256 each (union entries <= nnz;
+ *                the 256 behind the last one are readable zeros)
+ *   n_union_out  (device) one int64: union entries actually used
+ */
+REMAP_API int remap_share_build(const remap_csr *A, const int32_t *group_rid,
+                      int32_t share_waves, int64_t *share_meta,
+                      int32_t *share_col, int32_t *share_mask,
+                      int64_t *n_union_out, void *workspace,
+                      size_t workspace_bytes, void *stream);
 
 /*
  * Build the LDS patch plan of kernel family 5 (remap_apply_args.patch_*) for

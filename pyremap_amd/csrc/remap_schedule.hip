@@ -60,9 +60,15 @@ int group_layout(int64_t n_rows, int64_t nnz, GroupLayout *lay)
     REMAP_HIP_CHECK((rocprim::exclusive_scan(
         nullptr, c, static_cast<const uint32_t *>(nullptr),
         static_cast<uint32_t *>(nullptr), 0u, ne, rocprim::plus<uint32_t>())));
+    size_t d = 0;   // the keys-only sort of share_build
+    REMAP_HIP_CHECK((rocprim::radix_sort_keys(
+        nullptr, d, static_cast<const uint64_t *>(nullptr),
+        static_cast<uint64_t *>(nullptr), ne, 0u, 64u)));
     lay->temp_bytes = a > b ? a : b;
     if (c > lay->temp_bytes)
         lay->temp_bytes = c;
+    if (d > lay->temp_bytes)
+        lay->temp_bytes = d;
     size_t off = 0;
     lay->row_keys_in = off;  off += align_g(nr * 8);
     lay->row_keys_out = off; off += align_g(nr * 8);
@@ -80,9 +86,13 @@ int group_layout(int64_t n_rows, int64_t nnz, GroupLayout *lay)
 // key of a row in the tile walk of the destination grid (my x mx cells,
 // row-major numbering): 2 x gx tiles, row-major inside st x st supertiles,
 // supertiles row-major over the grid
+// share_waves = 2 / 4 (8-row groups): the 2 x 4 group tiles are walked inside
+// 4 x 4 / 4 x 8 SUPERGROUP tiles -- 2 / 4 consecutive groups -- and those
+// row-major inside the supertiles (the shared form, spmm_groupshare.h)
 __global__ __launch_bounds__(kBlock) void order_keys(
     int64_t n_rows, int64_t row_offset, int64_t mx, int64_t st, int32_t G,
-    uint64_t *__restrict__ keys, int32_t *__restrict__ rows)
+    int32_t share_waves, uint64_t *__restrict__ keys,
+    int32_t *__restrict__ rows)
 {
     const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (r >= n_rows)
@@ -92,10 +102,17 @@ __global__ __launch_bounds__(kBlock) void order_keys(
     const int64_t jy = i / mx;
     const int64_t jx = i - jy * mx;
     const int64_t nsx = (mx + st - 1) / st;
-    const int64_t key =
-        ((jy / st) * nsx + jx / st) * (st * st) +
-        (((jy % st) / 2) * (st / gx) + (jx % st) / gx) * G + (jy % 2) * gx +
-        jx % gx;
+    int64_t key = ((jy / st) * nsx + jx / st) * (st * st);
+    if (share_waves > 0) {
+        const int64_t ty = 4, tx = 2 * share_waves;
+        const int64_t ly = jy % st, lx = jx % st;
+        key += ((ly / ty) * (st / tx) + lx / tx) * (ty * tx) +
+               (((ly % ty) / 2) * (tx / gx) + (lx % tx) / gx) * G +
+               (jy % 2) * gx + jx % gx;
+    } else {
+        key += (((jy % st) / 2) * (st / gx) + (jx % st) / gx) * G +
+               (jy % 2) * gx + jx % gx;
+    }
     keys[r] = static_cast<uint64_t>(key);
     rows[r] = static_cast<int32_t>(r);
 }
@@ -163,7 +180,8 @@ __global__ __launch_bounds__(kBlock) void fill_union(
     const uint32_t u = head[n] ? uidx[n] : uidx[n] - 1u;
     if (head[n])
         gcol[u] = static_cast<int32_t>((key / G) % static_cast<uint64_t>(n_a));
-    atomicOr(gmask + u, 1 << static_cast<int>(key % G));
+    atomicOr(gmask + u, static_cast<int32_t>(
+                            1u << static_cast<unsigned>(key % G)));
     if (n == nnz - 1)
         *n_union_out = static_cast<int64_t>(uidx[n]) + head[n];
 }
@@ -228,7 +246,8 @@ int groups_workspace(int64_t n_rows, int64_t nnz, size_t *bytes_out)
 
 int groups_build(const remap_csr *A, const double *frac_b, int32_t G,
                  const int64_t *grid_dims, int64_t row_offset,
-                 int32_t super_tile, int32_t *row_order_out, int64_t *meta,
+                 int32_t super_tile, int32_t share_waves,
+                 int32_t *row_order_out, int64_t *meta,
                  int32_t *gcol, int32_t *gmask, double *gw, int32_t *rid,
                  double *gfrac, int64_t *n_union_out, void *workspace,
                  size_t workspace_bytes, hipStream_t stream)
@@ -253,6 +272,15 @@ int groups_build(const remap_csr *A, const double *frac_b, int32_t G,
         return fail(REMAP_ERR_UNSUPPORTED,
                     "remap_groups_build: mapping too large for 64-bit keys");
     int64_t st = super_tile > 0 ? super_tile : (int64_t(1) << 30);
+    if (share_waves != 0 &&
+        (G != 8 || (share_waves != 2 && share_waves != 4)))
+        return fail(REMAP_ERR_ARG,
+                    "remap_groups_build: share_waves %d: supergroups are 2 "
+                    "or 4 groups of 8 rows", share_waves);
+    if (share_waves != 0 && grid_dims && st % (2 * share_waves) != 0)
+        return fail(REMAP_ERR_ARG,
+                    "remap_groups_build: super_tile %lld is not a multiple "
+                    "of the supergroup tile", (long long)st);
     if (grid_dims) {
         if (grid_dims[0] <= 0 || grid_dims[1] <= 0 || row_offset < 0 ||
             row_offset + n_rows > grid_dims[0] * grid_dims[1])
@@ -289,7 +317,7 @@ int groups_build(const remap_csr *A, const double *frac_b, int32_t G,
     if (grid_dims) {
         hipLaunchKernelGGL(order_keys, dim3(blocks_for(n_rows)), dim3(kBlock),
                            0, stream, n_rows, row_offset, grid_dims[1], st, G,
-                           rk_in, rows_in);
+                           share_waves, rk_in, rows_in);
         REMAP_HIP_CHECK(hipGetLastError());
         size_t tb = lay.temp_bytes;
         REMAP_HIP_CHECK((rocprim::radix_sort_pairs(
@@ -343,6 +371,100 @@ int groups_build(const remap_csr *A, const double *frac_b, int32_t G,
     return REMAP_OK;
 }
 
+// ---------------------------------------------------------------------------
+// The shared union lists of the shared form of family 10 (spmm_groupshare.h):
+// the same derivation as groups_build's steps 2 - 4 with supergroups of SR =
+// 8 * share_waves work slots of an EXISTING 8-row schedule in place of its
+// groups -- slot of every row from group_rid, keys ((supergroup * n_a + col)
+// * SR + member), radix sort (keys only: the weights stay the 8-row
+// schedule's), head flags, scan, union entries and member masks, bounds.
+// ---------------------------------------------------------------------------
+namespace {
+
+__global__ __launch_bounds__(kBlock) void slots_of_rows(
+    int64_t n_rows, const int32_t *__restrict__ rid,
+    int32_t *__restrict__ slot_of)
+{
+    const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (s >= n_rows)
+        return;
+    slot_of[rid[s]] = static_cast<int32_t>(s);
+}
+
+}  // namespace
+
+int share_build(const remap_csr *A, const int32_t *group_rid,
+                int32_t share_waves, int64_t *meta, int32_t *scol,
+                int32_t *smask, int64_t *n_union_out, void *workspace,
+                size_t workspace_bytes, hipStream_t stream)
+{
+    if (!A || !group_rid || !meta || !scol || !smask || !n_union_out)
+        return fail(REMAP_ERR_ARG, "remap_share_build: NULL argument");
+    if (share_waves != 2 && share_waves != 4)
+        return fail(REMAP_ERR_ARG,
+                    "remap_share_build: supergroups hold 2 or 4 groups, "
+                    "not %d", share_waves);
+    const int32_t SR = 8 * share_waves;
+    const int64_t n_rows = A->n_rows, nnz = A->nnz, n_a = A->n_cols;
+    if (n_rows <= 0 || nnz <= 0 || n_a <= 0)
+        return fail(REMAP_ERR_ARG,
+                    "remap_share_build: an empty matrix has no schedule");
+    if (!A->rowptr || !A->col)
+        return fail(REMAP_ERR_ARG, "remap_share_build: NULL CSR array");
+    const int64_t n_super = (n_rows + SR - 1) / SR;
+    if (static_cast<long double>(n_super) * n_a * SR >= 9.0e18L ||
+        nnz >= (int64_t(1) << 32) - 1)
+        return fail(REMAP_ERR_UNSUPPORTED,
+                    "remap_share_build: mapping too large for 64-bit keys");
+    GroupLayout lay;
+    const int rc = group_layout(n_rows, nnz, &lay);
+    if (rc != REMAP_OK)
+        return rc;
+    if (!workspace || workspace_bytes < lay.total)
+        return fail(REMAP_ERR_WORKSPACE,
+                    "remap_share_build: workspace of %zu bytes, need %zu",
+                    workspace_bytes, lay.total);
+    char *ws = static_cast<char *>(workspace);
+    int32_t *slot_of = reinterpret_cast<int32_t *>(ws + lay.slot_of_row);
+    uint64_t *k_in = reinterpret_cast<uint64_t *>(ws + lay.keys_in);
+    uint64_t *k_out = reinterpret_cast<uint64_t *>(ws + lay.keys_out);
+    uint32_t *head = reinterpret_cast<uint32_t *>(ws + lay.head);
+    uint32_t *uidx = reinterpret_cast<uint32_t *>(ws + lay.uidx);
+    void *temp = ws + lay.temp;
+
+    hipLaunchKernelGGL(slots_of_rows, dim3(blocks_for(n_rows)), dim3(kBlock),
+                       0, stream, n_rows, group_rid, slot_of);
+    REMAP_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(entry_keys, dim3(blocks_for(n_rows)), dim3(kBlock), 0,
+                       stream, n_rows, n_a, SR, A->rowptr, A->col, slot_of,
+                       k_in);
+    REMAP_HIP_CHECK(hipGetLastError());
+    size_t tb = lay.temp_bytes;
+    REMAP_HIP_CHECK((rocprim::radix_sort_keys(
+        temp, tb, static_cast<const uint64_t *>(k_in), k_out,
+        static_cast<size_t>(nnz), 0u, 64u, stream)));
+    hipLaunchKernelGGL(flag_union_heads, dim3(blocks_for(nnz)), dim3(kBlock),
+                       0, stream, nnz, SR, k_out, head);
+    REMAP_HIP_CHECK(hipGetLastError());
+    tb = lay.temp_bytes;
+    REMAP_HIP_CHECK((rocprim::exclusive_scan(
+        temp, tb, static_cast<const uint32_t *>(head), uidx, 0u,
+        static_cast<size_t>(nnz), rocprim::plus<uint32_t>(), stream)));
+    REMAP_HIP_CHECK(hipMemsetAsync(scol, 0, (nnz + 256) * sizeof(int32_t),
+                                   stream));
+    REMAP_HIP_CHECK(hipMemsetAsync(smask, 0, (nnz + 256) * sizeof(int32_t),
+                                   stream));
+    hipLaunchKernelGGL(fill_union, dim3(blocks_for(nnz)), dim3(kBlock), 0,
+                       stream, nnz, n_a, SR, k_out, head, uidx, scol, smask,
+                       n_union_out);
+    REMAP_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(group_bounds, dim3(blocks_for(n_super + 1)),
+                       dim3(kBlock), 0, stream, n_super, nnz, n_a, SR, k_out,
+                       head, uidx, meta);
+    REMAP_HIP_CHECK(hipGetLastError());
+    return REMAP_OK;
+}
+
 }  // namespace remap
 
 extern "C" {
@@ -355,6 +477,7 @@ int remap_groups_workspace(int64_t n_rows, int64_t nnz, size_t *bytes_out)
 int remap_groups_build(const remap_csr *A, const double *frac_b,
                        int32_t group_rows, const int64_t *grid_dims,
                        int64_t row_offset, int32_t super_tile,
+                       int32_t share_waves,
                        int32_t *row_order_out, int64_t *group_meta,
                        int32_t *group_col, int32_t *group_mask,
                        double *group_w, int32_t *group_rid,
@@ -362,11 +485,24 @@ int remap_groups_build(const remap_csr *A, const double *frac_b,
                        void *workspace, size_t workspace_bytes, void *stream)
 {
     return remap::groups_build(A, frac_b, group_rows, grid_dims, row_offset,
-                               super_tile, row_order_out, group_meta,
+                               super_tile, share_waves, row_order_out,
+                               group_meta,
                                group_col, group_mask, group_w, group_rid,
                                group_frac, n_union_out, workspace,
                                workspace_bytes,
                                static_cast<hipStream_t>(stream));
+}
+
+int remap_share_build(const remap_csr *A, const int32_t *group_rid,
+                      int32_t share_waves, int64_t *share_meta,
+                      int32_t *share_col, int32_t *share_mask,
+                      int64_t *n_union_out, void *workspace,
+                      size_t workspace_bytes, void *stream)
+{
+    return remap::share_build(A, group_rid, share_waves, share_meta,
+                              share_col, share_mask, n_union_out, workspace,
+                              workspace_bytes,
+                              static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"
@@ -940,7 +1076,7 @@ int schedule_auto(const remap_csr *A, const double *frac_b,
         if (!gfrac)
             return fail(REMAP_ERR_WORKSPACE,
                         "remap_schedule_auto: arena too small");
-        rc = groups_build(A, frac_b, G, dims2, row_offset, st,
+        rc = groups_build(A, frac_b, G, dims2, row_offset, st, 0,
                           two_d ? order : nullptr, meta, gcol, gmask, gw, rid,
                           gfrac, stats, workspace, workspace_bytes, stream);
         if (rc != REMAP_OK)

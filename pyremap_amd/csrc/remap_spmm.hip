@@ -40,6 +40,7 @@
 //    to Infinity Cache / HBM eight times.
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 #include <hip/hip_ext.h>
 
@@ -63,6 +64,7 @@ namespace {
 #include "spmm_rowgroup.h"
 #include "spmm_grouproll.h"
 #include "spmm_groupmask.h"
+#include "spmm_groupshare.h"
 #include "spmm_rowlane.h"
 #include "spmm_rowcell.h"
 #include "spmm_patchcell.h"
@@ -601,6 +603,64 @@ int launch_rowgroup(const remap_apply_args *a, const KParams &p, int tiles,
     return REMAP_OK;
 }
 
+// the shared form (spmm_groupshare.h): float64, two elements per lane
+typedef void (*share_fn)(const KParams, const uint32_t, const int64_t *,
+                         const double *, const int32_t *, const double *,
+                         const int64_t *, const int32_t *, const int32_t *,
+                         const double *);
+
+template <int TILES, int W, int AHEAD>
+share_fn pick_groupshare_mode(int mode, bool fma)
+{
+    switch (mode) {
+    case REMAP_MODE_RAW:
+        return fma ? spmm_groupshare<TILES, REMAP_MODE_RAW, true, W, 8, AHEAD>
+                   : spmm_groupshare<TILES, REMAP_MODE_RAW, false, W, 8,
+                                     AHEAD>;
+    case REMAP_MODE_FRACB:
+        return fma ? spmm_groupshare<TILES, REMAP_MODE_FRACB, true, W, 8,
+                                     AHEAD>
+                   : spmm_groupshare<TILES, REMAP_MODE_FRACB, false, W, 8,
+                                     AHEAD>;
+    default:
+        return fma ? spmm_groupshare<TILES, REMAP_MODE_MASKED, true, W, 8,
+                                     AHEAD>
+                   : spmm_groupshare<TILES, REMAP_MODE_MASKED, false, W, 8,
+                                     AHEAD>;
+    }
+}
+
+template <int W>
+share_fn pick_groupshare(int tiles, int ahead, int mode, bool fma)
+{
+    if (tiles == 1)
+        return ahead == 1   ? pick_groupshare_mode<1, W, 1>(mode, fma)
+               : ahead == 3 ? pick_groupshare_mode<1, W, 3>(mode, fma)
+                            : pick_groupshare_mode<1, W, 2>(mode, fma);
+    return ahead == 1   ? pick_groupshare_mode<2, W, 1>(mode, fma)
+           : ahead == 3 ? pick_groupshare_mode<2, W, 3>(mode, fma)
+                        : pick_groupshare_mode<2, W, 2>(mode, fma);
+}
+
+int launch_groupshare(const remap_apply_args *a, const KParams &p, int tiles,
+                      int ahead, bool fma, int64_t grid, hipStream_t stream)
+{
+    const int W = a->share_waves;
+    share_fn fn = W == 4 ? pick_groupshare<4>(tiles, ahead, a->mode, fma)
+                         : pick_groupshare<2>(tiles, ahead, a->mode, fma);
+    // the ring: two buffers of 8 entries, 1 KiB per entry and K tile
+    uint32_t lds_bytes = 2u * 8u * 1024u * static_cast<uint32_t>(tiles);
+    REMAP_HIP_CHECK(diag_lds_throttle(a, reinterpret_cast<const void *>(fn),
+                                      lds_bytes));
+    hipLaunchKernelGGL(fn, dim3(static_cast<uint32_t>(grid)),
+                       dim3(kWave * W), lds_bytes, stream, p, a->flags,
+                       a->group_meta, a->group_w, a->group_rid, a->group_frac,
+                       a->share_meta, a->share_col, a->share_mask,
+                       static_cast<const double *>(a->X));
+    REMAP_HIP_CHECK(hipGetLastError());
+    return REMAP_OK;
+}
+
 bool aligned(const void *p, size_t a)
 {
     return (reinterpret_cast<uintptr_t>(p) % a) == 0;
@@ -622,6 +682,7 @@ struct Call {
     bool patch_ok;        // a usable patch plan is attached
     bool cell_ok;         // a patch plan family 7 can use is attached
     bool group_ok;        // a usable row-group schedule is attached
+    bool share_ok;        // ... and shared union lists on top of it
     bool strip_ok;        // a strip schedule this call can run on is attached
 };
 
@@ -716,6 +777,10 @@ int check_args(const remap_apply_args *a, Call &c)
                  a->group_reserved == 0 &&
                  a->n_groups ==
                      (c.n_rows + a->group_rows - 1) / a->group_rows;
+    c.share_ok = c.group_ok && a->group_rows == 8 && a->share_meta &&
+                 a->share_col && a->share_mask &&
+                 (a->share_waves == 2 || a->share_waves == 4) &&
+                 a->share_reserved == 0;
     const remap_strips *st = a->strips;
     c.strip_ok = st && st->n_units > 0 && st->steps_per_unit > 0 &&
                  st->rows_per_wave > 0 && st->ring_slots >= 2 &&
@@ -968,6 +1033,43 @@ int run_rowgroup(const remap_apply_args *a, const Call &c, KParams p,
                     "remap_apply_f64: the rowgroup kernel needs the "
                     "row-group schedule for [row_begin, row_end) and 32-bit "
                     "offsets");
+    // tune[5] = 32: the shared form (spmm_groupshare.h) -- W waves, one
+    // union through an LDS ring; float64 fields in whole 16-byte pieces,
+    // more than 128 columns.  A call it cannot serve takes the 8-row groups
+    // of the same schedule (a preference under REMAP_FLAG_TUNE_HINT, an
+    // error otherwise).
+    if (a->tune[5] == 32) {
+        const bool can = c.share_ok && c.dma16 && c.K > 128 &&
+                         a->x_src_fold == 0;
+        if (can) {
+            // K tiles per wave: 2 (256 columns per workgroup and step; the
+            // masked mode's per-lane normalisers leave room for one)
+            int tiles = a->tune[2];
+            if (tiles != 1 && tiles != 2)
+                tiles = a->mode == REMAP_MODE_MASKED ? 1 : 2;
+            const int ahead =
+                (a->tune[3] >= 1 && a->tune[3] <= 3) ? a->tune[3] : 2;
+            p.rows_per_wave = 1;
+            const int64_t k_chunks =
+                shape_tiles(p, a, c.K, kWave * 2, tiles);
+            const int64_t n_super =
+                ceil_div(a->n_groups, (int64_t)a->share_waves);
+            int64_t grid;
+            const int rc =
+                shape_grid(p, n_super, k_chunks, a->tune[4] != 1, grid);
+            if (rc != REMAP_OK)
+                return rc;
+            if (a->tune[4] == 3)
+                p.xcd_map |= 2;
+            return launch_groupshare(a, p, tiles, ahead, c.fma, grid,
+                                     stream);
+        }
+        if (!(a->flags & REMAP_FLAG_TUNE_HINT))
+            return fail(REMAP_ERR_UNSUPPORTED,
+                        "remap_apply_f64: the shared form (tune[5] = 32) "
+                        "serves float64 fields of more than 128 even-strided "
+                        "columns on a plan with share_* lists");
+    }
     // f32 rows are half as long: two K tiles per wave keep the bytes per
     // wave and row at 1 KiB (measured +7 % on config 3 with f32 fields).
     // f64 with 128 < K <= 224 columns: one wave over both (the second only
@@ -980,7 +1082,8 @@ int run_rowgroup(const remap_apply_args *a, const Call &c, KParams p,
     // (spmm_groupmask.h) with two K tiles per wave, whatever tune[2] says
     const bool cell_masks =
         (a->flags & REMAP_FLAG_CELL_MASKS) && a->mode == REMAP_MODE_MASKED &&
-        a->group_rows == 8 && c.can_vec2 && c.K > 128 && a->tune[5] == 0;
+        a->group_rows == 8 && c.can_vec2 && c.K > 128 &&
+        (a->tune[5] == 0 || a->tune[5] == 32);
     if (cell_masks)
         tiles = 2;
     if (tiles != 2 || c.K <= 128)
@@ -1000,7 +1103,8 @@ int run_rowgroup(const remap_apply_args *a, const Call &c, KParams p,
         return fail(REMAP_ERR_UNSUPPORTED,
                     "remap_apply_f64: 16-row groups serve float64 fields of "
                     "more than 64 even-strided columns");
-    int gpw = a->tune[3] > 0 ? a->tune[3] : 2;   // groups per wave
+    // groups per wave (the shared form reads tune[3] differently)
+    int gpw = (a->tune[3] > 0 && a->tune[5] != 32) ? a->tune[3] : 2;
     // union entries in flight
     int unr = (a->tune[5] == 4 || a->tune[5] == 16) ? a->tune[5] : 8;
     // waves per workgroup (tune[1], unused otherwise by this family)
@@ -1032,7 +1136,8 @@ int run_rowgroup(const remap_apply_args *a, const Call &c, KParams p,
     // sixteen union entries in flight instead of eight (config 3's map,
     // (8, nCells, 60), two boxes: 0.447 -> 0.426 ms, 0.412 -> 0.393; 100 or
     // 61 levels, one batch per tile: slower or no change)
-    if (a->tune[5] == 0 && p.bpc >= 2 && p.bpc != kBatchPerChunk && !lock &&
+    if ((a->tune[5] == 0 || a->tune[5] == 32) && p.bpc >= 2 &&
+        p.bpc != kBatchPerChunk && !lock &&
         a->group_rows == 4)
         unr = 16;
     int64_t grid;

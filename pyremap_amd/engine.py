@@ -50,7 +50,7 @@ CELL_MAX_RUN = 4
 DTYPE_F64 = 0
 DTYPE_F32 = 1
 
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 #: readable pad entries kept behind col/val (remap_csr.csr_pad)
 CSR_PAD = 8
@@ -67,7 +67,7 @@ EXPORTS = (
     'remap_device_count', 'remap_apply_f64', 'remap_csr_from_coo_workspace',
     'remap_csr_from_coo', 'remap_stream_copy', 'remap_scan_nan',
     'remap_scan_nan_kinds',
-    'remap_groups_workspace', 'remap_groups_build',
+    'remap_groups_workspace', 'remap_groups_build', 'remap_share_build',
     'remap_patches_workspace', 'remap_patches_build',
     'remap_schedule_sizes', 'remap_schedule_auto',
     'remap_plan_create', 'remap_plan_destroy', 'remap_plan_query',
@@ -137,6 +137,11 @@ class _ApplyArgs(ctypes.Structure):
         ('x_outer_stride', ctypes.c_int64),
         ('patch_ell_base', ctypes.c_void_p),
         ('strips', ctypes.c_void_p),
+        ('share_meta', ctypes.c_void_p),
+        ('share_col', ctypes.c_void_p),
+        ('share_mask', ctypes.c_void_p),
+        ('share_waves', ctypes.c_int32),
+        ('share_reserved', ctypes.c_int32),
     ]
 
 
@@ -288,8 +293,13 @@ def load_library():
     lib.remap_groups_build.restype = ctypes.c_int
     lib.remap_groups_build.argtypes = [
         ctypes.POINTER(_CSR), ctypes.c_void_p, ctypes.c_int32,
-        ctypes.POINTER(ctypes.c_int64), ctypes.c_int64, ctypes.c_int32] + \
+        ctypes.POINTER(ctypes.c_int64), ctypes.c_int64, ctypes.c_int32,
+        ctypes.c_int32] + \
         [ctypes.c_void_p] * 9 + [ctypes.c_size_t, ctypes.c_void_p]
+    lib.remap_share_build.restype = ctypes.c_int
+    lib.remap_share_build.argtypes = [
+        ctypes.POINTER(_CSR), ctypes.c_void_p, ctypes.c_int32] + \
+        [ctypes.c_void_p] * 5 + [ctypes.c_size_t, ctypes.c_void_p]
     lib.remap_patches_workspace.restype = ctypes.c_int
     lib.remap_patches_workspace.argtypes = [
         ctypes.c_int64, ctypes.c_int64, ctypes.POINTER(ctypes.c_size_t)]
@@ -562,6 +572,12 @@ class RemapPlan:
                 args.group_frac = groups['frac'].data_ptr()
                 args.n_groups = groups['n']
                 args.group_rows = groups['rows']
+                share = groups.get('share')
+                if share is not None:
+                    args.share_meta = share['meta'].data_ptr()
+                    args.share_col = share['col'].data_ptr()
+                    args.share_mask = share['mask'].data_ptr()
+                    args.share_waves = share['waves']
             if self.strips is not None:
                 # (self-contained: its own row order and row ids)
                 args.strips = ctypes.addressof(self.strips['struct'])
@@ -1010,7 +1026,8 @@ class RemapPlan:
 
     GROUP = 8   # default rows per group (remap_apply_args.group_rows)
 
-    def build_groups(self, grid_dims=None, super_tile=32, rows=None):
+    def build_groups(self, grid_dims=None, super_tile=32, rows=None,
+                     share=0):
         """
         Build the row-group schedule (``remap_apply_args.group_*``) with the
         library's device builder (``remap_groups_build``): ``rows`` (8 or 4)
@@ -1020,12 +1037,26 @@ class RemapPlan:
         the weights are stored for the present (union entry, member) pairs
         only, in that order.  Returns union entries / entries (small = many
         shared source rows).
+
+        ``share`` = 2 or 4: also build the SHARED union lists of the shared
+        form (``csrc/spmm_groupshare.h``, ``remap_share_build``): 2 / 4
+        consecutive 8-row groups -- a 4 x 4 / 4 x 8 tile of the grid, walked
+        row-major inside the supertiles -- get one union served by one
+        workgroup through LDS.  ``groups['share']['ratio']`` is their union
+        entries / entries.
         """
         torch = _torch()
         lib = load_library()
         G = int(rows or self.GROUP)
         if G not in (4, 8, 16):
             raise ValueError('row groups hold 4, 8 or 16 rows')
+        share = int(share or 0)
+        if share:
+            if share not in (2, 4) or G != 8:
+                raise ValueError('shared lists: 2 or 4 groups of 8 rows')
+            if int(super_tile) < (1 << 30) and int(super_tile) % (2 * share):
+                raise ValueError('super_tile must hold whole 4 x '
+                                 f'{2 * share} supergroup tiles')
         self.groups = None
         if self.nnz == 0 or self.n_b == 0:
             return None
@@ -1061,17 +1092,37 @@ class RemapPlan:
                              device=dev)
             _check(lib.remap_groups_build(
                 ctypes.byref(csr), _ptr(self.frac_b), G, dims,
-                self.row_offset, st, _ptr(order), _ptr(meta), _ptr(col),
+                self.row_offset, st, share, _ptr(order), _ptr(meta),
+                _ptr(col),
                 _ptr(mask), _ptr(w), _ptr(rid), _ptr(frac), _ptr(n_union),
                 _ptr(ws), ws.numel(), _stream_ptr(dev)),
                 'remap_groups_build')
             nu = int(n_union)
         self.row_order = order
         # trim the union arrays to what is used (+ the readable pad)
-        self.groups = dict(meta=meta, col=col[:nu + 32].clone(),
-                           w=w, mask=mask[:nu + 32].clone(), rid=rid,
-                           frac=frac, n=n_groups, rows=G, order=order,
-                           union=nu)
+        groups = dict(meta=meta, col=col[:nu + 32].clone(),
+                      w=w, mask=mask[:nu + 32].clone(), rid=rid,
+                      frac=frac, n=n_groups, rows=G, order=order,
+                      union=nu)
+        if share:
+            n_super = (self.n_b + 8 * share - 1) // (8 * share)
+            smeta = torch.empty((n_super + 1, 2), dtype=torch.int64,
+                                device=dev)
+            # (col / mask above are free again: trimmed copies were taken)
+            scol = torch.empty(self.nnz + 256, dtype=torch.int32, device=dev)
+            smask = torch.empty(self.nnz + 256, dtype=torch.int32,
+                                device=dev)
+            with torch.cuda.device(dev):
+                _check(lib.remap_share_build(
+                    ctypes.byref(csr), _ptr(rid), share, _ptr(smeta),
+                    _ptr(scol), _ptr(smask), _ptr(n_union), _ptr(ws),
+                    ws.numel(), _stream_ptr(dev)), 'remap_share_build')
+                su = int(n_union)
+            groups['share'] = dict(meta=smeta, col=scol[:su + 256].clone(),
+                                   mask=smask[:su + 256].clone(),
+                                   waves=share, union=su,
+                                   ratio=su / self.nnz)
+        self.groups = groups
         return nu / self.nnz
 
     #: a row counts as LONG from this many entries on (the widest stencils

@@ -1,0 +1,190 @@
+"""
+The shared form of kernel family 10 (round 6, csrc/spmm_groupshare.h): 2 or 4
+waves, one union of source rows per 16 / 32 destination rows, sent once into
+an LDS ring by LDS-DMA -- every value against the oracle, bit for bit,
+through the C ABI; the shared lists (`remap_share_build`) against a numpy
+restatement.  Reference arithmetic: remap_numpy.py:258-278 (each row adds its
+own entries in ascending column order, scipy's csr_matvecs).
+"""
+import numpy as np
+import pytest
+
+from helpers import assert_bitwise
+from test_gpu_group_forms import _check, _fields
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'these tests need an MI355X'
+    from pyremap_amd import engine
+    engine.load_library()
+    return torch.device('cuda', 0)
+
+
+def _problem(dev, share, n_a=1500, dims=(38, 60), k=(6, 22), seed=5,
+             two_d=True):
+    from oracle import oracle
+    from pyremap_amd import engine, synthetic
+    m = synthetic.conservative_map(n_a, dims, k[0], k[1], seed=seed,
+                                   signed=True, locality='mesh')
+    mm = m.numpy()
+    plan = engine.RemapPlan.from_triplets(
+        mm['row'], mm['col'], mm['S'], mm['frac_b'], m.n_a, m.n_b,
+        index_base=1, device=dev)
+    csr = oracle.coo_to_csr(mm['row'] - 1, mm['col'] - 1, mm['S'], m.n_b,
+                            m.n_a)
+    plan.build_groups(m.dst_dims if two_d else None, rows=8, share=share)
+    return m, mm, plan, csr
+
+
+@pytest.mark.parametrize('two_d', [True, False])
+@pytest.mark.parametrize('share', [2, 4])
+def test_shared_lists_match_a_numpy_restatement(dev, share, two_d):
+    """share_col / share_mask / share_meta: per supergroup of 8 * share work
+    slots the sorted distinct columns of its rows and who owns them; with a
+    2-D grid a supergroup is a 4 x 4 / 4 x 8 tile (whole tiles inside)."""
+    m, mm, plan, csr = _problem(dev, share, two_d=two_d)
+    indptr, indices = csr.indptr, csr.indices
+    g = plan.groups
+    sh = g['share']
+    assert sh['waves'] == share
+    rid = g['rid'].cpu().numpy()
+    meta = sh['meta'].cpu().numpy()
+    col = sh['col'].cpu().numpy()
+    mask = sh['mask'].cpu().numpy().view(np.uint32)
+    SR = 8 * share
+    n_super = (m.n_b + SR - 1) // SR
+    assert meta.shape == (n_super + 1, 2)
+    total = 0
+    for s in range(n_super):
+        slots = range(s * SR, min((s + 1) * SR, m.n_b))
+        want = {}
+        for member, slot in enumerate(slots):
+            r = rid[slot]
+            for c in indices[indptr[r]:indptr[r + 1]]:
+                want[int(c)] = want.get(int(c), 0) | (1 << member)
+        lo, hi = meta[s, 0], meta[s + 1, 0]
+        assert lo == total
+        cols = sorted(want)
+        assert hi - lo == len(cols), s
+        assert col[lo:hi].tolist() == cols, s
+        assert mask[lo:hi].tolist() == [want[c] for c in cols], s
+        total += len(cols)
+    assert total == sh['union']
+    # readable zeros behind the lists
+    assert not col[total:total + 256].any()
+    assert not mask[total:total + 256].any()
+    assert abs(sh['ratio'] - total / plan.nnz) < 1e-12
+    if two_d:
+        # a supergroup whose tile lies inside the grid is that tile
+        my, mx = m.dst_dims
+        ty, tx = 4, 2 * share
+        r0 = rid[:SR]
+        assert sorted(r0.tolist()) == sorted(
+            y * mx + x for y in range(ty) for x in range(tx))
+
+
+@pytest.mark.parametrize('share', [2, 4])
+@pytest.mark.parametrize('K', [130, 192, 256, 300, 1024])
+def test_shared_form_bitwise(dev, share, K):
+    """Three modes, one or two K tiles per wave, 1 - 3 LDS reads ahead, both
+    work-list orders; NaNs in the field (propagated in the frac_b / raw
+    modes, masked in the masked mode)."""
+    from pyremap_amd import engine
+    m, mm, plan, csr = _problem(dev, share)
+    fields = _fields(m.n_a, K, K + share)
+    for tiles in (1, 2):
+        for ahead, order in ((2, 3), (1, 2), (3, 1)):
+            tune = [10, 0, tiles, ahead, order, 32]
+            for mode, thr in ((engine.MODE_FRACB, 0.0),
+                              (engine.MODE_RAW, 0.0),
+                              (engine.MODE_MASKED, 0.3)):
+                for tag, x in fields:
+                    if mode != engine.MODE_MASKED and tag not in (
+                            'no NaN', 'single values'):
+                        continue
+                    _check(plan, csr, mm['frac_b'], x, dev, mode, thr, tune,
+                           f'share {share} K={K} {tag} tune={tune} '
+                           f'mode={mode}')
+
+
+@pytest.mark.parametrize('share', [2, 4])
+def test_shared_form_long_lists_one_dimensional_and_fma(dev, share):
+    """Lists of more than 64 and more than 128 union entries (the lane-held
+    blocks of columns and masks wrap), a 1-D destination (supergroups of
+    consecutive rows, the last one partial), REMAP_FLAG_FMA at rtol 1e-13."""
+    from oracle import oracle
+    from pyremap_amd import engine
+    m, mm, plan, csr = _problem(dev, share, n_a=700, dims=(30, 44),
+                                k=(24, 60), seed=11)
+    meta = plan.groups['share']['meta'][:, 0].cpu().numpy()
+    longest = int(np.diff(meta).max())
+    assert longest > 64 * (1 if share == 2 else 2), longest
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((m.n_a, 384))
+    for tune in ([10, 0, 2, 2, 3, 32], [10, 0, 1, 3, 2, 32]):
+        for mode, thr in ((engine.MODE_FRACB, 0.0), (engine.MODE_MASKED, 0.2)):
+            xm = x.copy()
+            if mode == engine.MODE_MASKED:
+                xm[rng.random(m.n_a) < 0.3] = np.nan
+            _check(plan, csr, mm['frac_b'], xm, dev, mode, thr, tune,
+                   f'long lists, share {share} tune={tune} mode={mode}')
+    # 1-D destination, n_b no multiple of the supergroup
+    m1, mm1, plan1, csr1 = _problem(dev, share, n_a=900, dims=(1, 1013),
+                                    k=(5, 14), seed=2, two_d=False)
+    x1 = rng.standard_normal((m1.n_a, 258))
+    _check(plan1, csr1, mm1['frac_b'], x1, dev, engine.MODE_FRACB, 0.0,
+           [10, 0, 2, 2, 3, 32], f'1-D, share {share}')
+    # fused multiply-add: opt-in, close
+    xd = torch.from_numpy(x).to(dev)
+    y = engine.remap_tensor(plan, None, xd, [0], engine.MODE_FRACB,
+                            tune=[10, 0, 2, 2, 3, 32],
+                            flags=engine.FLAG_FMA)
+    ref, ref_mask = oracle.remap_flat(csr, mm['frac_b'], x, False, 0.0)
+    ok = ~ref_mask
+    np.testing.assert_allclose(y.cpu().numpy()[ok], ref[ok], rtol=1e-12,
+                               atol=1e-13)
+
+
+def test_shared_form_layouts_and_what_it_declines(dev):
+    """(Time, nCells, L) in place (batch strides, 256 levels and 2 x 96);
+    float32 fields, few columns and odd strides are declined -- an error
+    when demanded, the 8-row groups of the same schedule under
+    REMAP_FLAG_TUNE_HINT (same bits)."""
+    from oracle import oracle
+    from pyremap_amd import engine
+    m, mm, plan, csr = _problem(dev, 4)
+    rng = np.random.default_rng(8)
+    tune = [10, 0, 2, 2, 3, 32]
+    for T, L in ((2, 256), (3, 96)):
+        f = rng.standard_normal((T, m.n_a, L))
+        fd = torch.from_numpy(f).to(dev)
+        y = engine.remap_tensor(plan, None, fd, [1], engine.MODE_FRACB,
+                                tune=tune)
+        flat = np.ascontiguousarray(f.transpose(1, 0, 2)).reshape(m.n_a, -1)
+        ref, ref_mask = oracle.remap_flat(csr, mm['frac_b'], flat, False, 0.0)
+        ref = ref.copy()
+        ref[ref_mask] = np.nan
+        got = y.cpu().numpy().transpose(1, 0, 2).reshape(m.n_b, -1)
+        assert_bitwise(got, ref, f'(T={T}, n, L={L})')
+    x = rng.standard_normal((m.n_a, 96))
+    x32 = rng.standard_normal((m.n_a, 256)).astype(np.float32)
+    xodd = rng.standard_normal((m.n_a, 257))
+    for what, field in (('96 columns', x), ('float32', x32),
+                        ('odd stride', xodd)):
+        fd = torch.from_numpy(field).to(dev)
+        with pytest.raises(engine.EngineError, match='shared form'):
+            engine.remap_tensor(plan, None, fd, [0], engine.MODE_FRACB,
+                                tune=tune)
+        _check(plan, csr, mm['frac_b'], field, dev, engine.MODE_FRACB, 0.0,
+               tune, what, flags=engine.FLAG_TUNE_HINT)
+    # without the lists the switch is an error as well
+    plan.build_groups(m.dst_dims, super_tile=32, rows=8)
+    with pytest.raises(engine.EngineError, match='shared form'):
+        engine.remap_tensor(plan, None, torch.from_numpy(
+            rng.standard_normal((m.n_a, 256))).to(dev), [0],
+            engine.MODE_FRACB, tune=tune)

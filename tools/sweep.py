@@ -44,6 +44,10 @@ def main():
                          'order, no timing (run under rocprofv3 --pmc)')
     ap.add_argument('--shard', default=None,
                     help="R/N: time the rows rank R of N would own")
+    ap.add_argument('--pairs', default=None,
+                    help="';'-separated order|tune[|flags]: the variants, "
+                         'instead of the product of --orders x --flags x '
+                         '--tunes (the orders still come from --orders)')
     ap.add_argument('--orders', default='none',
                     help="';'-separated: none | morton | tile:TYxTX")
     args = ap.parse_args()
@@ -89,13 +93,18 @@ def main():
     group_sets = {}
     for o in args.orders.split(';'):
         if o.startswith('group'):
-            # group:<supertile>[:<rows per group>]
+            # group:<supertile>[:<rows per group>[:share<W>]] -- share<W>:
+            # + the shared union lists of W groups (spmm_groupshare.h)
             parts = o.split(':')
             st = int(parts[1]) if len(parts) > 1 else 32
+            share = int(parts[3][5:]) if len(parts) > 3 else 0
             ratio = plan.build_groups(
                 None if o.startswith('group1d') else m.dst_dims,
-                super_tile=st, rows=int(parts[2]) if len(parts) > 2 else 8)
-            print(f'{o}: union/nnz = {ratio}')
+                super_tile=st, rows=int(parts[2]) if len(parts) > 2 else 8,
+                share=share)
+            print(f'{o}: union/nnz = {ratio}' + (
+                f', shared by {share} groups: '
+                f'{plan.groups["share"]["ratio"]}' if share else ''))
             orders[o] = plan.row_order
             group_sets[o] = plan.groups
             continue
@@ -125,6 +134,14 @@ def main():
             for t in args.tunes.split(';'):
                 tune = [int(v) for v in t.split(',')] if t != '0' else None
                 variants.append((int(fl), tune, o))
+    if args.pairs:
+        variants = []
+        for pr in args.pairs.split(';'):
+            parts = pr.split('|')
+            t = parts[1]
+            variants.append((int(parts[2]) if len(parts) > 2 else 0,
+                             [int(v) for v in t.split(',')] if t != '0'
+                             else None, parts[0]))
     bytes_alg = plan.algorithmic_bytes(K, xs[0].element_size(), mode)
     print(f'{args.workload}: n_a={m.n_a} n_b={m.n_b} nnz={plan.nnz} K={K} '
           f'bytes_alg={bytes_alg / 1e9:.3f} GB mode={args.mode}')
@@ -162,8 +179,9 @@ def main():
             if ref is None:
                 ref = ys[0].clone()
             else:
-                same = torch.equal(torch.nan_to_num(ys[0], nan=1e300),
-                                   torch.nan_to_num(ref, nan=1e300))
+                # bit for bit (no temporaries: config 5's Y is 53 GB)
+                same = torch.equal(ys[0].view(torch.int64),
+                                   ref.view(torch.int64))
                 assert same, f'variant {v} changes the result'
     for rnd in range(args.rounds):
         for vi, v in enumerate(variants):
