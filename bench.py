@@ -1346,9 +1346,12 @@ def main():
             def bail_big():
                 # The metric and its exchange measurements are complete and
                 # clean; what did not return is an EXTRA workload (15-30 GB
-                # broadcasts).  The line says so (`status`, the missing rows
-                # of multi_gpu.workloads) and the run ends with exit code 0:
-                # the scaling record must not be lost to an extra.
+                # broadcasts, or a kernel that hangs).  The line is printed
+                # all the same -- the scaling record survives, `status` and
+                # the missing rows of multi_gpu.workloads say what happened
+                # -- but a process that leaves a collective or a kernel
+                # behind does not end like a clean run: exit code 4 (3 is
+                # the hung exchange of the metric itself).
                 if rank == 0:
                     late = dict(res['exchange'] or {})
                     late['optional_measurements'] = (
@@ -1360,7 +1363,7 @@ def main():
                         status='extras_timed_out', details_path=shown_path)
                     write_details(details_path, line, details)
                     print_line(line)
-                os._exit(0)
+                os._exit(4)
             watchdog = threading.Timer(BIG_TIMEOUT_S, bail_big)
             watchdog.daemon = True
             watchdog.start()

@@ -121,7 +121,19 @@ enum {
      * missing, 26.7 -> 35.3 with the flag set on a bathymetry mask).
      * remap_scan_nan_kinds() tells the two apart on the device.  Ignored
      * elsewhere. */
-    REMAP_FLAG_CELL_MASKS = 1u << 4
+    REMAP_FLAG_CELL_MASKS = 1u << 4,
+    /* REMAP_MODE_MASKED on a field of several batches, a HINT (ABI 25): the
+     * mask is expected to be the same in every batch -- a (Time, nCells,
+     * nVertLevels) ocean variable is missing below the sea floor at every
+     * time.  The reference sums the normaliser `A . [not isnan X]` for every
+     * column of every time slice (remap_numpy.py:265); on mappings scheduled
+     * as 8-row groups a wave then takes four time slices of a level per lane
+     * and keeps ONE normaliser for them (csrc/spmm_grouptime.h).  Groups
+     * where the expectation fails are redone with per-element normalisers
+     * inside the same launch: same bits with or without the flag, whatever
+     * the data.  Needs n_batch >= 3; ignored elsewhere.  The device-side
+     * scan remap_scan_nan_layout() tells whether it holds. */
+    REMAP_FLAG_BATCH_MASKS = 1u << 5
 };
 
 /* CSR weight matrix of shape (n_rows, n_cols) = (n_b, n_a), or a row shard of
@@ -355,7 +367,8 @@ typedef struct remap_apply_args {
      *         strides; spmm_grouproll.h: measured, not chosen); 9: keep the
      *         per-lane masked form under REMAP_FLAG_CELL_MASKS; 32: the
      *         shared form (share_* below; tune[2] = K tiles per wave, 1 or
-     *         2; tune[3] = LDS reads ahead of the sums, 1 ... 4)
+     *         2; tune[1] = 10 * union entries per step + ring buffers: 82,
+     *         the default, or 83 / 43 / 44)
      * tune[6..7] reserved, must be 0 (a -DREMAP_DIAG build of the library,
      *         tools/build_diag.py, reads bottleneck-analysis switches from
      *         them; this build rejects them) */
@@ -549,7 +562,8 @@ REMAP_API int remap_patches_build(const remap_csr *A, const int64_t *grid_dims,
  *   family  0: nothing to attach (no destination grid, empty matrix, or no
  *              source-row sharing to exploit)
  *           5: LDS patches   -> row_order, patch_*   (bilinear, coarse->fine)
- *          10: row groups    -> row_order, group_*   (conservative maps)
+ *          10: row groups    -> row_order, group_*   (conservative maps;
+ *              entry-rich ones -- 2nd-order stencils -- also share_*)
  *           6: plain kernels in a tiled processing order -> row_order only
  *   tune[mode]: what to pass as remap_apply_args.tune for REMAP_MODE_<mode>,
  *              together with REMAP_FLAG_TUNE_HINT (a call the family cannot
@@ -587,6 +601,14 @@ typedef struct remap_schedule {
     int64_t n_distinct;          /* distinct pairs (5), union entries (10)   */
     int32_t tune[3][8];
     size_t arena_used;           /* bytes of the arena the schedule occupies */
+    /* (ABI 25) entry-rich row groups: the shared union lists of the shared
+     * form, remap_apply_args.share_* (NULL / 0 otherwise)                  */
+    const int64_t *share_meta;
+    const int32_t *share_col;
+    const int32_t *share_mask;
+    int32_t share_waves;
+    int32_t share_reserved;
+    int64_t n_share_union;       /* union entries of the supergroups        */
 } remap_schedule;
 
 REMAP_API
@@ -701,12 +723,14 @@ int remap_plan_apply(const remap_plan *plan, const remap_field *field,
  * the field for NaNs on the device and enqueue the masked, renormalised
  * branch (threshold = field->threshold) and the frac_b branch, each gated on
  * what the scan finds -- nothing synchronises, nothing is allocated, the
- * sequence is hipGraph-capturable.  `field->X` must be ONE contiguous buffer
- * of `x_elems` elements (what is scanned); `field->mode` and `field->gate` are
- * ignored; `kinds` is a device int32[2] the call zeroes and fills (see
- * remap_scan_nan_kinds).  On a mapping scheduled as 8-row groups the masked
- * branch is enqueued in both of its forms (REMAP_FLAG_CELL_MASKS): three
- * gated launches instead of two.
+ * sequence is hipGraph-capturable.  What is scanned is what the call reads:
+ * the n_a cells x n_batch x k_inner values the field's strides address
+ * (`x_elems` is kept for callers of ABI 24 and only checked for sign);
+ * `field->mode` and `field->gate` are ignored; `kinds` is a device int32[4]
+ * (ABI 25: two more words) the call zeroes and fills (see
+ * remap_scan_nan_layout).  On a mapping scheduled as 8-row groups the masked
+ * branch is enqueued in each of its forms (REMAP_FLAG_CELL_MASKS,
+ * REMAP_FLAG_BATCH_MASKS, neither): four gated launches instead of two.
  */
 REMAP_API
 int remap_plan_apply_auto(const remap_plan *plan, const remap_field *field,
@@ -735,6 +759,32 @@ int remap_scan_nan(const void *x, int32_t x_dtype, int64_t n, int32_t *flag,
  */
 REMAP_API int remap_scan_nan_kinds(const void *x, int32_t x_dtype, int64_t n,
                          int32_t *kinds, void *stream);
+
+/*
+ * The scan with the field's LAYOUT (ABI 25; device int32[4], zeroed by the
+ * caller): source cell a's k_inner values of batch b lie at x[b *
+ * x_batch_stride + a * x_row_stride + k], as in remap_apply_args.  What is
+ * missing is judged per source cell and per batch -- where the cells and the
+ * batches are, not in aligned runs of memory, which a (Time, nCells,
+ * nVertLevels) field with land cells reads as "column by column":
+ *   kinds[0]  1 if the field holds a NaN
+ *   kinds[1]  0 no NaN; 1 every cell is missing in ALL of its n_batch *
+ *             k_inner columns or in none (land: what REMAP_FLAG_CELL_MASKS
+ *             expects); 3 otherwise
+ *   kinds[2]  0 no NaN; 1 every batch has the mask of batch 0 (bathymetry:
+ *             what REMAP_FLAG_BATCH_MASKS expects); 3 otherwise
+ *   kinds[3]  the launch that suits: 0 none (FRACB), 1 MASKED with
+ *             REMAP_FLAG_CELL_MASKS, 2 MASKED with REMAP_FLAG_BATCH_MASKS
+ *             (n_batch >= 3 only), 3 MASKED without either
+ * Four calls gated on kinds[3] == 0 / 1 / 2 / 3 then cover
+ * remap_numpy.py:201-204 on an entry-rich mapping without a host round
+ * trip.  Hints only: results never depend on them.  Asynchronous on
+ * `stream`; kinds[3] is written by a second small launch behind the scan.
+ */
+REMAP_API int remap_scan_nan_layout(const void *x, int32_t x_dtype,
+                          int64_t n_rows, int64_t n_batch, int64_t k_inner,
+                          int64_t x_row_stride, int64_t x_batch_stride,
+                          int32_t *kinds, void *stream);
 
 /*
  * The two device steps of a ROW SHARD's exchange (no counterpart in the

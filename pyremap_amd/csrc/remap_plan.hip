@@ -140,6 +140,15 @@ int to_device(Owned &own, const T *src, int64_t n, bool on_host,
 
 // one wave per destination row: its entries from row rows[d] (or d) of the
 // source CSR
+// kinds[0 .. n) = 0 (remap_plan_apply_auto).  A kernel, not hipMemsetAsync:
+// a 16-byte memset captured into a hipGraph replayed as garbage on ROCm 7.2
+// (the 8-byte one of ABI 24 did not); this is four stores in any case.
+__global__ void zero_words_kernel(int32_t *__restrict__ w, int n)
+{
+    if (static_cast<int>(threadIdx.x) < n)
+        w[threadIdx.x] = 0;
+}
+
 __global__ __launch_bounds__(256) void copy_rows_kernel(
     const int64_t *__restrict__ src_rowptr, const int32_t *__restrict__ rows,
     const int64_t n_dst, const int64_t *__restrict__ dst_rowptr,
@@ -1060,6 +1069,10 @@ int remap_plan_apply(const remap_plan *plan, const remap_field *f,
         a.group_frac = s.group_frac;
         a.n_groups = s.n_groups;
         a.group_rows = s.group_rows;
+        a.share_meta = s.share_meta;
+        a.share_col = s.share_col;
+        a.share_mask = s.share_mask;
+        a.share_waves = s.share_waves;
         for (int t = 0; t < 8; ++t)
             a.tune[t] = s.tune[f->mode][t];
         a.flags |= REMAP_FLAG_TUNE_HINT;
@@ -1144,28 +1157,41 @@ int remap_plan_apply_auto(const remap_plan *plan, const remap_field *f,
         return remap::fail(REMAP_ERR_ARG,
                            "remap_plan_apply_auto: bad argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    REMAP_HIP_CHECK(hipMemsetAsync(kinds, 0, 2 * sizeof(int32_t), s));
-    int rc = remap_scan_nan_kinds(f->X, f->x_dtype, x_elems, kinds, stream);
+    hipLaunchKernelGGL(remap::zero_words_kernel, dim3(1), dim3(64), 0, s,
+                       kinds, 4);
+    REMAP_HIP_CHECK(hipGetLastError());
+    int rc = remap_scan_nan_layout(f->X, f->x_dtype, plan->n_a, f->n_batch,
+                                   f->k_inner, f->x_row_stride,
+                                   f->x_batch_stride, kinds, stream);
     if (rc != REMAP_OK)
         return rc;
     remap_field g = *f;
+    const uint32_t hints = REMAP_FLAG_CELL_MASKS | REMAP_FLAG_BATCH_MASKS;
     // the masked branch (remap_numpy.py:262-266) ...
     g.mode = REMAP_MODE_MASKED;
-    const bool two_forms =
+    const bool forms =
         plan->sched.family == 10 && plan->sched.group_rows == 8;
-    if (two_forms) {
-        // ... per-row normalisers where the NaNs fill whole cells, per-lane
-        // ones where they do not
-        g.gate = kinds + 1;
+    if (forms) {
+        // ... per-row normalisers where whole cells are missing, one per
+        // lane and row where the mask is the same in every batch, per
+        // element otherwise: kinds[3] names the form
+        g.gate = kinds + 3;
         g.gate_value = 1;
-        g.flags = f->flags | REMAP_FLAG_CELL_MASKS;
+        g.flags = (f->flags & ~hints) | REMAP_FLAG_CELL_MASKS;
         if ((rc = remap_plan_apply(plan, &g, stream)) != REMAP_OK)
             return rc;
+        if (f->n_batch >= 3) {
+            g.gate_value = 2;
+            g.flags = (f->flags & ~hints) | REMAP_FLAG_BATCH_MASKS;
+            if ((rc = remap_plan_apply(plan, &g, stream)) != REMAP_OK)
+                return rc;
+        }
         g.gate_value = 3;
-        g.flags = f->flags & ~static_cast<uint32_t>(REMAP_FLAG_CELL_MASKS);
+        g.flags = f->flags & ~hints;
     } else {
         g.gate = kinds;
         g.gate_value = 1;
+        g.flags = f->flags & ~hints;
     }
     if ((rc = remap_plan_apply(plan, &g, stream)) != REMAP_OK)
         return rc;
@@ -1173,7 +1199,7 @@ int remap_plan_apply_auto(const remap_plan *plan, const remap_field *f,
     g.mode = REMAP_MODE_FRACB;
     g.gate = kinds;
     g.gate_value = 0;
-    g.flags = f->flags & ~static_cast<uint32_t>(REMAP_FLAG_CELL_MASKS);
+    g.flags = f->flags & ~hints;
     return remap_plan_apply(plan, &g, stream);
 }
 

@@ -901,9 +901,13 @@ size_t arena_need(int64_t n_rows, int64_t nnz)
                          align_g((nr + 1) * 4) + align_g(ne * 4) +
                          align_g(ne * 8);
     const size_t n_groups = nr / 4 + 2;
+    const size_t n_super = nr / 32 + 2;
     const size_t group = align_g(2 * (n_groups + 1) * 8) +
                          2 * align_g((ne + 32) * 4) + align_g((ne + 128) * 8) +
-                         align_g(n_groups * 8 * 4) + align_g(n_groups * 8 * 8);
+                         align_g(n_groups * 8 * 4) + align_g(n_groups * 8 * 8) +
+                         // the shared lists of entry-rich mappings
+                         align_g(2 * (n_super + 1) * 8) +
+                         2 * align_g((ne + 256) * 4);
     return order + (patch > group ? patch : group) + align_g(64);
 }
 
@@ -1076,7 +1080,10 @@ int schedule_auto(const remap_csr *A, const double *frac_b,
         if (!gfrac)
             return fail(REMAP_ERR_WORKSPACE,
                         "remap_schedule_auto: arena too small");
-        rc = groups_build(A, frac_b, G, dims2, row_offset, st, 0,
+        // entry-rich: the group tiles nested in 4 x 8 tiles, the
+        // supergroups of the shared form (spmm_groupshare.h)
+        const int share = entry_rich ? 4 : 0;
+        rc = groups_build(A, frac_b, G, dims2, row_offset, st, share,
                           two_d ? order : nullptr, meta, gcol, gmask, gw, rid,
                           gfrac, stats, workspace, workspace_bytes, stream);
         if (rc != REMAP_OK)
@@ -1086,6 +1093,27 @@ int schedule_auto(const remap_csr *A, const double *frac_b,
         if (rc != REMAP_OK)
             return rc;
         const double ratio = static_cast<double>(n_union) / nnz;
+        int64_t *smeta = nullptr;
+        int32_t *scol = nullptr, *smask = nullptr;
+        int64_t n_share = 0;
+        if (share && ratio <= kAutoGroupRatio) {
+            // (the union arrays above stay as they are: the arena was sized
+            // for both)
+            const int64_t n_super = (n_rows + 8 * share - 1) / (8 * share);
+            smeta = arena.take<int64_t>(2 * (n_super + 1));
+            scol = arena.take<int32_t>(nnz + 256);
+            smask = arena.take<int32_t>(nnz + 256);
+            if (!smask)
+                return fail(REMAP_ERR_WORKSPACE,
+                            "remap_schedule_auto: arena too small");
+            rc = share_build(A, rid, share, smeta, scol, smask, stats + 1,
+                             workspace, workspace_bytes, stream);
+            if (rc != REMAP_OK)
+                return rc;
+            rc = read_back(&n_share, stats + 1, sizeof(int64_t), stream);
+            if (rc != REMAP_OK)
+                return rc;
+        }
         if (ratio <= kAutoGroupRatio) {
             out->family = 10;
             out->row_order = two_d ? order : nullptr;
@@ -1101,16 +1129,30 @@ int schedule_auto(const remap_csr *A, const double *frac_b,
             out->ratio = ratio;
             out->n_distinct = n_union;
             out->arena_used = arena.used;
+            out->share_meta = smeta;
+            out->share_col = scol;
+            out->share_mask = smask;
+            out->share_waves = smask ? share : 0;
+            out->n_share_union = n_share;
             for (int mode = 0; mode < 3; ++mode) {
                 // entry-rich: single-wave workgroups, one group each, the
                 // K-chunks of a group side by side in the work list (its
                 // schedule is fetched once per XCD: config 5 22.5 -> 22.0
-                // ms, masked 27.9 -> 26.7)
-                if (entry_rich)
+                // ms, masked 27.9 -> 26.7); round 6: the frac_b and raw
+                // modes in the shared form -- four waves, one union through
+                // an LDS ring (config 5 21.0 -> 19.7 ms on one box; a call
+                // it cannot serve takes the 8-row groups as before)
+                if (entry_rich) {
                     set_tune(out, mode, 10, 1,
                              mode == REMAP_MODE_MASKED ? 1 : 2, 1, 3);
-                else
+                    if (mode != REMAP_MODE_MASKED && smask) {
+                        out->tune[mode][1] = 0;
+                        out->tune[mode][3] = 0;
+                        out->tune[mode][5] = 32;
+                    }
+                } else {
                     set_tune(out, mode, 10, 0, 0, 1);
+                }
             }
             return REMAP_OK;
         }

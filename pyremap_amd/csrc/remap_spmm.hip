@@ -65,6 +65,8 @@ namespace {
 #include "spmm_grouproll.h"
 #include "spmm_groupmask.h"
 #include "spmm_groupshare.h"
+#include "spmm_grouptime.h"
+#include "spmm_timeshare.h"
 #include "spmm_rowlane.h"
 #include "spmm_rowcell.h"
 #include "spmm_patchcell.h"
@@ -603,53 +605,107 @@ int launch_rowgroup(const remap_apply_args *a, const KParams &p, int tiles,
     return REMAP_OK;
 }
 
+// REMAP_FLAG_BATCH_MASKS, masked mode on 8-row groups: time-major columns,
+// one normaliser per lane and row (spmm_grouptime.h)
+template <typename XT>
+int launch_grouptime(const remap_apply_args *a, const KParams &p, int wpb,
+                     bool fma, int64_t grid, hipStream_t stream)
+{
+    typename GroupFn<XT>::type fn = fma ? spmm_grouptime<XT, true, 8, 8, 4>
+                                        : spmm_grouptime<XT, false, 8, 8, 4>;
+    hipLaunchKernelGGL(fn, dim3(static_cast<uint32_t>(grid)),
+                       dim3(kWave * wpb), 0, stream, p, a->flags,
+                       a->group_meta, a->group_col, a->group_w, a->group_mask,
+                       a->group_rid, a->group_frac,
+                       static_cast<const XT *>(a->X));
+    REMAP_HIP_CHECK(hipGetLastError());
+    return REMAP_OK;
+}
+
+// ... and through the LDS ring of the shared form where the mapping has the
+// shared lists (spmm_timeshare.h): float64 fields in whole 16-byte pieces
+int launch_timeshare(const remap_apply_args *a, const KParams &p, bool fma,
+                     int64_t grid, hipStream_t stream)
+{
+    void (*fn)(const KParams, const uint32_t, const int64_t *,
+               const int32_t *, const double *, const int32_t *,
+               const int32_t *, const int64_t *, const int32_t *,
+               const int32_t *, const double *) =
+        fma ? spmm_timeshare<true, 2> : spmm_timeshare<false, 2>;
+    // the ring: two buffers of 8 entries x (4 slices x 512 B); 2 x 4 slots
+    // of a step's weights; slack
+    uint32_t lds_bytes = 2u * (8u * 2048u + 4u * 512u) + 512u;
+    REMAP_HIP_CHECK(diag_lds_throttle(a, reinterpret_cast<const void *>(fn),
+                                      lds_bytes));
+    hipLaunchKernelGGL(fn, dim3(static_cast<uint32_t>(grid)), dim3(kWave * 4),
+                       lds_bytes, stream, p, a->flags, a->group_meta,
+                       a->group_col, a->group_w, a->group_mask, a->group_rid,
+                       a->share_meta, a->share_col, a->share_mask,
+                       static_cast<const double *>(a->X));
+    REMAP_HIP_CHECK(hipGetLastError());
+    return REMAP_OK;
+}
+
 // the shared form (spmm_groupshare.h): float64, two elements per lane
 typedef void (*share_fn)(const KParams, const uint32_t, const int64_t *,
                          const double *, const int32_t *, const double *,
                          const int64_t *, const int32_t *, const int32_t *,
                          const double *);
 
-template <int TILES, int W, int AHEAD>
-share_fn pick_groupshare_mode(int mode, bool fma)
+template <int TILES, int W, int UNR, int NBUF, bool FMA>
+share_fn pick_groupshare_mode(int mode)
 {
     switch (mode) {
     case REMAP_MODE_RAW:
-        return fma ? spmm_groupshare<TILES, REMAP_MODE_RAW, true, W, 8, AHEAD>
-                   : spmm_groupshare<TILES, REMAP_MODE_RAW, false, W, 8,
-                                     AHEAD>;
+        return spmm_groupshare<TILES, REMAP_MODE_RAW, FMA, W, UNR, NBUF, 2>;
     case REMAP_MODE_FRACB:
-        return fma ? spmm_groupshare<TILES, REMAP_MODE_FRACB, true, W, 8,
-                                     AHEAD>
-                   : spmm_groupshare<TILES, REMAP_MODE_FRACB, false, W, 8,
-                                     AHEAD>;
+        return spmm_groupshare<TILES, REMAP_MODE_FRACB, FMA, W, UNR, NBUF, 2>;
     default:
-        return fma ? spmm_groupshare<TILES, REMAP_MODE_MASKED, true, W, 8,
-                                     AHEAD>
-                   : spmm_groupshare<TILES, REMAP_MODE_MASKED, false, W, 8,
-                                     AHEAD>;
+        return spmm_groupshare<TILES, REMAP_MODE_MASKED, FMA, W, UNR, NBUF,
+                               2>;
     }
 }
 
-template <int W>
-share_fn pick_groupshare(int tiles, int ahead, int mode, bool fma)
+// ring shapes (entries per step, buffers): 8 x 2 is the default; the others
+// exist for the 4-wave form without REMAP_FLAG_FMA (A/B material)
+template <int TILES>
+share_fn pick_groupshare(int W, int unr, int nbuf, int mode, bool fma)
 {
-    if (tiles == 1)
-        return ahead == 1   ? pick_groupshare_mode<1, W, 1>(mode, fma)
-               : ahead == 3 ? pick_groupshare_mode<1, W, 3>(mode, fma)
-                            : pick_groupshare_mode<1, W, 2>(mode, fma);
-    return ahead == 1   ? pick_groupshare_mode<2, W, 1>(mode, fma)
-           : ahead == 3 ? pick_groupshare_mode<2, W, 3>(mode, fma)
-                        : pick_groupshare_mode<2, W, 2>(mode, fma);
+    if (W == 2)
+        return fma ? pick_groupshare_mode<TILES, 2, 8, 2, true>(mode)
+                   : pick_groupshare_mode<TILES, 2, 8, 2, false>(mode);
+    if (fma)
+        return pick_groupshare_mode<TILES, 4, 8, 2, true>(mode);
+    if (unr == 8 && nbuf == 3)
+        return pick_groupshare_mode<TILES, 4, 8, 3, false>(mode);
+    if (unr == 4 && nbuf == 3)
+        return pick_groupshare_mode<TILES, 4, 4, 3, false>(mode);
+    if (unr == 4 && nbuf == 4)
+        return pick_groupshare_mode<TILES, 4, 4, 4, false>(mode);
+    return pick_groupshare_mode<TILES, 4, 8, 2, false>(mode);
 }
 
 int launch_groupshare(const remap_apply_args *a, const KParams &p, int tiles,
-                      int ahead, bool fma, int64_t grid, hipStream_t stream)
+                      int unr, int nbuf, bool fma, int64_t grid,
+                      hipStream_t stream)
 {
     const int W = a->share_waves;
-    share_fn fn = W == 4 ? pick_groupshare<4>(tiles, ahead, a->mode, fma)
-                         : pick_groupshare<2>(tiles, ahead, a->mode, fma);
-    // the ring: two buffers of 8 entries, 1 KiB per entry and K tile
-    uint32_t lds_bytes = 2u * 8u * 1024u * static_cast<uint32_t>(tiles);
+    if (W == 2 || fma) {   // (the shapes these forms are built in)
+        unr = 8;
+        nbuf = 2;
+    }
+    share_fn fn = tiles == 1
+                      ? pick_groupshare<1>(W, unr, nbuf, a->mode, fma)
+                      : pick_groupshare<2>(W, unr, nbuf, a->mode, fma);
+    // the ring: nbuf buffers of unr entries, 1 KiB per entry and K tile;
+    // nbuf x W slots of a step's weights; slack for the lanes that read
+    // past the last slot
+    uint32_t lds_bytes =
+        static_cast<uint32_t>(nbuf) *
+            (static_cast<uint32_t>(unr) * 1024u *
+                 static_cast<uint32_t>(tiles) +
+             static_cast<uint32_t>(W) * static_cast<uint32_t>(unr) * 64u) +
+        512u;
     REMAP_HIP_CHECK(diag_lds_throttle(a, reinterpret_cast<const void *>(fn),
                                       lds_bytes));
     hipLaunchKernelGGL(fn, dim3(static_cast<uint32_t>(grid)),
@@ -1040,15 +1096,21 @@ int run_rowgroup(const remap_apply_args *a, const Call &c, KParams p,
     // error otherwise).
     if (a->tune[5] == 32) {
         const bool can = c.share_ok && c.dma16 && c.K > 128 &&
-                         a->x_src_fold == 0;
+                         a->x_src_fold == 0 && a->x_row_stride >= 0 &&
+                         a->x_row_stride < (int64_t(1) << 29);
         if (can) {
             // K tiles per wave: 2 (256 columns per workgroup and step; the
             // masked mode's per-lane normalisers leave room for one)
             int tiles = a->tune[2];
             if (tiles != 1 && tiles != 2)
                 tiles = a->mode == REMAP_MODE_MASKED ? 1 : 2;
-            const int ahead =
-                (a->tune[3] >= 1 && a->tune[3] <= 3) ? a->tune[3] : 2;
+            // ring shape, tune[1] = 10 * entries per step + buffers: 82
+            // (the default), 83, 43, 44
+            const int unr = a->tune[1] / 10 == 4 ? 4 : 8;
+            const int nbuf = (a->tune[1] % 10 >= 2 && a->tune[1] % 10 <= 4 &&
+                              a->tune[1] >= 40)
+                                 ? a->tune[1] % 10
+                                 : 2;
             p.rows_per_wave = 1;
             const int64_t k_chunks =
                 shape_tiles(p, a, c.K, kWave * 2, tiles);
@@ -1061,7 +1123,7 @@ int run_rowgroup(const remap_apply_args *a, const Call &c, KParams p,
                 return rc;
             if (a->tune[4] == 3)
                 p.xcd_map |= 2;
-            return launch_groupshare(a, p, tiles, ahead, c.fma, grid,
+            return launch_groupshare(a, p, tiles, unr, nbuf, c.fma, grid,
                                      stream);
         }
         if (!(a->flags & REMAP_FLAG_TUNE_HINT))
@@ -1069,6 +1131,46 @@ int run_rowgroup(const remap_apply_args *a, const Call &c, KParams p,
                         "remap_apply_f64: the shared form (tune[5] = 32) "
                         "serves float64 fields of more than 128 even-strided "
                         "columns on a plan with share_* lists");
+    }
+    // REMAP_FLAG_BATCH_MASKS: the masked mode of a field of several batches
+    // whose mask is expected not to change from batch to batch -- (Time,
+    // nCells, nVertLevels) cut by bathymetry -- on 8-row groups: lanes
+    // across the levels, four time slices per lane, one normaliser per lane
+    // and row (spmm_grouptime.h).  A hint: a group that meets anything else
+    // takes the general form inside the same launch.
+    if ((a->flags & REMAP_FLAG_BATCH_MASKS) && a->mode == REMAP_MODE_MASKED &&
+        a->group_rows == 8 && a->n_batch >= 3 && a->x_src_fold == 0 &&
+        (a->tune[5] == 0 || a->tune[5] == 32 || a->tune[5] == 9)) {
+        const int wpb = a->tune[1] == 4 ? 4 : a->tune[1] == 2 ? 2 : 1;
+        p.rows_per_wave = a->tune[3] > 0 && a->tune[5] != 32 ? a->tune[3] : 1;
+        p.bpc = 0;
+        const int64_t n_lb = ceil_div(a->k_inner, kWave);
+        const int64_t n_tb = ceil_div(a->n_batch, kTimeBlock);
+        int64_t grid;
+        // with the shared lists: one union per 4 x 8 tile through the LDS
+        // ring (spmm_timeshare.h; tune[5] = 9 keeps the form below)
+        if (c.share_ok && a->share_waves == 4 && c.dma16 &&
+            a->tune[5] != 9 && a->x_row_stride >= 0 &&
+            a->x_row_stride < (int64_t(1) << 29)) {
+            p.rows_per_wave = 1;
+            const int rc = shape_grid(p, ceil_div(a->n_groups, (int64_t)4),
+                                      n_lb * n_tb, a->tune[4] != 1, grid);
+            if (rc != REMAP_OK)
+                return rc;
+            if (a->tune[4] == 3)
+                p.xcd_map |= 2;
+            return launch_timeshare(a, p, c.fma, grid, stream);
+        }
+        const int rc = shape_grid(
+            p, ceil_div(a->n_groups, (int64_t)wpb * p.rows_per_wave),
+            n_lb * n_tb, a->tune[4] != 1, grid);
+        if (rc != REMAP_OK)
+            return rc;
+        if (a->tune[4] == 3)
+            p.xcd_map |= 2;
+        return c.f32 ? launch_grouptime<float>(a, p, wpb, c.fma, grid, stream)
+                     : launch_grouptime<double>(a, p, wpb, c.fma, grid,
+                                                stream);
     }
     // f32 rows are half as long: two K tiles per wave keep the bytes per
     // wave and row at 1 KiB (measured +7 % on config 3 with f32 fields).
@@ -1103,13 +1205,15 @@ int run_rowgroup(const remap_apply_args *a, const Call &c, KParams p,
         return fail(REMAP_ERR_UNSUPPORTED,
                     "remap_apply_f64: 16-row groups serve float64 fields of "
                     "more than 64 even-strided columns");
-    // groups per wave (the shared form reads tune[3] differently)
-    int gpw = (a->tune[3] > 0 && a->tune[5] != 32) ? a->tune[3] : 2;
+    // groups per wave (a call the shared form declined: the shape the
+    // entry-rich groups run in, one group per single-wave workgroup)
+    int gpw = a->tune[5] == 32 ? 1 : a->tune[3] > 0 ? a->tune[3] : 2;
     // union entries in flight
     int unr = (a->tune[5] == 4 || a->tune[5] == 16) ? a->tune[5] : 8;
     // waves per workgroup (tune[1], unused otherwise by this family)
-    int wpb = (a->tune[1] == 1 || a->tune[1] == 2) ? a->tune[1]
-                                                   : kWavesPerBlock;
+    int wpb = a->tune[5] == 32 ? 1
+              : (a->tune[1] == 1 || a->tune[1] == 2) ? a->tune[1]
+                                                     : kWavesPerBlock;
     // tune[5] >= 100 (diagnostic build): the lock-step experiment
     // (step-aligned lists: see spmm_rowgroup.h); the workgroup is one
     // supergroup of tune[1] groups
@@ -1895,6 +1999,121 @@ int scan_nan(const void *x, int32_t dtype, int64_t n, int32_t *flag,
     return REMAP_OK;
 }
 
+// ---------------------------------------------------------------------------
+// The same scan, aware of the field's LAYOUT (round 6): what is missing is
+// judged per source cell and per batch, where the cells and batches are --
+// not in aligned runs of the flat buffer, which a (Time, nCells, nVertLevels)
+// field with land cells reads as "column by column".  One wave per source
+// cell, lanes across its k_inner contiguous values, batch after batch.
+// ---------------------------------------------------------------------------
+namespace {
+template <typename T>
+__global__ __launch_bounds__(kBlock) void scan_layout_kernel(
+    const T *__restrict__ x, int64_t n_rows, int64_t n_batch, int64_t k_inner,
+    int64_t rs, int64_t bs, int32_t *__restrict__ kinds)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t wave0 =
+        ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const int64_t n_waves = (int64_t)gridDim.x * (kBlock / kWave);
+    bool found = false;   // a NaN
+    bool part = false;    // a cell missing in some of its columns only
+    bool vary = false;    // a (cell, k) missing in some batches only
+    for (int64_t a = wave0; a < n_rows; a += n_waves) {
+        bool any_c = false, all_c = true;
+        const T *__restrict__ xa = x + a * rs;
+        for (int64_t k0 = 0; k0 < k_inner; k0 += kWave) {
+            const int64_t k = k0 + lane;
+            const bool on = k < k_inner;
+            const T *__restrict__ xk = xa + (on ? k : 0);
+            bool first = false;
+            int64_t b = 0;
+            for (; b + 4 <= n_batch; b += 4) {   // four loads in flight
+                T v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    v[q] = __builtin_nontemporal_load(xk + (b + q) * bs);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool m = on && (v[q] != v[q]);
+                    if (b + q == 0)
+                        first = m;
+                    vary |= (m != first);
+                    any_c |= m;
+                    all_c &= (m || !on);
+                }
+            }
+            for (; b < n_batch; ++b) {
+                const T t = __builtin_nontemporal_load(xk + b * bs);
+                const bool m = on && (t != t);
+                if (b == 0)
+                    first = m;
+                vary |= (m != first);
+                any_c |= m;
+                all_c &= (m || !on);
+            }
+        }
+        if (__any(any_c)) {
+            found = true;
+            if (__any(!all_c))
+                part = true;
+        }
+    }
+    const bool v = __any(vary);
+    if (found && lane == 0) {
+        atomicOr(kinds, 1);
+        atomicOr(kinds + 1, part ? 3 : 1);
+        atomicOr(kinds + 2, v ? 3 : 1);
+    }
+}
+
+// kinds[3]: which launch the field gets (0 no NaN; 1 whole cells missing; 2
+// the same mask in every batch; 3 anything else)
+__global__ void scan_layout_form(int32_t *__restrict__ kinds, int multi)
+{
+    kinds[3] = kinds[0] == 0   ? 0
+               : kinds[1] == 1 ? 1
+               : (multi && kinds[2] == 1) ? 2
+                                          : 3;
+}
+}  // namespace
+
+int scan_nan_layout(const void *x, int32_t dtype, int64_t n_rows,
+                    int64_t n_batch, int64_t k_inner, int64_t rs, int64_t bs,
+                    int32_t *kinds, hipStream_t stream)
+{
+    if (n_rows < 0 || n_batch < 0 || k_inner < 0 || rs < 0 || bs < 0 ||
+        !kinds || (n_rows > 0 && n_batch > 0 && k_inner > 0 && !x))
+        return fail(REMAP_ERR_ARG, "remap_scan_nan_layout: bad argument");
+    if (dtype != REMAP_DTYPE_F64 && dtype != REMAP_DTYPE_F32)
+        return fail(REMAP_ERR_ARG, "remap_scan_nan_layout: unknown dtype %d",
+                    dtype);
+    if (x && !aligned(x, dtype == REMAP_DTYPE_F64 ? 8 : 4))
+        return fail(REMAP_ERR_ARG,
+                    "remap_scan_nan_layout: the buffer is not "
+                    "element-aligned");
+    if (n_rows > 0 && n_batch > 0 && k_inner > 0) {
+        int64_t grid = (n_rows + kBlock / kWave - 1) / (kBlock / kWave);
+        if (grid > 256 * 64)
+            grid = 256 * 64;
+        if (dtype == REMAP_DTYPE_F64)
+            hipLaunchKernelGGL(scan_layout_kernel<double>,
+                               dim3((uint32_t)grid), dim3(kBlock), 0, stream,
+                               static_cast<const double *>(x), n_rows,
+                               n_batch, k_inner, rs, bs, kinds);
+        else
+            hipLaunchKernelGGL(scan_layout_kernel<float>,
+                               dim3((uint32_t)grid), dim3(kBlock), 0, stream,
+                               static_cast<const float *>(x), n_rows, n_batch,
+                               k_inner, rs, bs, kinds);
+        REMAP_HIP_CHECK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(scan_layout_form, dim3(1), dim3(1), 0, stream, kinds,
+                       n_batch >= 3 ? 1 : 0);
+    REMAP_HIP_CHECK(hipGetLastError());
+    return REMAP_OK;
+}
+
 // one wave: shader cycles and 100 MHz ticks across a spin of `ticks` ticks
 __global__ __launch_bounds__(kWave) void clock_probe_kernel(
     long long *__restrict__ out, long long ticks)
@@ -1985,6 +2204,16 @@ int remap_scan_nan_kinds(const void *x, int32_t x_dtype, int64_t n,
 {
     return remap::scan_nan(x, x_dtype, n, kinds,
                            static_cast<hipStream_t>(stream), true);
+}
+
+int remap_scan_nan_layout(const void *x, int32_t x_dtype, int64_t n_rows,
+                          int64_t n_batch, int64_t k_inner,
+                          int64_t x_row_stride, int64_t x_batch_stride,
+                          int32_t *kinds, void *stream)
+{
+    return remap::scan_nan_layout(x, x_dtype, n_rows, n_batch, k_inner,
+                                  x_row_stride, x_batch_stride, kinds,
+                                  static_cast<hipStream_t>(stream));
 }
 
 int remap_stream_copy(void *dst, const void *src, size_t bytes, void *stream)

@@ -226,46 +226,162 @@ __device__ __forceinline__ void accumulate_entries(
     }
 }
 
+// One store of a row's VEC results of tile t (and of their mask bytes).
+template <int VEC>
+__device__ __forceinline__ void store_row_tile(const KParams &p, int64_t o,
+                                               const double (&y)[VEC],
+                                               const bool (&ok)[VEC])
+{
+    if (REMAP_DIAG_SKIP_STORE(p, y[0]))
+        return;
+    store_y<VEC>(p.Y + o, y);
+#ifndef REMAP_STAMPS
+    if (p.mask_out) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v)
+            p.mask_out[o + v] = ok[v] ? 0 : 1;
+    }
+#endif
+}
+
+// acc / fb for a WAVE-UNIFORM fb (the frac_b mode: one row, one frac_b per
+// wave).  `acc / fb` as hipcc expands it is 11 VALU instructions per element
+// -- v_div_scale x 2, v_rcp_f64 (quarter rate), four FMAs refining the
+// reciprocal, v_mul, v_fma, v_div_fmas, v_div_fixup -- a quarter of the
+// row-group kernels' whole VALU stream on entry-rich mappings (config 5: 32
+// elements per wave).  For ordinary operands the two v_div_scale return their
+// inputs unchanged with VCC = 0, v_div_fmas is then a plain FMA and
+// v_div_fixup returns its first operand: what remains is
+//     y = rcp(fb), refined twice          -- depends on fb alone: ONCE per row
+//     q0 = a * y;  r = fma(-fb, q0, a);  q = fma(r, y, q0)   -- per element
+// the very instructions of the full sequence on the very values, hence the
+// same bits.  "Ordinary" (V_DIV_SCALE_F64's conditions for scaling nothing:
+// neither operand zero or denormal, exponent(a) - exponent(fb) < 768, 1 / fb
+// and a / fb no denormals, biased exponent(a) > 53; nothing for v_div_fixup
+// to repair): fb in [2^-126, 2^126], |a| in [2^-800, 2^600].  fb is tested on
+// the scalar side, the elements with three 32-bit VALU instructions each; one
+// lane outside (a zero, an Inf, a NaN, 1e-300) and the wave divides the row
+// the long way.
+constexpr uint32_t kDivLoHi = 223u << 20;     // biased exponent 223 = 2^-800
+constexpr uint32_t kDivSpanHi = (1624u - 223u) << 20;   // ... below 2^601
+
+__device__ __forceinline__ bool div_fast_divisor(double fb)
+{
+    const uint32_t eb = (static_cast<uint32_t>(__double2hiint(fb)) >> 20) &
+                        0x7ffu;
+    return eb >= 1023u - 126u && eb <= 1023u + 126u;   // (fb > 0 is known)
+}
+
+__device__ __forceinline__ bool div_fast_numerator(double a)
+{
+    const uint32_t h = static_cast<uint32_t>(__double2hiint(a)) & 0x7fffffffu;
+    return h - kDivLoHi < kDivSpanHi;
+}
+
+// One row divided by a WAVE-UNIFORM number (frac_b; the per-row normaliser of
+// spmm_groupmask): `okrow` says whether the row is kept (else NaN, masked).
+template <int VEC, int TILES>
+__device__ __forceinline__ void finish_row_uniform(
+    const KParams &p, int64_t i, double fb_in, bool okrow_in,
+    const bool (&act)[TILES], const int64_t (&yoff)[TILES],
+    const double (&acc)[TILES][VEC])
+{
+    // fb is wave-uniform (every caller: one row per wave): scalar
+    // branches, no selects -- left to itself hipcc computed the
+    // division, `fb == 1.0 ? acc : quotient` and the NaN fill for every
+    // lane and element and selected afterwards (15 VALU per element)
+    const double fb = __hiloint2double(
+        __builtin_amdgcn_readfirstlane(__double2hiint(fb_in)),
+        __builtin_amdgcn_readfirstlane(__double2loint(fb_in)));
+    const bool okrow = __builtin_amdgcn_readfirstlane(okrow_in ? 1 : 0) != 0;
+    // every lane computes (idle lanes of a K tail hold sums of columns
+    // that exist: nothing traps); ONE store site behind the three paths
+    double y[TILES][VEC];
+    if (!okrow) {
+#pragma unroll
+        for (int t = 0; t < TILES; ++t)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v)
+                y[t][v] = __builtin_nan("");
+    } else if (fb == 1.0) {
+        // x / 1.0 == x exactly: bilinear maps skip the division
+#pragma unroll
+        for (int t = 0; t < TILES; ++t)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v)
+                y[t][v] = acc[t][v];
+    } else {
+        bool fast = div_fast_divisor(fb);
+        if (fast) {
+            bool in = true;
+#pragma unroll
+            for (int t = 0; t < TILES; ++t)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v)
+                    in = in && div_fast_numerator(acc[t][v]);
+            fast = __ballot(!in) == 0ull;
+        }
+        if (fast) {
+            double r = __builtin_amdgcn_rcp(fb);
+            double e = __builtin_fma(-fb, r, 1.0);
+            r = __builtin_fma(r, e, r);
+            e = __builtin_fma(-fb, r, 1.0);
+            r = __builtin_fma(r, e, r);
+#pragma unroll
+            for (int t = 0; t < TILES; ++t)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    const double q0 = acc[t][v] * r;
+                    const double rem = __builtin_fma(-fb, q0, acc[t][v]);
+                    y[t][v] = __builtin_fma(rem, r, q0);
+                }
+        } else {
+#pragma unroll
+            for (int t = 0; t < TILES; ++t)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v)
+                    y[t][v] = acc[t][v] / fb;
+        }
+    }
+    bool ok[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v)
+        ok[v] = okrow;
+#pragma unroll
+    for (int t = 0; t < TILES; ++t)
+        if (act[t])
+            store_row_tile<VEC>(p, i * p.ldy + yoff[t], y[t], ok);
+}
+
 // Fused epilogue of one row: normalise, mask, store (remap_numpy.py:266-278).
 template <int VEC, int TILES, int MODE>
 __device__ __forceinline__ void finish_row(
-    const KParams &p, int64_t i, double fb, const bool (&act)[TILES],
+    const KParams &p, int64_t i, double fb_in, const bool (&act)[TILES],
     const int64_t (&yoff)[TILES], const double (&acc)[TILES][VEC],
     const double (&den)[TILES][VEC])
 {
+    if constexpr (MODE == REMAP_MODE_FRACB) {
+        finish_row_uniform<VEC, TILES>(p, i, fb_in, fb_in > 0.0, act, yoff,
+                                       acc);
+    } else {
 #pragma unroll
-    for (int t = 0; t < TILES; ++t) {
-        if (!act[t])
-            continue;
-        double y[VEC];
-        bool ok[VEC];
+        for (int t = 0; t < TILES; ++t) {
+            if (!act[t])
+                continue;
+            double y[VEC];
+            bool ok[VEC];
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-            if constexpr (MODE == REMAP_MODE_RAW) {
-                ok[v] = true;
-                y[v] = acc[t][v];
-            } else if constexpr (MODE == REMAP_MODE_FRACB) {
-                // x / 1.0 == x exactly: bilinear maps (frac_b == 1) skip
-                // the 11-instruction f64 division; fb is wave-uniform
-                ok[v] = fb > 0.0;
-                y[v] = !ok[v] ? __builtin_nan("")
-                       : (fb == 1.0) ? acc[t][v] : acc[t][v] / fb;
-            } else {
-                ok[v] = den[t][v] > p.thr;
-                y[v] = ok[v] ? acc[t][v] / den[t][v] : __builtin_nan("");
+            for (int v = 0; v < VEC; ++v) {
+                if constexpr (MODE == REMAP_MODE_RAW) {
+                    ok[v] = true;
+                    y[v] = acc[t][v];
+                } else {
+                    ok[v] = den[t][v] > p.thr;
+                    y[v] = ok[v] ? acc[t][v] / den[t][v] : __builtin_nan("");
+                }
             }
+            store_row_tile<VEC>(p, i * p.ldy + yoff[t], y, ok);
         }
-        const int64_t o = i * p.ldy + yoff[t];
-        if (REMAP_DIAG_SKIP_STORE(p, y[0]))
-            continue;
-        store_y<VEC>(p.Y + o, y);
-#ifndef REMAP_STAMPS
-        if (p.mask_out) {
-#pragma unroll
-            for (int v = 0; v < VEC; ++v)
-                p.mask_out[o + v] = ok[v] ? 0 : 1;
-        }
-#endif
     }
 }
 

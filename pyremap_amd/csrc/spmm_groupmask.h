@@ -26,7 +26,11 @@
 // same separate multiply and add: same bits.  (A cell missing in every
 // column adds `a * 0.0` to num and to den: nothing, for finite `a` -- skipped
 // behind a scalar test of the weight's exponent; a NaN or Inf weight sends
-// the group to the general form as well.)
+// the group to the general form as well.  One exception, under REMAP_FLAG_FMA
+// only, which is a tolerance mode anyway: there a sum can be -0.0 -- an
+// fma(a, x, +0.0) that underflows -- and adding the skipped `a * 0.0` would
+// turn it into +0.0; the sign of such a zero result may differ between the
+// two forms.  Without the flag sums start at +0.0 and never are -0.0.)
 // ---------------------------------------------------------------------------
 
 // one K tile of one group with per-lane normalisers (spmm_rowgroup's masked
@@ -285,14 +289,12 @@ __attribute__((amdgpu_waves_per_eu(3, 8))) void spmm_groupmask(
 #pragma unroll
                 for (int m = 0; m < G; ++m) {
                     if (m < nmem) {
-                        double den[TILES][VEC];
-#pragma unroll
-                        for (int t = 0; t < TILES; ++t)
-#pragma unroll
-                            for (int v = 0; v < VEC; ++v)
-                                den[t][v] = den_u[m];
-                        finish_row<VEC, TILES, REMAP_MODE_MASKED>(
-                            p, rid[m], 0.0, act, yoff, acc[m], den);
+                        // the row's normaliser is one number for the whole
+                        // wave: the frac_b mode's epilogue (one reciprocal
+                        // per row), `den > thr` in place of `frac_b > 0`
+                        finish_row_uniform<VEC, TILES>(
+                            p, rid[m], den_u[m], den_u[m] > p.thr, act, yoff,
+                            acc[m]);
                     }
                 }
             }

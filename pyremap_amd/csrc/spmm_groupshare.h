@@ -12,42 +12,46 @@
 // room for more than 8 rows x 256 columns of accumulators at 3 waves per SIMD.
 //
 // Here W (2 or 4) waves -- a workgroup -- own W consecutive 8-row groups, a
-// SUPERGROUP: a 4 x 4 or 4 x 8 tile of the destination grid (the 8-row
-// groups are walked inside super_tile = 4 or 8 blocks, so consecutive groups
-// stack up to such a tile).  The supergroup has ONE sorted union of source
-// rows (share_col, share_mask: bit 8 w + m = member m of wave w owns the
-// entry; remap_share_build).  Per step of UNR union entries:
+// SUPERGROUP: a 4 x 4 or 4 x 8 tile of the destination grid (the group tiles
+// are walked inside such tiles: remap_groups_build's share_waves).  The
+// supergroup has ONE sorted union of source rows (share_col, share_mask: bit
+// 8 w + m = member m of wave w owns the entry; remap_share_build).  The list
+// is walked in steps of UNR union entries through a ring of NBUF buffers in
+// LDS:
 //
-//   * every wave sends its share of the step's entries, 1 KiB per
-//     instruction, straight from global memory into an LDS ring by LDS-DMA
-//     (global_load_lds_dwordx4) -- each distinct source row enters the CU
-//     ONCE per supergroup: 0.16 union entries per entry on config 5 where the
-//     8-row groups have 0.33;
-//   * one s_barrier; the DMA of step s + 1 flies while step s is summed;
+//   * every wave sends its share of a step's entries, 1 KiB per instruction,
+//     straight from global memory into the ring by LDS-DMA
+//     (global_load_lds_dwordx4), NBUF - 1 steps ahead of the sums -- each
+//     distinct source row enters the CU ONCE per supergroup: 0.16 union
+//     entries per entry on config 5 where the 8-row groups have 0.33;
+//   * one s_barrier per step: behind it step s is in the ring for every wave
+//     and the buffer of step s - 1 is free for step s + NBUF - 1;
 //   * every wave reads the step's entries from LDS (ds_read_b128, a few
 //     entries ahead of the sums) and adds the ones its own 8 rows own --
 //     exactly the inner loop of spmm_rowgroup: member bits from the mask, the
 //     wave's weights (group_w of the 8-row schedule: its own contiguous
-//     stream, one coalesced load per step) handed over by v_readlane with a
-//     running scalar index.  A row adds its own entries in ascending column
-//     order: the same bits as every other family.
+//     stream) handed over by v_readlane with a running scalar index.  A row
+//     adds its own entries in ascending column order: the same bits as every
+//     other family.
 //
-// The wave keeps no X values in flight in registers (the ring does): 8 rows x
-// 256 columns of accumulators + two or three entries on their way from LDS.
+// Inside the step loop EVERY vector-memory instruction is an LDS-DMA and
+// every step issues the same number of them -- the step's weights travel the
+// same way, into a small wave-private ring -- so that "step s has landed" is
+// the immediate of one s_waitcnt vmcnt(N): loads return in order, and a plain
+// load issued between the DMAs could only be awaited together with
+// everything issued before it (NBUF - 2 steps of lookahead lost).  Entries
+// behind the list's end re-send its last entry (an L1 hit).
+//
 // Columns and masks do not pass through the scalar cache here: a scalar load
-// in flight turns every LDS wait into lgkmcnt(0); they are fetched 64 entries
-// at a time, one per lane, and handed out by v_readlane -- the masks already
-// cut down to this wave's 8 member bits, with the number of weights each
-// step takes summed over its 8 lanes (three DPP adds per 64 entries): a
-// step's scalar side is nine v_readlane (the first build extracted bits and
-// counts entry by entry on the scalar unit: 100 SALU instructions per step,
-// 5.7e9 per launch against the row-group kernel's 3.5e9, and an on-chip floor
-// of 17.7 ms where that kernel has 14.6 -- profiles/r06_analysis).
+// in flight turns every LDS wait into lgkmcnt(0).  They are fetched once per
+// segment of 128 union entries (nearly every list is one segment), one per
+// lane, cut down to this wave's 8 member bits, and handed out by v_readlane;
+// the weights each step takes are counted on the vector side (DPP adds) and
+// summed up once per segment.  (The first build extracted bits and counts
+// entry by entry on the scalar unit: 100 SALU instructions per step, 5.7e9
+// per launch against the row-group kernel's 3.5e9, and an on-chip floor of
+// 17.7 ms where that kernel has 14.6 -- profiles/r06_analysis.)
 // ---------------------------------------------------------------------------
-template <>
-struct I32Vec<2> {
-    typedef int32_t type __attribute__((ext_vector_type(2), aligned(4)));
-};
 
 // compile-time loop: the body sees its index as a constant (the offsets of
 // the ds_read_b128 below are instruction immediates)
@@ -58,11 +62,29 @@ __device__ __forceinline__ void share_static_for(
     (f(std::integral_constant<int, I>{}), ...);
 }
 
-// every DMA and every load of this wave has landed, every LDS read of the
-// last step is done; then the workgroup's barrier
+// The DMAs of this wave up to the N last ones have landed, every LDS read of
+// the last step is done; then the workgroup's barrier.  (Not __syncthreads():
+// that drains vmcnt altogether.)
+template <int N>
 __device__ __forceinline__ void share_barrier()
 {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier"
+                 :
+                 : "n"(N)
+                 : "memory");
+}
+
+// The same with the read of the step's weights -- the wave's own slot, landed
+// once ITS DMAs have -- issued in front of the barrier: its trip to LDS runs
+// while the other waves arrive.
+template <int N>
+__device__ __forceinline__ void share_barrier_w(double &w, uint32_t addr)
+{
+    asm volatile("s_waitcnt vmcnt(%2) lgkmcnt(0)\n\t"
+                 "ds_read_b64 %0, %1\n\ts_barrier"
+                 : "=v"(w)
+                 : "v"(addr), "n"(N)
+                 : "memory");
 }
 
 // The ring is read with explicit ds_read_b128 / s_waitcnt lgkmcnt(N): left to
@@ -94,7 +116,19 @@ __device__ __forceinline__ void share_wait(share_x2 (&x)[TILES])
                      : "n"(N));
 }
 
-template <int TILES, int MODE, bool FMA, int W, int UNR, int AHEAD>
+// the step's weights: lane j's is weight j of the wave's slot
+__device__ __forceinline__ void share_read_w(double &w, uint32_t addr)
+{
+    asm volatile("ds_read_b64 %0, %1" : "=v"(w) : "v"(addr));
+}
+
+template <int N>
+__device__ __forceinline__ void share_wait_w(double &w)
+{
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(w) : "n"(N));
+}
+
+template <int TILES, int MODE, bool FMA, int W, int UNR, int NBUF, int AHEAD>
 __global__ __launch_bounds__(W *kWave) void spmm_groupshare(
     const KParams p, const uint32_t flags,
     const int64_t *__restrict__ gmeta, const double *__restrict__ gw,
@@ -104,18 +138,22 @@ __global__ __launch_bounds__(W *kWave) void spmm_groupshare(
 {
     constexpr int G = 8, VEC = 2;
     constexpr int EPW = UNR / W;             // entries a wave sends per step
+    constexpr int A = NBUF - 1;              // steps the DMA runs ahead
     constexpr int kEntryBytes = TILES * 1024;
     constexpr int kBufBytes = UNR * kEntryBytes;
-    constexpr int kStepsPerBlock = kWave / UNR;   // steps one lane-held block
-                                                  // of 64 columns / masks lasts
-    constexpr int NW = (UNR * G + kWave - 1) / kWave;
-    static_assert(UNR % W == 0 && UNR == 8, "step shape");
+    constexpr int kWSlot = UNR * G * 8;      // a step's weights at most
+    constexpr int kWDma = kWSlot / 256;      // ... 256 bytes per instruction
+    constexpr int kOps = EPW * TILES + kWDma;    // DMAs per wave and step
+    constexpr int kSeg = 2 * kWave;          // union entries per segment
+    static_assert(UNR % W == 0 && (UNR == 4 || UNR == 8), "step shape");
+    static_assert(NBUF >= 2 && NBUF <= 4 && (A - 1) * kOps <= 63, "ring");
     static_assert(AHEAD >= 1 && AHEAD < UNR && AHEAD * TILES <= 15,
                   "LDS reads ahead of the sums");
     static_assert(TILES == 1 || TILES == 2, "K tiles per wave");
     typedef typename I32Vec<G>::type rvec_t;
     typedef typename F64Vec<G>::type fvec_t;
-    extern __shared__ __attribute__((aligned(16))) char ring[];   // 2 buffers
+    // NBUF buffers of UNR entries, then NBUF x W slots of weights
+    extern __shared__ __attribute__((aligned(16))) char ring[];
 
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -164,6 +202,8 @@ __global__ __launch_bounds__(W *kWave) void spmm_groupshare(
     const uint32_t ldx_bytes = static_cast<uint32_t>(p.ldx) * 8u;
     const uint32_t ring_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
         (__attribute__((address_space(3))) char *)ring));
+    char *const wring = ring + NBUF * kBufBytes;
+    const uint32_t wring_lds = ring_lds + NBUF * kBufBytes;
 
     double acc[G][TILES][VEC];
     double den[G][TILES][VEC];
@@ -177,17 +217,62 @@ __global__ __launch_bounds__(W *kWave) void spmm_groupshare(
                 den[m][t][v] = 0.0;
             }
 
-    // this wave's pieces of the step whose first union entry is `base`, into
-    // ring buffer `buf`; `cols` holds the columns of the 64 entries from
-    // `cbase` on, one per lane
-    auto send = [&](const int buf, const int32_t cols, const int cbase,
-                    const int base) {
+    int seg_w = 0;   // weights of this wave's stream the earlier segments took
+    for (int seg0 = 0; seg0 < len; seg0 += kSeg) {
+        const int seg_len = (len - seg0) < kSeg ? len - seg0 : kSeg;
+        const int seg_steps = (seg_len + UNR - 1) / UNR;
+        if (seg0 > 0)   // the ring of the segment before is read to the end
+            share_barrier<0>();
+        // columns and masks of the segment, one entry per lane and block (the
+        // arrays are padded: always in bounds); the masks cut down to this
+        // wave's member bits (none behind the list's end); in the lanes of a
+        // step the number of bits set in the step
+        int32_t colv[2], bitsv[2], cntv[2];
 #pragma unroll
-        for (int i = 0; i < EPW; ++i) {
-            const int uu = wave * EPW + i;
-            if (base + uu < len) {
-                int32_t c =
-                    __builtin_amdgcn_readlane(cols, base - cbase + uu);
+        for (int b = 0; b < 2; ++b) {
+            colv[b] = lcol[seg0 + b * kWave + lane];
+            const int32_t raw = lmask[seg0 + b * kWave + lane];
+            int32_t mine = (raw >> sh) & 0xff;
+            mine = seg0 + b * kWave + lane < len ? mine : 0;
+            int32_t pc = __builtin_popcount(mine);
+            pc += __builtin_amdgcn_update_dpp(0, pc, 0xB1, 0xf, 0xf, true);
+            pc += __builtin_amdgcn_update_dpp(0, pc, 0x4E, 0xf, 0xf, true);
+            if constexpr (UNR == 8)
+                pc += __builtin_amdgcn_update_dpp(0, pc, 0x141, 0xf, 0xf,
+                                                  true);
+            bitsv[b] = mine;
+            cntv[b] = pc;
+        }
+        // (the loads above are awaited HERE, in straight-line code: met
+        // first behind a branch, hipcc's wait-count pass no longer knows
+        // whether they are still in flight and puts `s_waitcnt vmcnt(0)` in
+        // front of every send of the pipeline's fill -- each of them then
+        // waits for the one before to land)
+        asm volatile("" : : "v"(colv[0]), "v"(colv[1]));
+        // lane j: the weights the steps before step j of the segment took
+        int32_t cumv = 0;
+        {
+            int run = seg_w;
+            for (int j = 0; j < seg_steps; ++j) {
+                cumv = lane == j ? run : cumv;
+                const int e = j * UNR;
+                run += __builtin_amdgcn_readlane(
+                    e < kWave ? cntv[0] : cntv[1], e & (kWave - 1));
+            }
+            seg_w = run;
+        }
+
+        // this wave's pieces of step st of the segment: its entries of the
+        // step and the step's weights
+        auto send = [&](const int st) {
+            const int buf = st % NBUF;
+#pragma unroll
+            for (int i = 0; i < EPW; ++i) {
+                const int uu = wave * EPW + i;
+                int e = st * UNR + uu;
+                e = e < seg_len ? e : seg_len - 1;
+                int32_t c = __builtin_amdgcn_readlane(
+                    e < kWave ? colv[0] : colv[1], e & (kWave - 1));
                 REMAP_DIAG_COL(p, c);
                 const char *src =
                     reinterpret_cast<const char *>(X) +
@@ -203,151 +288,122 @@ __global__ __launch_bounds__(W *kWave) void spmm_groupshare(
                             t * 1024),
                         16, 0, 0);
             }
-        }
-    };
-
-    const int n_steps = (len + UNR - 1) / UNR;
-    // columns and masks, 64 entries per block, one per lane (the arrays are
-    // padded: always in bounds)
-    int32_t colv = lcol[lane];
-    int32_t maskv_next = lmask[lane];
-    int32_t colv_next = colv;
-    // a block of 64 masks -> this wave's member bits of every entry (none
-    // behind the list's end) and, in the 8 lanes of a step, the number of
-    // bits set in the step
-    int32_t bitsv = 0, cntv = 0;
-    auto prepare = [&](const int32_t raw, const int block_base) {
-        int32_t mine = (raw >> sh) & 0xff;
-        mine = block_base + lane < len ? mine : 0;
-        int32_t pc = __builtin_popcount(mine);
-        pc += __builtin_amdgcn_update_dpp(0, pc, 0xB1, 0xf, 0xf, true);
-        pc += __builtin_amdgcn_update_dpp(0, pc, 0x4E, 0xf, 0xf, true);
-        pc += __builtin_amdgcn_update_dpp(0, pc, 0x141, 0xf, 0xf, true);
-        bitsv = mine;
-        cntv = pc;
-    };
-    double my_w[NW];
+            const int wo = __builtin_amdgcn_readlane(cumv, st);
+            const char *wsrc = reinterpret_cast<const char *>(lw + wo);
 #pragma unroll
-    for (int q = 0; q < NW; ++q)
-        my_w[q] = lw[q * kWave + lane];
-    int woff = 0;
-    if (n_steps > 0)
-        send(0, colv, 0, 0);
+            for (int q = 0; q < kWDma; ++q)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(
+                        wsrc + q * 256 + lane * 4),
+                    (__attribute__((address_space(3))) void *)(
+                        wring + (buf * W + wave) * kWSlot + q * 256),
+                    4, 0, 0);
+        };
 
-    for (int st = 0; st < n_steps; ++st) {
-        const int base = st * UNR;
-        const int buf = st & 1;
-        const int sib = st % kStepsPerBlock;
-        share_barrier();
-        if (sib == 0)
-            prepare(maskv_next, base);
-        // step st is in the ring, step st - 1's buffer is free: the next
-        // step's pieces leave now and fly while this one is summed
-        if (st + 1 < n_steps) {
-            const bool wrap = sib + 1 == kStepsPerBlock;
-            send(buf ^ 1, wrap ? colv_next : colv,
-                 wrap ? base + UNR : base - sib * UNR, base + UNR);
-            if (wrap) {
-                colv = colv_next;
-                maskv_next = lmask[base + UNR + lane];
-            }
-            // the block of columns after this one, a step before its first
-            // piece is sent
-            if (sib + 2 == kStepsPerBlock)
-                colv_next = lcol[base + 2 * UNR + lane];
-        }
-        // the member bits of this wave's rows, the number of weights the
-        // step takes from the wave's stream
-        int bits[UNR];
+        // the pipeline fills: steps 0 ... A - 1 leave
 #pragma unroll
-        for (int uu = 0; uu < UNR; ++uu)
-            bits[uu] = __builtin_amdgcn_readlane(bitsv, sib * UNR + uu);
-        const int cnt = __builtin_amdgcn_readlane(cntv, sib * UNR);
-        double w_next[NW];
-#pragma unroll
-        for (int q = 0; q < NW; ++q)
-            w_next[q] = lw[woff + cnt + q * kWave + lane];
+        for (int st = 0; st < A; ++st)
+            if (st < seg_steps)
+                send(st);
 
-        // the step's entries from LDS, AHEAD of the sums
-        const uint32_t mine = ring_lds + buf * kBufBytes + lane * 16;
-        share_x2 xr[AHEAD + 1][TILES];
-        share_static_for(
-            std::make_integer_sequence<int, AHEAD>{}, [&](auto d_c) {
-                constexpr int d = decltype(d_c)::value;
-                share_read<d * kEntryBytes>(xr[d][0], mine);
-                if constexpr (TILES == 2)
-                    share_read<d * kEntryBytes + 1024>(xr[d][1], mine);
-            });
-        int idx = 0;   // scalar: next weight of the step
-        share_static_for(
-            std::make_integer_sequence<int, UNR>{}, [&](auto uu_c) {
-                constexpr int uu = decltype(uu_c)::value;
-                constexpr int slot = uu % (AHEAD + 1);
-                if constexpr (uu + AHEAD < UNR) {
-                    constexpr int nx = (uu + AHEAD) % (AHEAD + 1);
-                    share_read<(uu + AHEAD) * kEntryBytes>(xr[nx][0], mine);
+        for (int st = 0; st < seg_steps; ++st) {
+            const int buf = st % NBUF;
+            // step st has landed in this wave's eyes when at most the DMAs
+            // of the A - 1 steps behind it are in flight (the list's last
+            // steps: fewer are, everything is awaited)
+            double my_w;
+            const uint32_t my_w_lds =
+                wring_lds + (buf * W + wave) * kWSlot + lane * 8;
+            if (st + A - 1 < seg_steps)
+                share_barrier_w<(A - 1) * kOps>(my_w, my_w_lds);
+            else
+                share_barrier_w<0>(my_w, my_w_lds);
+            // ... and in everybody's behind the barrier, and the buffer of
+            // step st - 1 is free: step st + A leaves
+            if (st + A < seg_steps)
+                send(st + A);
+            const int e0 = st * UNR;
+            const int32_t bv = e0 < kWave ? bitsv[0] : bitsv[1];
+            int bits[UNR];
+#pragma unroll
+            for (int uu = 0; uu < UNR; ++uu)
+                bits[uu] =
+                    __builtin_amdgcn_readlane(bv, (e0 & (kWave - 1)) + uu);
+
+            // the step's entries from LDS, AHEAD of the sums (its weights
+            // were asked for in front of the barrier)
+            const uint32_t mine = ring_lds + buf * kBufBytes + lane * 16;
+            share_x2 xr[AHEAD + 1][TILES];
+            share_static_for(
+                std::make_integer_sequence<int, AHEAD>{}, [&](auto d_c) {
+                    constexpr int d = decltype(d_c)::value;
+                    share_read<d * kEntryBytes>(xr[d][0], mine);
                     if constexpr (TILES == 2)
-                        share_read<(uu + AHEAD) * kEntryBytes + 1024>(
-                            xr[nx][1], mine);
-                }
-                const int b = bits[uu];
-                if (b) {
-                    // reads issued behind this entry's: those of the entries
-                    // uu + 1 ... min(uu + AHEAD, UNR - 1)
-                    constexpr int behind =
-                        (uu + AHEAD < UNR ? AHEAD : UNR - 1 - uu) * TILES;
-                    share_wait<behind, TILES>(xr[slot]);
-                    constexpr bool kMasked = MODE == REMAP_MODE_MASKED;
-                    double xz[TILES][VEC], vf[TILES][VEC];
+                        share_read<d * kEntryBytes + 1024>(xr[d][1], mine);
+                });
+            share_wait_w<AHEAD * TILES>(my_w);
+            int idx = 0;   // scalar: next weight of the step
+            share_static_for(
+                std::make_integer_sequence<int, UNR>{}, [&](auto uu_c) {
+                    constexpr int uu = decltype(uu_c)::value;
+                    constexpr int slot = uu % (AHEAD + 1);
+                    if constexpr (uu + AHEAD < UNR) {
+                        constexpr int nx = (uu + AHEAD) % (AHEAD + 1);
+                        share_read<(uu + AHEAD) * kEntryBytes>(xr[nx][0],
+                                                               mine);
+                        if constexpr (TILES == 2)
+                            share_read<(uu + AHEAD) * kEntryBytes + 1024>(
+                                xr[nx][1], mine);
+                    }
+                    const int b = bits[uu];
+                    if (b) {
+                        // reads issued behind this entry's: those of the
+                        // entries uu + 1 ... min(uu + AHEAD, UNR - 1)
+                        constexpr int behind =
+                            (uu + AHEAD < UNR ? AHEAD : UNR - 1 - uu) *
+                            TILES;
+                        share_wait<behind, TILES>(xr[slot]);
+                        constexpr bool kMasked = MODE == REMAP_MODE_MASKED;
+                        double xz[TILES][VEC], vf[TILES][VEC];
 #pragma unroll
-                    for (int t = 0; t < TILES; ++t)
+                        for (int t = 0; t < TILES; ++t)
 #pragma unroll
-                        for (int v = 0; v < VEC; ++v) {
-                            const double x = xr[slot][t][v];
-                            if constexpr (kMasked) {
-                                // once per entry, reused by every member
-                                // row that owns it (spmm_rowgroup.h: kHoist)
-                                const bool valid = (x == x);
-                                xz[t][v] = valid ? x : 0.0;
-                                vf[t][v] = valid ? 1.0 : 0.0;
-                                asm volatile(""
-                                             : "+v"(xz[t][v]),
-                                               "+v"(vf[t][v]));
-                            } else {
-                                xz[t][v] = x;
-                                vf[t][v] = 0.0;
+                            for (int v = 0; v < VEC; ++v) {
+                                const double x = xr[slot][t][v];
+                                if constexpr (kMasked) {
+                                    // once per entry, reused by every member
+                                    // row that owns it (spmm_rowgroup.h)
+                                    const bool valid = (x == x);
+                                    xz[t][v] = valid ? x : 0.0;
+                                    vf[t][v] = valid ? 1.0 : 0.0;
+                                    asm volatile(""
+                                                 : "+v"(xz[t][v]),
+                                                   "+v"(vf[t][v]));
+                                } else {
+                                    xz[t][v] = x;
+                                    vf[t][v] = 0.0;
+                                }
+                            }
+#pragma unroll
+                        for (int m = 0; m < G; ++m) {
+                            if (b & (1 << m)) {
+                                const double a = readlane_f64(my_w, idx);
+                                ++idx;
+#pragma unroll
+                                for (int t = 0; t < TILES; ++t)
+#pragma unroll
+                                    for (int v = 0; v < VEC; ++v) {
+                                        acc[m][t][v] = mul_add<FMA>(
+                                            a, xz[t][v], acc[m][t][v]);
+                                        if constexpr (kMasked)
+                                            den[m][t][v] = den_add(
+                                                a, vf[t][v], den[m][t][v]);
+                                    }
                             }
                         }
-#pragma unroll
-                    for (int m = 0; m < G; ++m) {
-                        if (b & (1 << m)) {
-                            double a;
-                            if constexpr (NW == 1)
-                                a = readlane_f64(my_w[0], idx);
-                            else
-                                a = idx < kWave
-                                        ? readlane_f64(my_w[0], idx)
-                                        : readlane_f64(my_w[1],
-                                                       idx - kWave);
-                            ++idx;
-#pragma unroll
-                            for (int t = 0; t < TILES; ++t)
-#pragma unroll
-                                for (int v = 0; v < VEC; ++v) {
-                                    acc[m][t][v] = mul_add<FMA>(
-                                        a, xz[t][v], acc[m][t][v]);
-                                    if constexpr (kMasked)
-                                        den[m][t][v] = den_add(
-                                            a, vf[t][v], den[m][t][v]);
-                                }
-                        }
                     }
-                }
-            });
-        woff += cnt;
-#pragma unroll
-        for (int q = 0; q < NW; ++q)
-            my_w[q] = w_next[q];
+                });
+        }
     }
 
     if (nmem > 0) {

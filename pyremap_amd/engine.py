@@ -30,6 +30,7 @@ FLAG_FMA = 1
 FLAG_TUNE_HINT = 4
 FLAG_TREE = 8
 FLAG_CELL_MASKS = 16   # masked mode, a hint: validity is per source cell
+FLAG_BATCH_MASKS = 32  # masked mode, a hint: the same mask in every batch
 
 #: long rows apart (RemapPlan._split_long_rows): up to this many fields the
 #: long rows run one wave per (row, few columns) -- family 9 -- beyond it on
@@ -66,7 +67,7 @@ EXPORTS = (
     'remap_abi_version', 'remap_arch', 'remap_last_error',
     'remap_device_count', 'remap_apply_f64', 'remap_csr_from_coo_workspace',
     'remap_csr_from_coo', 'remap_stream_copy', 'remap_scan_nan',
-    'remap_scan_nan_kinds',
+    'remap_scan_nan_kinds', 'remap_scan_nan_layout',
     'remap_groups_workspace', 'remap_groups_build', 'remap_share_build',
     'remap_patches_workspace', 'remap_patches_build',
     'remap_schedule_sizes', 'remap_schedule_auto',
@@ -193,6 +194,12 @@ class _Schedule(ctypes.Structure):
         ('n_distinct', ctypes.c_int64),
         ('tune', (ctypes.c_int32 * 8) * 3),
         ('arena_used', ctypes.c_size_t),
+        ('share_meta', ctypes.c_void_p),
+        ('share_col', ctypes.c_void_p),
+        ('share_mask', ctypes.c_void_p),
+        ('share_waves', ctypes.c_int32),
+        ('share_reserved', ctypes.c_int32),
+        ('n_share_union', ctypes.c_int64),
     ]
 
 
@@ -360,6 +367,11 @@ def load_library():
     lib.remap_scan_nan_kinds.argtypes = [ctypes.c_void_p, ctypes.c_int32,
                                    ctypes.c_int64, ctypes.c_void_p,
                                    ctypes.c_void_p]
+    lib.remap_scan_nan_layout.restype = ctypes.c_int
+    lib.remap_scan_nan_layout.argtypes = [
+        ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64,
+        ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
+        ctypes.c_void_p]
     lib.remap_stream_copy.restype = ctypes.c_int
     lib.remap_stream_copy.argtypes = [ctypes.c_void_p, ctypes.c_void_p,
                                       ctypes.c_size_t, ctypes.c_void_p]
@@ -1339,7 +1351,7 @@ class RemapPlan:
 
         self._arena = arena
         order = view(sched.row_order, self.n_b, torch.int32)
-        tune = {mode: [int(v) for v in sched.tune[mode]][:5]
+        tune = {mode: [int(v) for v in sched.tune[mode]][:6]
                 for mode in (MODE_RAW, MODE_FRACB, MODE_MASKED)}
         if sched.family == 5:
             self.row_order = order
@@ -1373,13 +1385,31 @@ class RemapPlan:
                 rid=view(sched.group_rid, n_g * G, torch.int32),
                 frac=view(sched.group_frac, n_g * G, torch.float64),
                 n=n_g, rows=G, order=order, union=nu)
+            share = None
+            if sched.share_waves:
+                W, su = int(sched.share_waves), int(sched.n_share_union)
+                n_s = (self.n_b + 8 * W - 1) // (8 * W)
+                share = dict(
+                    meta=view(sched.share_meta, 2 * (n_s + 1),
+                              torch.int64).reshape(n_s + 1, 2),
+                    col=view(sched.share_col, su + 256, torch.int32),
+                    mask=view(sched.share_mask, su + 256, torch.int32),
+                    waves=W, union=su, ratio=su / self.nnz)
+                self.groups['share'] = share
+                # (assigning into the dict does not pass the property)
+                self._sched_version += 1
             self.default_tune = tune
             rich = bool(sched.entry_rich)
-            return {'family': 'rowgroup', 'union_ratio': float(sched.ratio),
-                    'rows_per_group': G,
-                    'order': '2x4 groups in 32x32 supertiles' if rich
-                    else '2x2 groups, row-major' if len(dims) == 2 else
-                    '4 consecutive rows', 'tune': self.default_tune}
+            out = {'family': 'rowgroup', 'union_ratio': float(sched.ratio),
+                   'rows_per_group': G,
+                   'order': '2x4 groups in 32x32 supertiles' if rich
+                   else '2x2 groups, row-major' if len(dims) == 2 else
+                   '4 consecutive rows', 'tune': self.default_tune}
+            if share is not None:
+                out['shared_by'] = share['waves']
+                out['shared_union_ratio'] = share['ratio']
+                out['order'] = '2x4 groups in 4x8 tiles in 32x32 supertiles'
+            return out
         if sched.family == 6:
             self.row_order = order.clone()
             self._arena = None
@@ -1832,6 +1862,30 @@ def scan_nan(x, flag):
                   _stream_ptr(x.device)), name)
 
 
+def scan_nan_layout(x, n_rows, n_batch, k_inner, kinds):
+    """
+    The NaN scan with the field's layout (``remap_scan_nan_layout``): ``x`` a
+    contiguous device tensor holding ``n_batch`` batches of ``n_rows`` source
+    cells of ``k_inner`` contiguous values -- ``(Time, nCells, nVertLevels)``
+    -- and ``kinds`` four zeroed int32: any NaN; whole cells missing (1) or
+    not (3); the same mask in every batch (1) or not (3); the masked form that
+    suits (0 none, 1 ``FLAG_CELL_MASKS``, 2 ``FLAG_BATCH_MASKS``, 3 neither).
+    """
+    torch = _torch()
+    lib = load_library()
+    if not x.is_contiguous() or x.numel() != n_batch * n_rows * k_inner:
+        raise ValueError('scan_nan_layout needs a contiguous (n_batch, '
+                         'n_rows, k_inner) tensor')
+    if kinds.numel() < 4 or kinds.dtype != torch.int32:
+        raise ValueError('kinds: four int32')
+    dtype = {torch.float64: DTYPE_F64, torch.float32: DTYPE_F32}[x.dtype]
+    with torch.cuda.device(x.device):
+        _check(lib.remap_scan_nan_layout(
+            _ptr(x), dtype, n_rows, n_batch, k_inner, k_inner,
+            n_rows * k_inner, _ptr(kinds), _stream_ptr(x.device)),
+            'remap_scan_nan_layout')
+
+
 def cell_mask_form(plan):
     """Does ``plan`` run the masked mode faster with FLAG_CELL_MASKS when
     whole cells are missing (8-row groups: entry-rich mappings)?"""
@@ -1864,17 +1918,31 @@ def remap_tensor_auto_mode(plan, dst_grid_dims, field, remap_axes, threshold,
                             flags=flags, out=out)
     X = field.contiguous()
     if flag is None and cell_mask_form(plan):
-        # entry-rich mapping: the scan also tells whole missing cells from
-        # values missing column by column, and the masked branch comes in
-        # the form that suits (REMAP_FLAG_CELL_MASKS): three gated launches
-        kinds = torch.zeros(2, dtype=torch.int32, device=field.device)
-        scan_nan(X, kinds)
+        # entry-rich mapping: the scan -- told where the cells and the
+        # batches of the field are -- also says whether whole cells are
+        # missing (land) or the mask is the same in every batch
+        # (bathymetry), and the masked branch comes in the form that suits
+        # (REMAP_FLAG_CELL_MASKS / REMAP_FLAG_BATCH_MASKS / neither): up to
+        # four gated launches, one of which runs
+        axes = [int(a) % X.ndim for a in remap_axes]
+        lead = min(axes)
+        n_batch = _prod(X.shape[:lead])
+        k_inner = _prod(X.shape[lead + len(axes):])
+        hints = FLAG_CELL_MASKS | FLAG_BATCH_MASKS
+        flags &= ~hints
+        kinds = torch.zeros(4, dtype=torch.int32, device=field.device)
+        scan_nan_layout(X, plan.n_a, n_batch, k_inner, kinds)
         Y = remap_tensor(plan, dst_grid_dims, X, remap_axes, MODE_MASKED,
                          threshold=threshold, flags=flags | FLAG_CELL_MASKS,
-                         out=out, gate=kinds[1:], gate_value=1)
+                         out=out, gate=kinds[3:], gate_value=1)
+        if n_batch >= 3:
+            Y = remap_tensor(plan, dst_grid_dims, X, remap_axes, MODE_MASKED,
+                             threshold=threshold,
+                             flags=flags | FLAG_BATCH_MASKS, out=Y,
+                             gate=kinds[3:], gate_value=2)
         Y = remap_tensor(plan, dst_grid_dims, X, remap_axes, MODE_MASKED,
                          threshold=threshold, flags=flags, out=Y,
-                         gate=kinds[1:], gate_value=3)
+                         gate=kinds[3:], gate_value=3)
         return remap_tensor(plan, dst_grid_dims, X, remap_axes, MODE_FRACB,
                             flags=flags, out=Y, gate=kinds, gate_value=0)
     if flag is None:

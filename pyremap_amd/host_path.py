@@ -388,11 +388,19 @@ def remap_host_batch(plan, dst_grid_dims, arrays, remap_axes, *, mode,
             # (the caller's stream sees the batch finished as well)
             main.wait_event(event)
         except BaseException:
-            _release_pinned(pinned)
-            try:           # (the feeder ends by itself: its list is finite)
-                feeder.join(timeout=10.0)
+            # The feeder may still be copying from `arrays` into x_d on the
+            # upload stream, downloads of earlier sub-batches may still be
+            # writing out_h: wait for all of it BEFORE the buffers go back
+            # to their allocators -- a block handed out again while a side
+            # stream still writes into it is silent corruption.  (The feeder
+            # ends by itself: its list is finite.)
+            try:
+                feeder.join()
             except NameError:
                 pass
+            up.synchronize()
+            down.synchronize()
+            _release_pinned(pinned)
             raise
     return PendingBatch(event, out_h, pinned)
 

@@ -347,6 +347,17 @@ def _start_data_array(da, remapper, renormalization_threshold,
     return finish
 
 
+def _in_memory(da):
+    """The numpy array behind ``da`` if its values are already in memory,
+    else None (xr_lite's ``LazyValues``; with real xarray a dask array or a
+    lazily indexed backend array) -- without touching ``.values``."""
+    var = getattr(da, 'variable', da)
+    if getattr(var, 'is_lazy', False) or getattr(da, 'is_lazy', False):
+        return None
+    data = getattr(var, '_data', None)
+    return data if isinstance(data, np.ndarray) else None
+
+
 def _batches(remapper, ds, names):
     """
     ``{name: [names of its batch]}`` for the variables that are remapped
@@ -363,21 +374,30 @@ def _batches(remapper, ds, names):
     src_dims = remapper.src_descriptor.dims
     for name in names:
         da = ds[name]
-        values = da.values
-        if not isinstance(values, np.ndarray) or values.dtype.kind not in \
-                'fiub' or values.nbytes > host_path.BATCH_VAR_BYTES or \
-                values.size == 0:
+        # metadata only: `.values` of a dask-backed or lazily indexed
+        # variable computes / reads it -- every variable of the Dataset up
+        # front, the multi-GB ones that are rejected by size included, and
+        # once more when its turn comes.  Only arrays already in memory are
+        # batched; the others keep the per-variable pipeline, `depth` at a
+        # time.
+        data = _in_memory(da)
+        if data is None or data.dtype.kind not in 'fiub' or data.size == 0:
+            continue
+        # what travels: float32 as it is, everything else as float64
+        dtype = data.dtype if data.dtype in (np.float32, np.float64) \
+            else np.dtype(np.float64)
+        nbytes = data.size * dtype.itemsize
+        if nbytes > host_path.BATCH_VAR_BYTES:
             continue
         hit = [dim in src_dims for dim in da.dims]
         if sum(hit) != len(src_dims):
             continue
-        dtype = values.dtype if values.dtype in (np.float32, np.float64) \
-            else np.dtype(np.float64)
-        groups.setdefault((tuple(da.dims), values.shape, dtype.str),
-                          []).append(name)
+        groups.setdefault((tuple(da.dims), tuple(data.shape), dtype.str),
+                          []).append((name, nbytes))
     out = {}
-    for members in groups.values():
-        per = max(1, ds[members[0]].values.nbytes)
+    for sized in groups.values():
+        members = [name for name, _ in sized]
+        per = max(1, sized[0][1])
         cap = max(2, host_path.BATCH_TOTAL_BYTES // per)
         for i in range(0, len(members), cap):
             part = members[i:i + cap]

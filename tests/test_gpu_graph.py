@@ -183,7 +183,7 @@ def test_plan_handle_launches_are_capturable(dev):
         # `remap_plan_apply_auto` (memset of the flags, the scan, the gated
         # launches) is capturable too: one capture, replayed on a field
         # without NaNs and on one with (the branch is taken on the device)
-        kinds = torch.zeros(2, dtype=torch.int32, device=dev)
+        kinds = torch.zeros(4, dtype=torch.int32, device=dev)
         f.threshold = 0.2
         graph2 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph2):
@@ -201,8 +201,9 @@ def test_plan_handle_launches_are_capturable(dev):
             arg = np.ma.masked_array(h, np.isnan(h)) if with_nan else h
             want = np.ma.filled(oracle.remap_numpy_array(
                 csr, mm['frac_b'], (40, 60), arg, [1], 0.2), np.nan)
+            assert int(kinds[0]) == int(with_nan), kinds.tolist()
             assert_bitwise(y.cpu().numpy().reshape(30, 40, 60), want,
-                           f'apply_auto replayed, NaNs: {with_nan}')
-            assert int(kinds[0]) == int(with_nan)
+                           f'apply_auto replayed, NaNs: {with_nan} '
+                           f'{kinds.tolist()}')
     finally:
         lib.remap_plan_destroy(handle)

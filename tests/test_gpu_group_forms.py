@@ -336,7 +336,7 @@ def test_plan_handle_apply_auto(dev, rich):
         assert lib.remap_plan_query(handle, ctypes.byref(info)) == 0
         assert (info.group_rows == 8) == rich
         K = 384
-        kinds = torch.full((2,), 7, dtype=torch.int32, device=dev)
+        kinds = torch.full((4,), 7, dtype=torch.int32, device=dev)
         for tag, x in _fields(m.n_a, K, 11):
             xd = torch.from_numpy(x).to(dev)
             y = torch.full((m.n_b, K), 5.0, dtype=torch.float64, device=dev)
@@ -357,7 +357,10 @@ def test_plan_handle_apply_auto(dev, rich):
             ref = ref.copy()
             ref[ref_mask] = np.nan
             assert_bitwise(y.cpu().numpy(), ref, f'{tag} rich={rich}')
-            want = {'no NaN': (0, 0), 'whole cells': (1, 1)}.get(tag, (1, 3))
+            # (any NaN, whole cells 1 / not 3, one batch: its own mask 1,
+            # the form the masked launch took)
+            want = {'no NaN': (0, 0, 0, 0),
+                    'whole cells': (1, 1, 1, 1)}.get(tag, (1, 3, 1, 3))
             assert tuple(kinds.tolist()) == want, (tag, kinds.tolist())
     finally:
         lib.remap_plan_destroy(handle)

@@ -91,15 +91,16 @@ def test_shared_lists_match_a_numpy_restatement(dev, share, two_d):
 @pytest.mark.parametrize('share', [2, 4])
 @pytest.mark.parametrize('K', [130, 192, 256, 300, 1024])
 def test_shared_form_bitwise(dev, share, K):
-    """Three modes, one or two K tiles per wave, 1 - 3 LDS reads ahead, both
-    work-list orders; NaNs in the field (propagated in the frac_b / raw
-    modes, masked in the masked mode)."""
+    """Three modes, one or two K tiles per wave, the ring shapes (entries per
+    step x buffers: 8 x 2, 8 x 3, 4 x 3, 4 x 4), the work-list orders; NaNs in
+    the field (propagated in the frac_b / raw modes, masked in the masked
+    mode)."""
     from pyremap_amd import engine
     m, mm, plan, csr = _problem(dev, share)
     fields = _fields(m.n_a, K, K + share)
     for tiles in (1, 2):
-        for ahead, order in ((2, 3), (1, 2), (3, 1)):
-            tune = [10, 0, tiles, ahead, order, 32]
+        for shape, order in ((0, 3), (83, 2), (43, 1), (44, 3)):
+            tune = [10, shape, tiles, 0, order, 32]
             for mode, thr in ((engine.MODE_FRACB, 0.0),
                               (engine.MODE_RAW, 0.0),
                               (engine.MODE_MASKED, 0.3)):
@@ -123,10 +124,11 @@ def test_shared_form_long_lists_one_dimensional_and_fma(dev, share):
                                 k=(24, 60), seed=11)
     meta = plan.groups['share']['meta'][:, 0].cpu().numpy()
     longest = int(np.diff(meta).max())
-    assert longest > 64 * (1 if share == 2 else 2), longest
+    assert longest > 64 * (1 if share == 2 else 2), longest   # segments of 128
     rng = np.random.default_rng(3)
     x = rng.standard_normal((m.n_a, 384))
-    for tune in ([10, 0, 2, 2, 3, 32], [10, 0, 1, 3, 2, 32]):
+    for tune in ([10, 0, 2, 0, 3, 32], [10, 44, 1, 0, 2, 32],
+                 [10, 83, 2, 0, 3, 32], [10, 43, 2, 0, 3, 32]):
         for mode, thr in ((engine.MODE_FRACB, 0.0), (engine.MODE_MASKED, 0.2)):
             xm = x.copy()
             if mode == engine.MODE_MASKED:
@@ -188,3 +190,50 @@ def test_shared_form_layouts_and_what_it_declines(dev):
         engine.remap_tensor(plan, None, torch.from_numpy(
             rng.standard_normal((m.n_a, 256))).to(dev), [0],
             engine.MODE_FRACB, tune=tune)
+
+
+def test_fracb_division_fast_path_and_its_guards(dev):
+    """The frac_b mode divides a row by ONE wave-uniform number: for ordinary
+    operands the epilogue refines 1 / frac_b once per row and finishes each
+    element with a multiply and two FMAs -- the very instructions the full
+    IEEE division sequence ends with when its scaling steps scale nothing
+    (csrc/spmm_device.h: finish_row) -- and anything else (zeros, denormals,
+    1e-250, 1e300, Inf, NaN, a frac_b outside [2^-126, 2^126]) takes the full
+    sequence.  Every value equals the C division of the oracle, bit for bit
+    (`num[ok] /= den[ok]`, remap_numpy.py:277), in every kernel family that
+    shares the epilogue."""
+    from oracle import oracle
+    from pyremap_amd import engine
+    rng = np.random.default_rng(12)
+    n_cells, K = 32, 256
+    x = rng.standard_normal((n_cells, K)) * \
+        10.0 ** rng.integers(-200, 150, (n_cells, 1))
+    specials = [0.0, -0.0, 1e-310, -4e-320, 1e-250, 2.0 ** -800,
+                np.nextafter(2.0 ** -800, 0.0), 2.0 ** 600,
+                np.nextafter(2.0 ** 601, 1.0), 2.0 ** 601, 1e300, np.inf,
+                -np.inf, np.nan, 1.5e-241, 8.3e180]
+    for j, s in enumerate(specials):            # cells 16 ... : one each
+        x[16 + j, (37 * j) % K] = s
+    fracs = [1.0, 0.5, 0.3, 1.0 / 3.0, 1e-30, 1e-38, 2.0 ** -126,
+             np.nextafter(2.0 ** -126, 0.0), 2.0 ** 126,
+             np.nextafter(2.0 ** 127, 1.0), 1e38, 1e-310, 0.0, -0.5, 1e300,
+             0.9999999999999999]
+    row = np.repeat(np.arange(n_cells * len(fracs)), 1)
+    col = row % n_cells
+    frac_b = np.repeat(np.asarray(fracs), n_cells)
+    S = np.ones(row.size)
+    n_b = row.size
+    plan = engine.RemapPlan.from_triplets(row + 1, col + 1, S, frac_b,
+                                          n_cells, n_b, index_base=1,
+                                          device=dev)
+    csr = oracle.coo_to_csr(row, col, S, n_b, n_cells)
+    with np.errstate(all='ignore'):
+        for rows, share, tunes in ((None, 0, [None, [1], [6, 2, 2]]),
+                                   (4, 0, [[10, 0, 1, 1]]),
+                                   (8, 4, [[10, 1, 2, 1, 3],
+                                           [10, 0, 2, 0, 3, 32]])):
+            if rows:
+                plan.build_groups(None, rows=rows, share=share)
+            for tune in tunes:
+                _check(plan, csr, frac_b, x, dev, engine.MODE_FRACB, 0.0,
+                       tune, f'division, rows={rows} tune={tune}')

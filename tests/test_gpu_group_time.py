@@ -1,0 +1,201 @@
+"""
+Round 6: masks that do not change from batch to batch.
+
+* `spmm_grouptime` (csrc/spmm_grouptime.h): the masked mode of the 8-row
+  groups under REMAP_FLAG_BATCH_MASKS -- lanes across the levels, four time
+  slices per lane, ONE normaliser per lane and row while the four slices of a
+  lane are valid or missing together; a group that meets anything else is
+  redone with per-element normalisers inside the launch.  Every value against
+  the oracle, bit for bit, whatever is missing and whether or not the flag is
+  passed (reference: remap_numpy.py:262-266, 277-278).
+* `remap_scan_nan_layout`: the NaN scan told where the field's cells and
+  batches are, and the form of the masked launch it names; the four gated
+  launches of `remap_tensor_auto_mode` / `remap_plan_apply_auto`.
+"""
+import numpy as np
+import pytest
+
+from helpers import assert_bitwise
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'these tests need an MI355X'
+    from pyremap_amd import engine
+    engine.load_library()
+    return torch.device('cuda', 0)
+
+
+@pytest.fixture(scope='module')
+def problem(dev):
+    from oracle import oracle
+    from pyremap_amd import engine, synthetic
+    m = synthetic.conservative_map(1500, (38, 60), 6, 22, seed=5,
+                                   signed=True, locality='mesh')
+    mm = m.numpy()
+    plan = engine.RemapPlan.from_triplets(
+        mm['row'], mm['col'], mm['S'], mm['frac_b'], m.n_a, m.n_b,
+        index_base=1, device=dev)
+    csr = oracle.coo_to_csr(mm['row'] - 1, mm['col'] - 1, mm['S'], m.n_b,
+                            m.n_a)
+    choice = plan.auto_schedule(m.dst_dims)
+    assert choice['rows_per_group'] == 8
+    return m, mm, plan, csr
+
+
+def _fields(n_a, T, L, seed):
+    """(tag, (T, n_a, L) field, form the layout scan should name)."""
+    rng = np.random.default_rng(seed)
+    base = rng.standard_normal((T, n_a, L))
+    out = [('no NaN', base.copy(), 0)]
+    x = base.copy()
+    x[:, rng.random(n_a) < 0.25, :] = np.nan          # land: whole cells
+    x[:, 0, :] = np.nan
+    out.append(('whole cells', x, 1))
+    x = base.copy()
+    depth = rng.integers(1, L + 1, n_a)                # bathymetry
+    x[:, np.arange(L)[None, :] >= depth[:, None]] = np.nan
+    out.append(('bathymetry', x, 2 if T >= 3 else 3))
+    x = x.copy()
+    x[:, rng.random(n_a) < 0.2, :] = np.nan            # + land
+    out.append(('bathymetry and land', x, 2 if T >= 3 else 3))
+    x = base.copy()
+    x[rng.random(x.shape) < 0.02] = np.nan             # changes with time
+    x[-1, -1, -1] = np.nan
+    out.append(('single values', x, 3))
+    x = base.copy()
+    x[:, np.arange(L)[None, :] >= depth[:, None]] = np.nan
+    x[T // 2, 7, 0] = np.nan                           # one slice differs
+    out.append(('bathymetry but one value', x, 3))
+    return out
+
+
+def _reference(csr, frac_b, f, thr, masked=None):
+    from oracle import oracle
+    T, n_a, L = f.shape
+    flat = np.ascontiguousarray(f.transpose(1, 0, 2)).reshape(n_a, T * L)
+    if masked is None:     # the reference's branch (remap_numpy.py:201-204)
+        masked = bool(np.isnan(flat).any())
+    ref, ref_mask = oracle.remap_flat(csr, frac_b, flat.astype(np.float64),
+                                      masked, thr)
+    ref = ref.copy()
+    ref[ref_mask] = np.nan
+    n_b = ref.shape[0]
+    return ref.reshape(n_b, T, L).transpose(1, 0, 2)
+
+
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+@pytest.mark.parametrize('shape', [(8, 64), (5, 60), (3, 100), (16, 7),
+                                   (4, 130), (2, 64)])
+def test_batch_masks_form_bitwise(dev, problem, shape, dtype):
+    """REMAP_FLAG_BATCH_MASKS on every kind of field, with and without the
+    other hint, float32 fields, level runs shorter / longer than a wave,
+    time-block tails; two batches: the flag is ignored."""
+    from pyremap_amd import engine
+    m, mm, plan, csr = problem
+    T, L = shape
+    for tag, f, _ in _fields(m.n_a, T, L, T * 131 + L):
+        f = f.astype(dtype)
+        ref = _reference(csr, mm['frac_b'], f, 0.3, masked=True)
+        fd = torch.from_numpy(f).to(dev)
+        for flags in (engine.FLAG_BATCH_MASKS, 0,
+                      engine.FLAG_BATCH_MASKS | engine.FLAG_CELL_MASKS):
+            # (the plan's own choice: through the LDS ring where the field
+            # allows; tune[5] = 9: the form without the ring)
+            for tune in (None, [10, 1, 1, 1, 3], [10, 4, 1, 2, 2],
+                         [10, 1, 1, 1, 3, 9]):
+                y, mask = engine.remap_tensor(
+                    plan, None, fd, [1], engine.MODE_MASKED, threshold=0.3,
+                    flags=flags, tune=tune, want_mask=True)
+                what = f'{tag} (T={T}, L={L}) flags={flags} tune={tune}'
+                assert_bitwise(y.cpu().numpy(), ref, what)
+                assert np.array_equal(mask.cpu().numpy().astype(bool),
+                                      np.isnan(ref)), what
+
+
+def test_layout_scan_names_the_form_and_the_gated_launches(dev, problem):
+    """remap_scan_nan_layout on (Time, nCells, L) fields: land cells are
+    whole cells (the flat scan of round 5 called them "column by column"),
+    bathymetry is the same mask in every batch; remap_tensor_auto_mode
+    enqueues the four gated launches and the one that runs gives the
+    reference's result (remap_numpy.py:201-204, 258-278)."""
+    from pyremap_amd import engine
+    m, mm, plan, csr = problem
+    for T, L in ((6, 64), (4, 60), (2, 64), (1, 192)):
+        for tag, f, form in _fields(m.n_a, T, L, T + L):
+            fd = torch.from_numpy(f).to(dev)
+            kinds = torch.zeros(4, dtype=torch.int32, device=dev)
+            engine.scan_nan_layout(fd, m.n_a, T, L, kinds)
+            got = kinds.tolist()
+            has = bool(np.isnan(f).any())
+            cells = np.isnan(f).all(axis=(0, 2)) | \
+                ~np.isnan(f).any(axis=(0, 2))
+            same = (np.isnan(f) == np.isnan(f[:1])).all()
+            want = [int(has), 0 if not has else 1 if cells.all() else 3,
+                    0 if not has else 1 if same else 3]
+            want.append(0 if not has else 1 if cells.all() else
+                        2 if same and T >= 3 else 3)
+            assert got == want, (tag, T, L, got, want)
+            if T > 1:
+                assert got[3] == form, (tag, T, L, got)
+            y = engine.remap_tensor_auto_mode(plan, m.dst_dims, fd, [1], 0.3)
+            ref = _reference(csr, mm['frac_b'], f, 0.3)
+            assert_bitwise(y.cpu().numpy().reshape(ref.shape), ref,
+                           f'auto {tag} (T={T}, L={L})')
+    # float32, and a field with nothing in it
+    f32 = np.random.default_rng(1).standard_normal((3, m.n_a, 8)).astype(
+        np.float32)
+    f32[:, 5, :] = np.nan
+    kinds = torch.zeros(4, dtype=torch.int32, device=dev)
+    engine.scan_nan_layout(torch.from_numpy(f32).to(dev), m.n_a, 3, 8, kinds)
+    assert kinds.tolist() == [1, 1, 1, 1]
+    kinds.zero_()
+    engine.scan_nan_layout(torch.zeros((0, m.n_a, 8), device=dev), m.n_a, 0,
+                           8, kinds)
+    assert kinds.tolist() == [0, 0, 0, 0]
+
+
+def test_plan_handle_auto_with_four_forms(dev, problem):
+    """remap_plan_apply_auto (the C plan handle): the layout scan and the
+    gated launches issued by the library; kinds comes back with the form."""
+    import ctypes
+    from pyremap_amd import engine
+    m, mm, plan, csr = problem
+    lib = engine.load_library()
+    handle = ctypes.c_void_p()
+    row = torch.from_numpy(mm['row'].astype(np.int32)).to(dev)
+    col = torch.from_numpy(mm['col'].astype(np.int32)).to(dev)
+    S = torch.from_numpy(mm['S']).to(dev)
+    fb = torch.from_numpy(mm['frac_b']).to(dev)
+    dims = (ctypes.c_int64 * 2)(*m.dst_dims)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    engine._check(lib.remap_plan_create(
+        m.n_b, m.n_a, row.numel(), row.data_ptr(), col.data_ptr(),
+        S.data_ptr(), 1, fb.data_ptr(), 1, dims, 2, stream,
+        ctypes.byref(handle)), 'remap_plan_create')
+    try:
+        T, L = 6, 64
+        for tag, f, form in _fields(m.n_a, T, L, 99):
+            fd = torch.from_numpy(f).to(dev)
+            y = torch.full((T, m.n_b, L), 7.0, dtype=torch.float64,
+                           device=dev)
+            kinds = torch.full((4,), 9, dtype=torch.int32, device=dev)
+            fld = engine._Field()
+            fld.X, fld.x_dtype = fd.data_ptr(), 0
+            fld.n_batch, fld.k_inner = T, L
+            fld.x_row_stride, fld.x_batch_stride = L, m.n_a * L
+            fld.Y = y.data_ptr()
+            fld.y_row_stride, fld.y_batch_stride = L, m.n_b * L
+            fld.threshold = 0.3
+            engine._check(lib.remap_plan_apply_auto(
+                handle, ctypes.byref(fld), fd.numel(), kinds.data_ptr(),
+                stream), 'remap_plan_apply_auto')
+            assert kinds.tolist()[3] == form, (tag, kinds.tolist())
+            ref = _reference(csr, mm['frac_b'], f, 0.3)
+            assert_bitwise(y.cpu().numpy(), ref, f'plan handle, {tag}')
+    finally:
+        lib.remap_plan_destroy(handle)

@@ -1097,6 +1097,30 @@ def test_a_datasets_small_variables_are_grouped_by_shape_and_dtype():
                                                                  'i']
     finally:
         host_path.BATCH_VAR_BYTES, host_path.BATCH_TOTAL_BYTES = old
+    # values that are produced on demand are never touched (with real
+    # xarray: dask-backed / lazily indexed variables) -- `.values` would read
+    # every variable of the Dataset up front -- and the size cap counts what
+    # TRAVELS: int8 goes up as float64, eight times its bytes
+    from pyremap_amd.xr_lite import LazyValues
+
+    def boom():
+        raise AssertionError('_batches read a lazy variable')
+    ds['lazy0'] = DataArray(LazyValues((1, n), np.float64, boom),
+                            dims=('Time', 'nCells'))
+    ds['lazy1'] = DataArray(LazyValues((1, n), np.float64, boom),
+                            dims=('Time', 'nCells'))
+    ds['s0'] = DataArray(np.zeros((4, n), dtype=np.int8),
+                         dims=('T4', 'nCells'))
+    ds['s1'] = DataArray(np.zeros((4, n), dtype=np.int8),
+                         dims=('T4', 'nCells'))
+    names = list(ds.data_vars)
+    got = rn._batches(R(), ds, names)
+    assert 'lazy0' not in got and got['s0'] == ['s0', 's1']
+    try:
+        host_path.BATCH_VAR_BYTES = 4 * n * 4      # int8: 4 n bytes in RAM,
+        assert 's0' not in rn._batches(R(), ds, names)   # 32 n on the wire
+    finally:
+        host_path.BATCH_VAR_BYTES, host_path.BATCH_TOTAL_BYTES = old
     multi = R()
     multi._matrix = Plan()
     multi._matrix.shards = []

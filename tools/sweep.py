@@ -44,6 +44,10 @@ def main():
                          'order, no timing (run under rocprofv3 --pmc)')
     ap.add_argument('--shard', default=None,
                     help="R/N: time the rows rank R of N would own")
+    ap.add_argument('--levels', type=int, default=0,
+                    help='address the (n_a, K) buffers as K / L batches of L '
+                         'levels: n_batch = K / L, k_inner = L, batch stride '
+                         'L (what REMAP_FLAG_BATCH_MASKS wants to see)')
     ap.add_argument('--pairs', default=None,
                     help="';'-separated order|tune[|flags]: the variants, "
                          'instead of the product of --orders x --flags x '
@@ -152,9 +156,12 @@ def main():
         plan.patches = patch_sets.get(o)
         plan.groups = group_sets.get(o)
         s = i % args.sets
-        engine.apply_strided(plan, xs[s], ys[s], n_batch=1, k_inner=K,
-                             x_row_stride=K + args.x_pad, x_batch_stride=0,
-                             y_row_stride=K + args.y_pad, y_batch_stride=0,
+        L = args.levels or K
+        engine.apply_strided(plan, xs[s], ys[s], n_batch=K // L, k_inner=L,
+                             x_row_stride=K + args.x_pad,
+                             x_batch_stride=L if args.levels else 0,
+                             y_row_stride=K + args.y_pad,
+                             y_batch_stride=L if args.levels else 0,
                              mode=mode,
                              threshold=0.01, flags=fl, tune=tune)
 
