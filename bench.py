@@ -330,13 +330,17 @@ def make_launch(w, dst, axes, tune):
     return launch
 
 
-def same_with(w, flags=None, mode=None, mask='cells'):
+def same_with(w, flags=None, mode=None, mask='cells', tnl=0):
     """The prepared workload `w` once more with other REMAP_FLAG_* bits or in
     the masked mode: the same plan and buffers, nothing rebuilt.  (Masked:
     a quarter of the source cells of `w`'s fields become NaN IN PLACE, as
     make_fields makes them -- measure `w` itself first; `mask='levels'`: the
     K columns read as (Time, 64 levels), every cell missing below a depth of
-    its own as well -- bathymetry: validity differs from column to column.)"""
+    its own as well -- bathymetry: validity differs from column to column.
+    `tnl` = T: the buffers of an (n_a, K) workload read as a (T, nCells, K /
+    T) field, MPAS's layout -- fresh values, a quarter of the cells missing
+    at every time and level (land), with mask='levels' also every cell below
+    a depth of its own (bathymetry: the same mask at every time).)"""
     import copy
 
     import torch
@@ -345,6 +349,28 @@ def same_with(w, flags=None, mode=None, mask='cells'):
     v = copy.copy(w)
     if flags is not None:
         v.flags = flags
+    if tnl:
+        assert w.layout in ('nk', 'tnl') and mode == 'masked'
+        v.mode, v.emode = 'masked', engine.MODE_MASKED
+        v.layout, v.times = 'tnl', tnl
+        n_a, n_b, L = w.m.n_a, w.plan.n_b, w.K_local // tnl
+        g = torch.Generator(device=w.fields[0].device)
+        g.manual_seed(4321)
+        dst, _, tune = w.launch_args
+        dshape = [n_b] if dst is None else [int(d) for d in dst]
+        v.fields = [x.view(tnl, n_a, L) for x in w.fields]
+        v.outs = [y.view([tnl] + dshape + [L]) for y in w.outs]
+        for x in v.fields:
+            x.normal_(generator=g)
+            dead = torch.rand(n_a, generator=g, device=x.device) < 0.25
+            x.index_fill_(1, dead.nonzero().squeeze(1), float('nan'))
+            if mask == 'levels':
+                depth = torch.randint(8, L + 1, (n_a, 1), generator=g,
+                                      device=x.device)
+                lev = torch.arange(L, device=x.device)[None]
+                x.masked_fill_((lev >= depth)[None], float('nan'))
+        v.launch = make_launch(v, dst, [1], tune)
+        return v
     if mode == 'masked':
         v.mode, v.emode = 'masked', engine.MODE_MASKED
         g = torch.Generator(device=w.fields[0].device)
@@ -361,6 +387,22 @@ def same_with(w, flags=None, mode=None, mask='cells'):
                 lev = (torch.arange(x.shape[1], device=x.device) % 64)[None]
                 x.masked_fill_(lev >= depth, float('nan'))
     v.launch = make_launch(v, *w.launch_args)
+    if mode == 'masked' and mask == 'levels' and w.layout == 'nk' and \
+            (v.flags & 32):
+        # the K columns of a cell are (Time, 64 levels): told so -- K / 64
+        # batches of 64 levels, 64 elements apart -- the launch can keep one
+        # normaliser per (row, level) for four time slices
+        # (REMAP_FLAG_BATCH_MASKS); the bytes are where they were
+        K, tune = w.K_local, w.launch_args[2]
+
+        def launch(i):
+            s = i % v.sets
+            engine.apply_strided(
+                v.plan, v.fields[s], v.outs[s], n_batch=K // 64, k_inner=64,
+                x_row_stride=K, x_batch_stride=64, y_row_stride=K,
+                y_batch_stride=64, mode=v.emode, threshold=0.01,
+                flags=v.flags, tune=tune)
+        v.launch = launch
     return v
 
 
@@ -783,7 +825,8 @@ BIG = ('headline', 'config4', 'config5')
 #: command has to stay short): north_star's target workload, BASELINE config
 #: 5 in the bitwise and in the FMA mode, and the weak spots VERDICT.md names
 DEFAULT_ROWS = ('headline', 'config5', 'config5_fma', 'config5_masked',
-                'config5_masked_levels', 'config4', 'config2',
+                'config5_masked_levels', 'config5_tnl_masked',
+                'config5_tnl_masked_levels', 'config4', 'config2',
                 'Time120_nCells', 'layout_T8_nCells_L60',
                 'layout_T48_nCells_L10', 'layout_T120_nCells_L4',
                 'config1_esmf_pole_caps_K1',
@@ -824,11 +867,25 @@ def extras_todo(args, world):
         # NaNs in whole cells ...
         ('config5_masked', dict(name='config5', sets=1, mode='masked',
                                 share='config5', flags=16), 4),
+        # ... the same as MPAS lays a 3-D variable out, (Time = 16, nCells,
+        # 64 levels), land cells missing: what the layout-aware scan
+        # (remap_scan_nan_layout) picks there, REMAP_FLAG_CELL_MASKS again
         # ... and cells missing below a depth of their own as well (the K
-        # columns read as Time x 64 levels): the per-lane form, no flag --
-        # what the scan picks for values missing column by column
+        # columns of a cell are Time x 64 levels; bathymetry: the same mask
+        # at every time): REMAP_FLAG_BATCH_MASKS (32), one normaliser per
+        # (row, level) for four time slices -- what the layout-aware scan
+        # (remap_scan_nan_layout) picks there
         ('config5_masked_levels', dict(name='config5', sets=1, mode='masked',
-                                       share='config5', mask='levels'), 4),
+                                       share='config5', mask='levels',
+                                       flags=32), 4),
+        # ... the same two masks as MPAS lays a 3-D variable out, (Time = 16,
+        # nCells, 64 levels): a source cell's values are 16 runs of 512 bytes
+        # 1.9 GB apart, not one of 8 KiB
+        ('config5_tnl_masked', dict(name='config5', sets=1, mode='masked',
+                                    share='config5', flags=16, tnl=16), 4),
+        ('config5_tnl_masked_levels',
+         dict(name='config5', sets=1, mode='masked', share='config5',
+              mask='levels', flags=32, tnl=16), 4),
         ('config4', dict(name='config4', sets=1), 6),
         # BASELINE config 2: one round of workgroups, microseconds
         ('config2', dict(name='config2'), 50),
@@ -894,7 +951,8 @@ def measure_big_extras(args, rank, world, dist, extra):
             share = kw.pop('share', None)
             if share is not None and share == w_tag:
                 v = same_with(w, flags=kw.get('flags'), mode=kw.get('mode'),
-                              mask=kw.get('mask', 'cells'))
+                              mask=kw.get('mask', 'cells'),
+                              tnl=kw.get('tnl', 0))
             else:
                 if w is not None:
                     w.launch = w.fields = w.outs = w.full_field = None
@@ -903,6 +961,7 @@ def measure_big_extras(args, rank, world, dist, extra):
                 gc.collect()
                 torch.cuda.empty_cache()
                 kw.pop('mask', None)
+                kw.pop('tnl', None)
                 v = w = prepare(kw.pop('name'), args, rank, world, dist, **kw)
                 w_tag = tag
             measure_extras([(tag, v, steps)], args, dist, extra,
@@ -1019,10 +1078,18 @@ def kernel_of(e):
     """The kernel a workload's launches ran (for the side file)."""
     sched = e.get('schedule') or {}
     family = KERNEL_OF_FAMILY.get(sched.get('family'), 'spmm_*')
+    rich = sched.get('rows_per_group') == 8
     if family == 'spmm_rowgroup' and e.get('mode') == 'masked' and \
-            (e.get('flags') or 0) & 16 and sched.get('rows_per_group') == 8 \
-            and e['K'] > 128:
+            (e.get('flags') or 0) & 16 and rich and e['K'] > 128:
         family = 'spmm_groupmask (REMAP_FLAG_CELL_MASKS)'
+    elif family == 'spmm_rowgroup' and e.get('mode') == 'masked' and \
+            (e.get('flags') or 0) & 32 and rich and e['layout'] == 'tnl':
+        family = ('spmm_timeshare' if sched.get('shared_by') else
+                  'spmm_grouptime') + ' (REMAP_FLAG_BATCH_MASKS)'
+    elif family == 'spmm_rowgroup' and rich and sched.get('shared_by') and \
+            e.get('mode') != 'masked' and e['K'] > 128 and \
+            e.get('dtype', 'f64') == 'f64':
+        family = 'spmm_groupshare'
 
     if sched.get('long_rows'):
         return family + ' + spmm_patchcell (long rows apart)'

@@ -962,6 +962,23 @@ bool patch_serves(const remap_apply_args *a, const Call &c)
             (c.K >= 16 && a->n_patches >= 8192));
 }
 
+// The forms of family 10 that address X with a flat 64-bit address per lane
+// (LDS-DMA: spmm_groupshare.h, spmm_timeshare.h) also serve fields whose
+// batches lie further apart than 32-bit offsets reach -- (Time, nCells,
+// nVertLevels) on a 3.7 M-cell mesh: 1.9 GB per time slice.  Does this call
+// take one of them?
+bool wide_share(const remap_apply_args *a, const Call &c)
+{
+    if (!c.share_ok || !c.dma16 || a->x_src_fold != 0 ||
+        a->x_row_stride < 0 || a->x_row_stride >= (int64_t(1) << 29))
+        return false;
+    if (a->mode == REMAP_MODE_MASKED)
+        return a->share_waves == 4 && a->n_batch >= 3 &&
+               (a->flags & (REMAP_FLAG_BATCH_MASKS | REMAP_FLAG_CELL_MASKS)) &&
+               (a->tune[5] == 0 || a->tune[5] == 32);
+    return a->tune[5] == 32 && c.K > 128;
+}
+
 // REMAP_FLAG_TUNE_HINT: can the preferred family serve this call?
 bool hint_usable(const remap_apply_args *a, const Call &c)
 {
@@ -973,7 +990,7 @@ bool hint_usable(const remap_apply_args *a, const Call &c)
     // config 5 (8-row groups, 12 entries per row) 16 2 157 / 1 967, 24
     // 3 102 / 2 020, 32 3 779 / 2 026
     if (a->tune[0] == 10 && !short_runs(a))
-        return c.group_ok && c.small_offsets &&
+        return c.group_ok && (c.small_offsets || wide_share(a, c)) &&
                (c.K >= 28 || (c.K >= 16 && a->group_rows == 8));
     if (a->tune[0] == 7 && a->tune[2] == 2)
         return runs_usable(a, c);
@@ -990,7 +1007,7 @@ bool hint_usable(const remap_apply_args *a, const Call &c)
         return false;  // (Time, nCells): lanes across rows
     switch (a->tune[0]) {
     case 10:
-        return c.group_ok && c.small_offsets;
+        return c.group_ok && (c.small_offsets || wide_share(a, c));
     case 5:
         return c.patch_ok;
     case 7:
@@ -1084,11 +1101,12 @@ int64_t shape_tiles(KParams &p, const remap_apply_args *a, int64_t K,
 int run_rowgroup(const remap_apply_args *a, const Call &c, KParams p,
                  hipStream_t stream)
 {
-    if (!c.group_ok || !c.small_offsets)
+    if (!c.group_ok || !(c.small_offsets || wide_share(a, c)))
         return fail(REMAP_ERR_ARG,
                     "remap_apply_f64: the rowgroup kernel needs the "
                     "row-group schedule for [row_begin, row_end) and 32-bit "
-                    "offsets");
+                    "offsets (or the shared lists and a float64 field in "
+                    "whole 16-byte pieces)");
     // tune[5] = 32: the shared form (spmm_groupshare.h) -- W waves, one
     // union through an LDS ring; float64 fields in whole 16-byte pieces,
     // more than 128 columns.  A call it cannot serve takes the 8-row groups
@@ -1138,7 +1156,13 @@ int run_rowgroup(const remap_apply_args *a, const Call &c, KParams p,
     // across the levels, four time slices per lane, one normaliser per lane
     // and row (spmm_grouptime.h).  A hint: a group that meets anything else
     // takes the general form inside the same launch.
-    if ((a->flags & REMAP_FLAG_BATCH_MASKS) && a->mode == REMAP_MODE_MASKED &&
+    // (REMAP_FLAG_CELL_MASKS on a field whose batches lie further apart
+    // than 32-bit offsets reach: land cells are missing at every time too,
+    // and the form below through the LDS ring is the one that reaches)
+    const bool time_form =
+        (a->flags & REMAP_FLAG_BATCH_MASKS) ||
+        ((a->flags & REMAP_FLAG_CELL_MASKS) && !c.small_offsets);
+    if (time_form && a->mode == REMAP_MODE_MASKED &&
         a->group_rows == 8 && a->n_batch >= 3 && a->x_src_fold == 0 &&
         (a->tune[5] == 0 || a->tune[5] == 32 || a->tune[5] == 9)) {
         const int wpb = a->tune[1] == 4 ? 4 : a->tune[1] == 2 ? 2 : 1;
@@ -1161,6 +1185,10 @@ int run_rowgroup(const remap_apply_args *a, const Call &c, KParams p,
                 p.xcd_map |= 2;
             return launch_timeshare(a, p, c.fma, grid, stream);
         }
+        if (!c.small_offsets)
+            return fail(REMAP_ERR_UNSUPPORTED,
+                        "remap_apply_f64: batches further apart than 32-bit "
+                        "offsets reach need the shared lists");
         const int rc = shape_grid(
             p, ceil_div(a->n_groups, (int64_t)wpb * p.rows_per_wave),
             n_lb * n_tb, a->tune[4] != 1, grid);

@@ -193,12 +193,15 @@ __global__ __launch_bounds__(W *kWave) void spmm_groupshare(
     const int32_t *__restrict__ lmask = smask + s0;
     const double *__restrict__ lw = gw + gmeta[2 * (have ? g : n_groups) + 1];
     const int sh = wave * G;
-    // byte offsets from a source row's base; a row's base from its index
-    // with one 32 x 32 -> 64 bit product (the host checked both ranges)
-    uint32_t xob[TILES];
+    // byte offsets from a source row's base -- 64 bits: the batches of a
+    // (Time, nCells, nVertLevels) field on a 3.7 M-cell mesh are 1.9 GB
+    // apart, and the DMA takes a flat address per lane anyway; a row's base
+    // from its index with one 32 x 32 -> 64 bit product (the host checked
+    // that range)
+    uint64_t xob[TILES];
 #pragma unroll
     for (int t = 0; t < TILES; ++t)
-        xob[t] = static_cast<uint32_t>(xoff[t]) * 8u;
+        xob[t] = static_cast<uint64_t>(xoff[t]) * 8u;
     const uint32_t ldx_bytes = static_cast<uint32_t>(p.ldx) * 8u;
     const uint32_t ring_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
         (__attribute__((address_space(3))) char *)ring));

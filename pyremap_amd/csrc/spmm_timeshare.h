@@ -96,7 +96,9 @@ __attribute__((amdgpu_waves_per_eu(4, 8))) void spmm_timeshare(
     const uint32_t lb = static_cast<uint32_t>(chunk) / n_tb;
     const uint32_t tb = static_cast<uint32_t>(chunk) - lb * n_tb;
     // the sending side: lane -> (slice 2 t + lane / 32, two levels)
-    uint32_t xob[2];
+    // (64-bit offsets: the time slices of a (Time, nCells, nVertLevels)
+    // field on a 3.7 M-cell mesh are 1.9 GB apart)
+    uint64_t xob[2];
     {
         const uint32_t k2 = lb * kWave + 2u * (lane & 31);
         const bool k_on = k2 < p.k_inner;
@@ -104,9 +106,9 @@ __attribute__((amdgpu_waves_per_eu(4, 8))) void spmm_timeshare(
         for (int t = 0; t < 2; ++t) {
             const uint32_t b = tb * TB + 2 * t + (lane >> 5);
             const uint32_t bx = b < n_batch ? b : tb * TB;
-            xob[t] = k_on ? static_cast<uint32_t>(
+            xob[t] = k_on ? static_cast<uint64_t>(
                                 (static_cast<int64_t>(bx) * p.bsx + k2) * 8)
-                          : static_cast<uint32_t>(
+                          : static_cast<uint64_t>(
                                 static_cast<int64_t>(tb * TB) * p.bsx * 8);
         }
     }
@@ -317,16 +319,11 @@ __attribute__((amdgpu_waves_per_eu(4, 8))) void spmm_timeshare(
     const uint32_t k = lb * kWave + lane;
     const bool lane_on = k < p.k_inner;
     int64_t yoff[TB];
-    uint32_t xo[TB];    // (byte offsets for the general form's own loads)
     bool act[TB];
 #pragma unroll
     for (int e = 0; e < TB; ++e) {
         const uint32_t b = tb * TB + e;
         act[e] = lane_on && b < n_batch;
-        const uint32_t bx = b < n_batch ? b : tb * TB;
-        xo[e] = lane_on ? static_cast<uint32_t>(
-                              (static_cast<int64_t>(bx) * p.bsx + k) * 8)
-                        : 0u;
         yoff[e] = act[e] ? static_cast<int64_t>(b) * p.bsy + k : 0;
     }
     if (nmem > 0 && !mixed) {
@@ -352,10 +349,13 @@ __attribute__((amdgpu_waves_per_eu(4, 8))) void spmm_timeshare(
         const int64_t e_end = gmeta[2 * g + 2];
 #pragma unroll 1
         for (int e = 0; e < TB; ++e) {
-            const uint32_t xo_e = e == 0   ? xo[0]
-                                  : e == 1 ? xo[1]
-                                  : e == 2 ? xo[2]
-                                           : xo[3];
+            // (a slice is one batch: its offset goes into the base pointer,
+            // the lane's own offset -- its level -- stays small)
+            const uint32_t b_e = tb * TB + e;
+            const double *X_e =
+                X + static_cast<int64_t>(b_e < n_batch ? b_e : tb * TB) *
+                        p.bsx;
+            const uint32_t xo_e = lane_on ? k * 8u : 0u;
             const int64_t yoff_e = e == 0   ? yoff[0]
                                    : e == 1 ? yoff[1]
                                    : e == 2 ? yoff[2]
@@ -365,7 +365,7 @@ __attribute__((amdgpu_waves_per_eu(4, 8))) void spmm_timeshare(
                                : e == 2 ? act[2]
                                         : act[3];
             groupmask_general_tile<double, FMA, G, 8, 1>(
-                p, s, woff0, e_end, gcol, gw, gmask, grid, X, xo_e, yoff_e,
+                p, s, woff0, e_end, gcol, gw, gmask, grid, X_e, xo_e, yoff_e,
                 act_e, slot0, nmem, lane);
         }
     }

@@ -199,3 +199,56 @@ def test_plan_handle_auto_with_four_forms(dev, problem):
             assert_bitwise(y.cpu().numpy(), ref, f'plan handle, {tag}')
     finally:
         lib.remap_plan_destroy(handle)
+
+
+def test_batches_further_apart_than_32_bit_offsets(dev, problem):
+    """(Time, nCells, nVertLevels) on a 3.7 M-cell mesh: the time slices lie
+    1.9 GB apart.  The forms of family 10 that address X through the LDS-DMA
+    take 64-bit offsets -- frac_b (the shared form), masked with either hint
+    -- and give the bits of the same call on a compact field; the other
+    forms decline (under REMAP_FLAG_TUNE_HINT: the wave-per-row kernel with
+    64-bit addressing)."""
+    from pyremap_amd import engine
+    m, mm, plan, csr = problem
+    T, L = 5, 64
+    stride = (1 << 28) + 64           # elements: 2 GiB and a bit per slice
+    rng = np.random.default_rng(21)
+    f = rng.standard_normal((T, m.n_a, L))
+    depth = rng.integers(1, L + 1, m.n_a)
+    fm = f.copy()
+    fm[:, np.arange(L)[None, :] >= depth[:, None]] = np.nan
+    fm[:, rng.random(m.n_a) < 0.2, :] = np.nan
+    big = torch.zeros(T * stride, dtype=torch.float64, device=dev)
+    y = torch.empty((T, m.n_b, L), dtype=torch.float64, device=dev)
+
+    def run(field, mode, flags, tune):
+        view = torch.as_strided(big, (T, m.n_a, L), (stride, L, 1))
+        view.copy_(torch.from_numpy(field).to(dev))
+        y.fill_(7.0)
+        engine.apply_strided(
+            plan, big, y, n_batch=T, k_inner=L, x_row_stride=L,
+            x_batch_stride=stride, y_row_stride=L, y_batch_stride=m.n_b * L,
+            mode=mode, threshold=0.3, flags=flags, tune=tune)
+        return y.cpu().numpy()
+
+    ref = _reference(csr, mm['frac_b'], f, 0.3, masked=False)
+    assert_bitwise(run(f, engine.MODE_FRACB, 0, [10, 0, 2, 0, 3, 32]), ref,
+                   'frac_b, shared form, wide batches')
+    assert_bitwise(run(f, engine.MODE_FRACB, engine.FLAG_TUNE_HINT,
+                       [10, 0, 2, 0, 3, 32]), ref, 'frac_b, hint')
+    refm = _reference(csr, mm['frac_b'], fm, 0.3, masked=True)
+    for flags in (engine.FLAG_BATCH_MASKS, engine.FLAG_CELL_MASKS):
+        assert_bitwise(run(fm, engine.MODE_MASKED, flags, [10, 1, 1, 1, 3]),
+                       refm, f'masked, flags {flags}, wide batches')
+    # neither hint: the 8-row groups cannot reach; declined / handed on
+    with pytest.raises(engine.EngineError, match='32-bit offsets'):
+        run(fm, engine.MODE_MASKED, 0, [10, 1, 1, 1, 3])
+    assert_bitwise(run(fm, engine.MODE_MASKED, engine.FLAG_TUNE_HINT,
+                       [10, 1, 1, 1, 3]), refm, 'masked, hint, wide batches')
+    # a mask that changes with time: the time form redoes its groups
+    fv = fm.copy()
+    fv[2, 11, 3] = np.nan
+    fv[4, 200:260, :] = np.nan
+    refv = _reference(csr, mm['frac_b'], fv, 0.3, masked=True)
+    assert_bitwise(run(fv, engine.MODE_MASKED, engine.FLAG_BATCH_MASKS,
+                       [10, 1, 1, 1, 3]), refv, 'varying mask, wide batches')

@@ -48,6 +48,11 @@ def main():
                     help='address the (n_a, K) buffers as K / L batches of L '
                          'levels: n_batch = K / L, k_inner = L, batch stride '
                          'L (what REMAP_FLAG_BATCH_MASKS wants to see)')
+    ap.add_argument('--tnl', type=int, default=0,
+                    help='read the buffers as (T, nCells, K / T) fields -- '
+                         "MPAS's layout: n_batch = T, k_inner = K / T, batch "
+                         'stride n_a * K / T (the mask options then apply to '
+                         'that layout)')
     ap.add_argument('--pairs', default=None,
                     help="';'-separated order|tune[|flags]: the variants, "
                          'instead of the product of --orders x --flags x '
@@ -72,7 +77,16 @@ def main():
     dt = torch.float64 if args.dtype == 'f64' else torch.float32
     xs = [torch.randn((m.n_a, K + args.x_pad), device=dev, dtype=dt)
           for _ in range(args.sets)]
-    if args.mode == 'masked':
+    if args.mode == 'masked' and args.tnl:
+        for x in xs:
+            x3 = x.view(args.tnl, m.n_a, K // args.tnl)
+            x3[:, torch.rand(m.n_a, device=dev) < 0.25, :] = float('nan')
+            if args.mask == 'levels':
+                Lt = K // args.tnl
+                depth = torch.randint(8, Lt + 1, (m.n_a, 1), device=dev)
+                lev = torch.arange(Lt, device=dev)[None]
+                x3.masked_fill_((lev >= depth)[None], float('nan'))
+    elif args.mode == 'masked':
         for x in xs:
             if args.mask == 'cells':      # whole cells missing (land)
                 x[torch.rand(m.n_a, device=dev) < 0.25, :] = float('nan')
@@ -156,6 +170,14 @@ def main():
         plan.patches = patch_sets.get(o)
         plan.groups = group_sets.get(o)
         s = i % args.sets
+        if args.tnl:
+            Lt = K // args.tnl
+            engine.apply_strided(plan, xs[s], ys[s], n_batch=args.tnl,
+                                 k_inner=Lt, x_row_stride=Lt,
+                                 x_batch_stride=m.n_a * Lt, y_row_stride=Lt,
+                                 y_batch_stride=plan.n_b * Lt, mode=mode,
+                                 threshold=0.01, flags=fl, tune=tune)
+            return
         L = args.levels or K
         engine.apply_strided(plan, xs[s], ys[s], n_batch=K // L, k_inner=L,
                              x_row_stride=K + args.x_pad,
