@@ -781,6 +781,39 @@ def pcie_inclusive(args):
     return out
 
 
+def pcie_row(main_w):
+    """
+    The metric workload as every `remap_numpy(ds)` / `ncremap()` caller meets
+    it: the (n_a, K) field in PAGEABLE host memory (numpy), the result back
+    in host memory (remap_numpy.py:254-256, 268: the reference's whole path
+    is host-side).  Upload, launch and download in column panels, both PCIe
+    directions busy (host_path._panel_pipeline).  `[ms, GB/s]`: best of 4
+    calls, bytes over PCIe (X up + Y down) per second.  Never `value`.
+    """
+    import numpy as np
+    import torch
+
+    from pyremap_amd import host_path
+    x = main_w.fields[0].cpu().numpy()
+    dst = main_w.m.dst_dims
+    emode = 'fracb' if main_w.mode == 'fracb' else 'masked'
+    times = []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        y = host_path.remap_host_array(
+            main_w.plan, dst, x, [0], mode=emode,
+            threshold=None if emode == 'fracb' else 0.01).result()
+        times.append(time.perf_counter() - t0)
+        nbytes = x.nbytes + y.nbytes
+        del y
+    t = min(times[1:])
+    return dict(ms=t * 1e3, GBps=nbytes / t / 1e9, first_call_ms=times[0] *
+                1e3, bytes_over_pcie=nbytes, layout=f'{tuple(x.shape)} '
+                f'{x.dtype} pageable numpy in -> float64 numpy out',
+                form='column panels (host_path._panel_pipeline)')
+
+
 def load_traffic(name, K, mode, locality='mesh', family=None):
     """PMC-measured HBM bytes per launch, from a committed rocprofv3 run
     (`traffic_<workload>_mesh.json` for the mesh numbering, the round-2
@@ -1270,6 +1303,11 @@ def compose_line(args, res, world, ceiling, cpu, extra, pipelined,
         'status': status,
         'details': details_path,
     }
+    pcie = extra.get('pcie_inclusive') if isinstance(extra, dict) else None
+    if isinstance(pcie, dict):
+        # host numpy in -> host numpy out (never `value`): [ms, GB/s]
+        line['pcie_inclusive'] = [rnd(pcie['ms']), rnd(pcie['GBps'])] \
+            if 'ms' in pcie else 'error: ' + pcie.get('error', '')[:60]
     details = {
         'line': None,       # (filled in by write_details)
         'result': res,
@@ -1450,6 +1488,14 @@ def main():
         cpu = cpu_baseline(main_w.full, main_w.m, main_w.fields[0],
                            res['mode'], args.cpu_seconds)
         t = mark('cpu_baseline_s', t)
+    if world == 1 and not args.no_extra and args.workload == 'config3' \
+            and not main_w.sharded:
+        try:
+            extra['pcie_inclusive'] = pcie_row(main_w)
+        except Exception as exc:  # noqa: BLE001
+            extra['pcie_inclusive'] = {'error': f'{type(exc).__name__}: '
+                                       f'{exc}'}
+        t = mark('pcie_row_s', t)
     if world == 1 and args.all_workloads and not args.no_extra and \
             args.workload == 'config3':
         main_w.fields = main_w.outs = None

@@ -61,6 +61,44 @@ RING_SLOTS = 4
 #: 326-342) -- the runtime's pageable-copy staging is shared.
 N_UPLOADERS = 1
 
+#: the column-panel pipeline of (n_a, K) host arrays: columns per panel (1
+#: KiB rows of float64: hipMemcpy2DAsync moves such panels at the rate of a
+#: contiguous copy, 53-57 GB/s either way, tools/pcie_panel_probe.py) and the
+#: fewest panels worth the extra launches
+PANEL_COLUMNS = 128
+PANEL_MIN = 3
+
+_hip_runtime = [None]
+
+
+def _hip():
+    """The HIP runtime torch itself uses (2-D copies: torch's strided
+    ``copy_`` between host and device goes through a host-side contiguous
+    copy at 4-5 GB/s)."""
+    if _hip_runtime[0] is None:
+        import ctypes
+        torch = engine._torch()
+        lib = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__),
+                                       'lib', 'libamdhip64.so'))
+        lib.hipMemcpy2DAsync.restype = ctypes.c_int
+        lib.hipMemcpy2DAsync.argtypes = [
+            ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
+            ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int,
+            ctypes.c_void_p]
+        _hip_runtime[0] = lib
+    return _hip_runtime[0]
+
+
+def _copy_2d(dst_ptr, dst_pitch, src_ptr, src_pitch, width, height, kind,
+             stream):
+    import ctypes
+    rc = _hip().hipMemcpy2DAsync(dst_ptr, dst_pitch, src_ptr, src_pitch,
+                                 width, height, kind,
+                                 ctypes.c_void_p(stream.cuda_stream))
+    if rc != 0:
+        raise engine.EngineError(f'hipMemcpy2DAsync failed ({rc})')
+
+
 _streams = {}
 _extra_streams = {}
 _pinned_alive = [0]
@@ -177,12 +215,17 @@ class Pending:
     torch's pool when they are garbage collected.
     """
 
-    def __init__(self, event, out, mask, pinned=(0, 0)):
+    def __init__(self, event, out, mask, pinned=(0, 0), recheck=None):
         self._event = event
         self._out = out
         self._mask = mask
         self._pinned = list(pinned)    # pinned bytes of (out, mask)
         self._done = None
+        # the column-panel pipeline's second look (mode 'auto' taken as
+        # frac_b panel by panel: a NaN found by the device scans means the
+        # whole field over again in the masked mode); called once the
+        # downloads are in
+        self._recheck = recheck
         # a Pending dropped without result() gives its budget back
         self._guard = weakref.finalize(self, _release_pinned, sum(pinned))
 
@@ -192,6 +235,9 @@ class Pending:
         if self._event is not None:
             self._event.synchronize()
             self._event = None
+        if self._recheck is not None:
+            recheck, self._recheck = self._recheck, None
+            recheck()
         # the budget now follows the ARRAYS (views keep their base alive)
         self._guard.detach()
         data = self._out.numpy()
@@ -513,6 +559,21 @@ def _enqueue(plan, dst_grid_dims, values, host, remap_axes, lead, n_batch,
     banded = in_place and host_mask is None and mode != 'auto' and \
         n_batch == 1 and lead == 0 and not multi and \
         values.nbytes >= 4 * CHUNK_BYTES and plan.n_b == plan.n_b_global
+    # a field whose source axes lead, (n_a, K): column panels, both PCIe
+    # directions busy whatever the mesh numbering (mode 'auto' included:
+    # frac_b panel by panel, the masked mode over again if a device scan
+    # meets a NaN)
+    panels = in_place and host_mask is None and n_batch == 1 and \
+        lead == 0 and not multi and plan.n_b == plan.n_b_global and \
+        values.nbytes >= 4 * CHUNK_BYTES and values.flags.c_contiguous and \
+        out_h.is_pinned() and (mask_h is None or mask_h.is_pinned())
+    if panels:
+        got = _panel_pipeline(plan, values, out_h, mask_h, mode, thr, flags,
+                              up, down, main)
+        if got is not None:
+            done, recheck = got
+            return Pending(done, out_h, mask_h, (pin_o, pin_m),
+                           recheck=recheck)
     # (the batch pipeline below streams through chunk-sized buffers instead)
     x_d = torch.empty(values.shape, dtype=host.dtype, device=device) \
         if single or banded else None
@@ -688,6 +749,142 @@ def _enqueue(plan, dst_grid_dims, values, host, remap_axes, lead, n_batch,
     for t in y_slots + (m_slots or []):
         t.record_stream(down)
     return Pending(finished, out_h, mask_h, (pin_o, pin_m))
+
+
+def _panel_pipeline(plan, values, out_h, mask_h, mode, thr, flags, up, down,
+                    main):
+    """
+    A host field whose source axes lead -- ``(n_a, K)``, what the reference
+    flattens every field to (``remap_numpy.py:254-256``) -- in COLUMN PANELS:
+    panel p + 1 comes up (one strided 2-D copy straight from the caller's
+    pageable array, issued by a feeder thread: such a call holds its thread
+    until the bytes are staged) while panel p is remapped and panel p - 1
+    goes down into its columns of the pinned result.  Both PCIe directions
+    stay busy whatever the numbering of the source mesh (the band pipeline
+    needs a numbering no MPAS mesh has): 0.96 GB up + 1.06 GB down in the
+    time of the longer of the two plus one panel, not in their sum.
+
+    ``mode='auto'`` (masked iff the field holds a NaN, the reference's rule
+    :201-204, and no NaN was seen in the strided sample): the panels are
+    remapped in the frac_b mode while a device scan of each looks for NaNs;
+    the returned ``recheck`` reads the scans' flag when the result is asked
+    for and, should it be set, remaps the (still resident) panels again in
+    the masked mode.  Returns ``(event, recheck)`` or ``None`` to decline.
+    """
+    torch = engine._torch()
+    device = plan.device
+    n_a, n_b = plan.n_a, plan.n_b
+    K = values.size // n_a
+    kp = PANEL_COLUMNS
+    n_p = (K + kp - 1) // kp
+    if n_p < PANEL_MIN:
+        return None
+    esize = values.dtype.itemsize
+    tdtype = torch.from_numpy(values.reshape(-1)[:0]).dtype
+    bounds = [(p * kp, min((p + 1) * kp, K)) for p in range(n_p)]
+    x_p = torch.empty((n_p, n_a, kp), dtype=tdtype, device=device)
+    y_p = torch.empty((n_p, n_b, kp), dtype=torch.float64, device=device)
+    m_p = torch.empty((n_p, n_b, kp), dtype=torch.uint8, device=device) \
+        if mask_h is not None else None
+    flag = torch.zeros(1, dtype=torch.int32, device=device) \
+        if mode == 'auto' else None
+    emode = engine.MODE_MASKED if mode == 'masked' else engine.MODE_FRACB
+    src = values.ctypes.data
+    start = torch.cuda.Event()
+    start.record(main)
+    up.wait_event(start)
+    down.wait_event(start)
+    arrivals = queue.Queue()
+
+    def uploader():
+        try:
+            with torch.cuda.device(device):
+                for p, (c0, c1) in enumerate(bounds):
+                    _copy_2d(x_p[p].data_ptr(), kp * esize,
+                             src + c0 * esize, K * esize, (c1 - c0) * esize,
+                             n_a, 1, up)
+                    ev = torch.cuda.Event()
+                    ev.record(up)
+                    arrivals.put(ev)
+        except BaseException as exc:   # noqa: BLE001 - handed over
+            arrivals.put(exc)
+
+    def launch(p, launch_mode):
+        c0, c1 = bounds[p]
+        engine.apply_strided(
+            plan, x_p[p], y_p[p], n_batch=1, k_inner=c1 - c0,
+            x_row_stride=kp, x_batch_stride=0, y_row_stride=kp,
+            y_batch_stride=0, mode=launch_mode,
+            threshold=thr if launch_mode == engine.MODE_MASKED else 0.0,
+            mask_out=m_p[p] if m_p is not None else None, flags=flags)
+
+    def download(p):
+        c0, c1 = bounds[p]
+        _copy_2d(out_h.data_ptr() + c0 * 8, K * 8, y_p[p].data_ptr(),
+                 kp * 8, (c1 - c0) * 8, n_b, 2, down)
+        if m_p is not None:
+            _copy_2d(mask_h.data_ptr() + c0, K, m_p[p].data_ptr(), kp,
+                     c1 - c0, n_b, 2, down)
+
+    feeder = threading.Thread(target=uploader, daemon=True)
+    feeder.start()
+    finished = None
+    try:
+        for p in range(n_p):
+            arrived = arrivals.get()
+            if isinstance(arrived, BaseException):
+                raise arrived
+            main.wait_event(arrived)
+            if flag is not None:
+                # (a panel whose last columns are not there holds what the
+                # allocation held in them: scanned column range only)
+                c0, c1 = bounds[p]
+                if c1 - c0 == kp:
+                    engine.scan_nan(x_p[p], flag)
+                else:
+                    engine.scan_nan(x_p[p][:, :c1 - c0].contiguous(), flag)
+            launch(p, emode)
+            computed = torch.cuda.Event()
+            computed.record(main)
+            down.wait_event(computed)
+            download(p)
+            finished = torch.cuda.Event()
+            finished.record(down)
+    except BaseException:
+        feeder.join()
+        up.synchronize()
+        down.synchronize()
+        raise
+    feeder.join()
+    for t in (x_p, y_p) + ((m_p,) if m_p is not None else ()):
+        t.record_stream(up)
+        t.record_stream(down)
+    if flag is None:
+        return finished, None
+    flag_h = torch.zeros(1, dtype=torch.int32).pin_memory()
+    with torch.cuda.stream(down):
+        down.wait_stream(main)
+        flag_h.copy_(flag, non_blocking=True)
+        finished = torch.cuda.Event()
+        finished.record(down)
+
+    def recheck():
+        if int(flag_h[0]) == 0:
+            return
+        # a NaN the strided sample did not meet: the reference takes the
+        # masked branch for the whole field (remap_numpy.py:201-204) -- the
+        # panels are still here
+        with torch.cuda.device(device):
+            cur = torch.cuda.current_stream(device)
+            for p in range(n_p):
+                launch(p, engine.MODE_MASKED)
+            done = torch.cuda.Event()
+            done.record(cur)
+            down.wait_event(done)
+            for p in range(n_p):
+                download(p)
+            down.synchronize()
+    return finished, recheck
 
 
 def _banded_pipeline(plan, values, host, x_d, out_h, mask_h, mode, thr,

@@ -252,3 +252,74 @@ def test_batches_further_apart_than_32_bit_offsets(dev, problem):
     refv = _reference(csr, mm['frac_b'], fv, 0.3, masked=True)
     assert_bitwise(run(fv, engine.MODE_MASKED, engine.FLAG_BATCH_MASKS,
                        [10, 1, 1, 1, 3]), refv, 'varying mask, wide batches')
+
+
+def test_host_array_column_panels(dev, problem):
+    """host_path._panel_pipeline: an (n_a, K) host array goes up, is remapped
+    and comes down in column panels (strided 2-D copies, both PCIe
+    directions busy) -- the reference's result (remap_numpy.py:254-278) in
+    every mode, for float32 input, a last panel that is not full, masks, and
+    mode 'auto' on a field whose only NaN the strided sample does not meet
+    (the device scans find it: the masked mode over again)."""
+    from oracle import oracle
+    from pyremap_amd import engine, host_path
+    m, mm, plan, csr = problem
+    rng = np.random.default_rng(31)
+    old = host_path.CHUNK_BYTES, host_path.PANEL_COLUMNS
+    host_path.CHUNK_BYTES = 1 << 16       # these small fields qualify
+    calls = []
+    inner = host_path._panel_pipeline
+
+    def spy(*a, **k):
+        out = inner(*a, **k)
+        calls.append(out is not None)
+        return out
+    host_path._panel_pipeline = spy
+    try:
+        for K, kp in ((512, 128), (450, 128), (384, 64)):
+            host_path.PANEL_COLUMNS = kp
+            x = rng.standard_normal((m.n_a, K))
+            holed = x.copy()
+            holed[rng.random(m.n_a) < 0.2, K // 3:] = np.nan
+            rare = x.copy()
+            rare[m.n_a // 2 + 1, K - 3] = np.nan      # one NaN, off the sample
+            assert not host_path._sampled_nan(rare)
+            for field, mode, thr in ((x, 'fracb', None),
+                                     (holed, 'masked', 0.3),
+                                     (holed, 'auto', 0.3), (x, 'auto', 0.3),
+                                     (rare, 'auto', 0.3),
+                                     (x.astype(np.float32), 'fracb', None)):
+                masked = mode == 'masked' or (mode == 'auto' and
+                                              np.isnan(field).any())
+                arg = np.ma.masked_array(field, np.isnan(field)) if masked \
+                    else field
+                ref = oracle.remap_numpy_array(
+                    csr, mm['frac_b'], m.dst_dims, arg, [0],
+                    thr if masked else None)
+                want_mask = mode != 'auto'
+                n0 = len(calls)
+                got = host_path.remap_host_array(
+                    plan, m.dst_dims, field, [0], mode=mode, threshold=thr,
+                    want_mask=want_mask).result()
+                # (a NaN the sample meets decides 'auto' before the upload:
+                # masked, still in panels)
+                assert calls[n0:] == [True], (K, kp, mode, calls[n0:])
+                data = got[0] if want_mask else got
+                what = f'panels K={K} kp={kp} {mode} {field.dtype}'
+                assert_bitwise(data, np.ma.filled(ref, np.nan), what)
+                if want_mask:
+                    assert np.array_equal(got[1], np.ma.getmaskarray(ref)), \
+                        what
+        # too few panels: declined, the plain form answers
+        host_path.PANEL_COLUMNS = 128
+        x = rng.standard_normal((m.n_a, 200))
+        n0 = len(calls)
+        got = host_path.remap_host_array(plan, m.dst_dims, x, [0],
+                                         mode='fracb').result()
+        assert calls[n0:] == [False]
+        ref = oracle.remap_numpy_array(csr, mm['frac_b'], m.dst_dims, x, [0],
+                                       None)
+        assert_bitwise(got, np.ma.filled(ref, np.nan), 'plain form')
+    finally:
+        host_path._panel_pipeline = inner
+        host_path.CHUNK_BYTES, host_path.PANEL_COLUMNS = old
