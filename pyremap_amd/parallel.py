@@ -436,16 +436,29 @@ class ShardedRemap:
         # arithmetic on a meta tensor)
         x3, lead_shape, tail_shape, unpermute = _flatten_source_axes(
             like, remap_axes)
+        hint = 0
         if mode == 'auto':
             masked = False
             if threshold is not None:
-                flag = torch.zeros(1, dtype=torch.int32,
-                                   device=self.plan.device)
+                # the branch (remap_numpy.py:201-204) and the form of the
+                # masked launch that suits the field -- whole cells missing,
+                # the same mask in every batch -- from ONE layout-aware scan
+                # on `src`, four words to every rank
+                kinds = torch.zeros(4, dtype=torch.int32,
+                                    device=self.plan.device)
                 if self.rank == src:
-                    flag[0] = int(bool(torch.isnan(field).any()))
+                    x3c = x3.contiguous()
+                    if x3c.dtype not in (torch.float64, torch.float32):
+                        x3c = x3c.to(torch.float64)
+                    engine.scan_nan_layout(x3c, int(x3c.shape[1]),
+                                           int(x3c.shape[0]),
+                                           int(x3c.shape[2]), kinds)
                 if self.world_size > 1:
-                    dist.broadcast(flag, src=src, group=self.group)
-                masked = bool(int(flag[0]))
+                    dist.broadcast(kinds, src=src, group=self.group)
+                found = kinds.tolist()
+                masked = bool(found[0])
+                hint = {1: engine.FLAG_CELL_MASKS,
+                        2: engine.FLAG_BATCH_MASKS}.get(found[3], 0)
             emode = engine.MODE_MASKED if masked else engine.MODE_FRACB
         else:
             emode = {'masked': engine.MODE_MASKED, 'fracb': engine.MODE_FRACB,
@@ -456,7 +469,8 @@ class ShardedRemap:
         res = engine.remap_tensor(
             self.plan, None, packed, [1], emode,
             threshold=float(threshold) if emode == engine.MODE_MASKED
-            else 0.0, flags=flags, want_mask=want_mask)
+            else 0.0, flags=(flags | hint) if emode == engine.MODE_MASKED
+            else flags, want_mask=want_mask)
         dst_shape = [int(d) for d in dst_grid_dims] \
             if dst_grid_dims is not None else [self._full.n_b]
 
@@ -551,6 +565,16 @@ class MultiDeviceRemap:
                 f'the remapped axes hold {x3.shape[1]} source cells but the '
                 f'mapping has n_a = {self.n_a}')
         n_batch, inner = int(x3.shape[0]), int(x3.shape[2])
+        if _gate is not None:
+            # remap_numpy.py:201-204 decided on the device, ONCE for the
+            # whole field (the branch is a property of the field, not of a
+            # shard's packed rows): the layout-aware scan on the source
+            # device -- any NaN; whole cells missing; the same mask in every
+            # batch; the masked form that suits (engine.scan_nan_layout)
+            with torch.cuda.device(self.device):
+                x3 = x3.contiguous()
+                _gate = torch.zeros(4, dtype=torch.int32, device=self.device)
+                engine.scan_nan_layout(x3, self.n_a, n_batch, inner, _gate)
         slabs, masks = [], []
         for shard in self.shards:
             dev = shard.plan.device
@@ -568,16 +592,32 @@ class MultiDeviceRemap:
                         shard.plan, None, xp, [1], mode, threshold=threshold,
                         want_mask=want_mask, flags=flags, out=y, mask_out=m)
                 else:
-                    # remap_numpy.py:201-204 decided on the device: both
-                    # branches enqueued, each gated on the NaN flag
+                    # every candidate launch enqueued, each gated on the
+                    # scan's words (copied to the shard's device): frac_b,
+                    # and the masked mode in the form that suits -- as
+                    # engine.remap_tensor_auto_mode does on one device
                     gate = _gate.to(dev, non_blocking=True)
-                    engine.remap_tensor(
-                        shard.plan, None, xp, [1], engine.MODE_MASKED,
-                        threshold=threshold, flags=flags, out=y, gate=gate,
-                        gate_value=1)
+                    hints = engine.FLAG_CELL_MASKS | engine.FLAG_BATCH_MASKS
+                    base = flags & ~hints
+                    if engine.cell_mask_form(shard.plan):
+                        forms = [(engine.FLAG_CELL_MASKS, 1)]
+                        if n_batch >= 3:
+                            forms.append((engine.FLAG_BATCH_MASKS, 2))
+                        forms.append((0, 3))
+                        for hint, value in forms:
+                            engine.remap_tensor(
+                                shard.plan, None, xp, [1],
+                                engine.MODE_MASKED, threshold=threshold,
+                                flags=base | hint, out=y, gate=gate[3:],
+                                gate_value=value)
+                    else:
+                        engine.remap_tensor(
+                            shard.plan, None, xp, [1], engine.MODE_MASKED,
+                            threshold=threshold, flags=base, out=y,
+                            gate=gate, gate_value=1)
                     engine.remap_tensor(
                         shard.plan, None, xp, [1], engine.MODE_FRACB,
-                        flags=flags, out=y, gate=gate, gate_value=0)
+                        flags=base, out=y, gate=gate, gate_value=0)
             slabs.append(y)
             masks.append(m)
         if not gather:
@@ -601,16 +641,10 @@ class MultiDeviceRemap:
     def remap_tensor_auto_mode(self, dst_grid_dims, field, remap_axes,
                                threshold, flags=0):
         """``engine.remap_tensor_auto_mode`` over the shards: one NaN scan
-        on the source device, two gated launches per shard."""
+        of the whole field on the source device (layout-aware: it also names
+        the form of the masked launch), the gated launches per shard -- two,
+        or four on entry-rich mappings."""
         from pyremap_amd import engine
-        torch = _torch()
-        field = field.to(self.device)
-        if field.dtype not in (torch.float64, torch.float32):
-            field = field.to(torch.float64)
-        field = field.contiguous()
-        with torch.cuda.device(self.device):
-            flag = torch.zeros(1, dtype=torch.int32, device=self.device)
-            engine.scan_nan(field, flag)
         return self.remap_tensor(dst_grid_dims, field, remap_axes,
                                  engine.MODE_MASKED, threshold=threshold,
-                                 flags=flags, _gate=flag)
+                                 flags=flags, _gate=True)

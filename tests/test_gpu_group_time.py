@@ -323,3 +323,32 @@ def test_host_array_column_panels(dev, problem):
     finally:
         host_path._panel_pipeline = inner
         host_path.CHUNK_BYTES, host_path.PANEL_COLUMNS = old
+
+
+@pytest.mark.parametrize('name', ['config3', 'headline', 'config4',
+                                  'config5'])
+def test_csr_from_coo_at_baseline_scale_against_the_oracle(dev, name):
+    """`remap_csr_from_coo` (the device COO -> CSR of `_load_mapping`,
+    remap_numpy.py:134-137: stable sort by (row, col), duplicates summed in
+    input order) on BASELINE's own mappings -- config 3's 912 860 triplets
+    (45 625 of them duplicates that merge), the headline's 8 million, config
+    4's 110 million and config 5's 95 million (16.5 million duplicates) --
+    against the oracle's C restatement of scipy's coo -> csr: row pointers and
+    column indices equal, every weight bit for bit.  (The full-size parity
+    tests hand the oracle the DEVICE-built CSR; this is the test that the
+    CSR itself is the reference's; tools/csr_at_scale.py prints the line
+    recorded in profiles/r06_analysis/csr_at_scale.txt.)"""
+    from oracle import oracle
+    from pyremap_amd import engine, synthetic
+    m = synthetic.make_config(name, device=dev, locality='mesh')
+    plan = engine.RemapPlan.from_triplets(m.row, m.col, m.S, m.frac_b, m.n_a,
+                                          m.n_b, index_base=1, device=dev)
+    rowptr, col, val = plan.to_host_csr()
+    mm = m.numpy()
+    assert mm['row'].size > plan.nnz or name == 'config4'   # duplicates merge
+    ref = oracle.coo_to_csr(mm['row'] - 1, mm['col'] - 1, mm['S'], m.n_b,
+                            m.n_a)
+    assert ref.nnz == plan.nnz
+    assert np.array_equal(rowptr, ref.indptr)
+    assert np.array_equal(col, ref.indices)
+    assert np.array_equal(val.view(np.int64), ref.data.view(np.int64))

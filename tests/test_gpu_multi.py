@@ -529,3 +529,61 @@ def test_shards_without_entries(dev):
                                       threshold=thr)
             assert_bitwise(got.cpu().numpy(), want.cpu().numpy(),
                            f'{shape} {mode}')
+
+
+def test_entry_rich_shards_take_the_shared_and_the_masked_forms(dev):
+    """Round 6: a packed row shard of an entry-rich mapping schedules itself
+    like the whole mapping -- the shared lists (`spmm_groupshare`), and under
+    `remap_tensor_auto_mode` the masked form the layout-aware scan names
+    (whole cells / the same mask in every batch / neither) -- and N shards
+    give the bits of the one-device plan, which are the oracle's
+    (remap_numpy.py:201-204, 258-278)."""
+    from oracle import oracle
+    from pyremap_amd import engine, synthetic
+    from pyremap_amd.parallel import MultiDeviceRemap
+    m = synthetic.conservative_map(4000, (60, 80), 10, 24, seed=4,
+                                   device=dev, signed=True, locality='mesh')
+    plan = engine.RemapPlan.from_triplets(m.row, m.col, m.S, m.frac_b,
+                                          m.n_a, m.n_b, device=dev)
+    plan.auto_schedule(m.dst_dims)
+    multi = MultiDeviceRemap(plan, [dev, dev, dev], grid_dims=m.dst_dims)
+    for shard in multi.shards:
+        g = shard.plan.groups
+        assert g is not None and g['rows'] == 8 and 'share' in g
+        assert shard.plan.default_tune[engine.MODE_FRACB][5] == 32
+    rowptr, col, val = plan.to_host_csr()
+    csr = oracle.OracleCSR(rowptr, col, val, (m.n_b, m.n_a))
+    frac_b = m.frac_b.cpu().numpy()
+    rng = np.random.default_rng(6)
+    T, L = 6, 64
+    base = rng.standard_normal((T, m.n_a, L))
+    land = base.copy()
+    land[:, rng.random(m.n_a) < 0.25, :] = np.nan
+    depth = rng.integers(1, L + 1, m.n_a)
+    bathy = land.copy()
+    bathy[:, np.arange(L)[None, :] >= depth[:, None]] = np.nan
+    vary = bathy.copy()
+    vary[3, 17, 2] = np.nan
+    for tag, f in (('no NaN', base), ('land', land), ('bathymetry', bathy),
+                   ('varying', vary)):
+        fd = torch.from_numpy(f).to(dev)
+        one = engine.remap_tensor_auto_mode(plan, m.dst_dims, fd, [1], 0.3)
+        many = multi.remap_tensor_auto_mode(m.dst_dims, fd, [1], 0.3)
+        flat = np.ascontiguousarray(f.transpose(1, 0, 2)).reshape(m.n_a, -1)
+        masked = bool(np.isnan(flat).any())
+        ref, ref_mask = oracle.remap_flat(csr, frac_b, flat, masked, 0.3)
+        ref = ref.copy()
+        ref[ref_mask] = np.nan
+        ref = ref.reshape(m.n_b, T, L).transpose(1, 0, 2)
+        assert_bitwise(one.cpu().numpy().reshape(ref.shape), ref,
+                       f'one device, {tag}')
+        assert_bitwise(many.cpu().numpy().reshape(ref.shape), ref,
+                       f'three shards, {tag}')
+    # the frac_b mode on (n_a, K): the shared form per shard
+    x = rng.standard_normal((m.n_a, 384))
+    xd = torch.from_numpy(x).to(dev)
+    ref, ref_mask = oracle.remap_flat(csr, frac_b, x, False, 0.0)
+    ref = ref.copy()
+    ref[ref_mask] = np.nan
+    y = multi.remap_tensor(m.dst_dims, xd, [0], engine.MODE_FRACB)
+    assert_bitwise(y.cpu().numpy().reshape(m.n_b, -1), ref, 'shards, frac_b')
