@@ -366,9 +366,8 @@ typedef struct remap_apply_args {
      *         26 / 28: the rolling form with 6 / 8 in flight (float64, even
      *         strides; spmm_grouproll.h: measured, not chosen); 9: keep the
      *         per-lane masked form under REMAP_FLAG_CELL_MASKS; 32: the
-     *         shared form (share_* below; tune[2] = K tiles per wave, 1 or
-     *         2; tune[1] = 10 * union entries per step + ring buffers: 82,
-     *         the default, or 83 / 43 / 44)
+     *         shared form (share_* below: the frac_b and raw modes;
+     *         tune[2] = K tiles per wave, 1 or 2)
      * tune[6..7] reserved, must be 0 (a -DREMAP_DIAG build of the library,
      *         tools/build_diag.py, reads bottleneck-analysis switches from
      *         them; this build rejects them) */
@@ -413,9 +412,11 @@ typedef struct remap_apply_args {
      * from global memory into an LDS ring (LDS-DMA) and every wave adds the
      * entries its own rows own from there (csrc/spmm_groupshare.h); a row
      * still adds its entries in ascending column order, so results are
-     * unchanged.  Used by family 10 with tune[5] = 32 on float64 fields
-     * with even strides and more than 128 columns; built by
-     * remap_share_build.                                                   */
+     * unchanged.  Used by family 10 on float64 fields with even strides:
+     * with tune[5] = 32 in the frac_b and raw modes on more than 128
+     * columns, with REMAP_FLAG_BATCH_MASKS in the masked mode (share_waves
+     * = 4: the shape the kernels are built in; remap_share_build also makes
+     * the lists of 2 groups).                                              */
     const int64_t *share_meta;  /* (device) 2 * (n_super + 1)               */
     const int32_t *share_col;   /* (device) union entries (+ 256 readable)  */
     const int32_t *share_mask;  /* (device) union entries (+ 256 readable)  */

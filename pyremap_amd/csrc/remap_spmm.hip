@@ -652,64 +652,36 @@ typedef void (*share_fn)(const KParams, const uint32_t, const int64_t *,
                          const int64_t *, const int32_t *, const int32_t *,
                          const double *);
 
-template <int TILES, int W, int UNR, int NBUF, bool FMA>
-share_fn pick_groupshare_mode(int mode)
+// (built, measured on config 5 and NOT instantiated here -- the template
+// keeps the parameters: 2-wave workgroups over 4 x 4 tiles, 28.5 ms against
+// 20.5; rings of 8 x 3, 4 x 3, 4 x 4 entries x buffers, 31.2 / 21.4 / 21.2;
+// the masked mode with per-lane normalisers, 32.1 at one K tile and 37.8 at
+// two against 27.0 of the 8-row groups: profiles/r06_analysis/
+// config5_share.md.  The masked mode's shared form is spmm_timeshare.)
+template <int TILES, bool FMA>
+share_fn pick_groupshare(int mode)
 {
-    switch (mode) {
-    case REMAP_MODE_RAW:
-        return spmm_groupshare<TILES, REMAP_MODE_RAW, FMA, W, UNR, NBUF, 2>;
-    case REMAP_MODE_FRACB:
-        return spmm_groupshare<TILES, REMAP_MODE_FRACB, FMA, W, UNR, NBUF, 2>;
-    default:
-        return spmm_groupshare<TILES, REMAP_MODE_MASKED, FMA, W, UNR, NBUF,
-                               2>;
-    }
-}
-
-// ring shapes (entries per step, buffers): 8 x 2 is the default; the others
-// exist for the 4-wave form without REMAP_FLAG_FMA (A/B material)
-template <int TILES>
-share_fn pick_groupshare(int W, int unr, int nbuf, int mode, bool fma)
-{
-    if (W == 2)
-        return fma ? pick_groupshare_mode<TILES, 2, 8, 2, true>(mode)
-                   : pick_groupshare_mode<TILES, 2, 8, 2, false>(mode);
-    if (fma)
-        return pick_groupshare_mode<TILES, 4, 8, 2, true>(mode);
-    if (unr == 8 && nbuf == 3)
-        return pick_groupshare_mode<TILES, 4, 8, 3, false>(mode);
-    if (unr == 4 && nbuf == 3)
-        return pick_groupshare_mode<TILES, 4, 4, 3, false>(mode);
-    if (unr == 4 && nbuf == 4)
-        return pick_groupshare_mode<TILES, 4, 4, 4, false>(mode);
-    return pick_groupshare_mode<TILES, 4, 8, 2, false>(mode);
+    return mode == REMAP_MODE_RAW
+               ? spmm_groupshare<TILES, REMAP_MODE_RAW, FMA, 4, 8, 2, 2>
+               : spmm_groupshare<TILES, REMAP_MODE_FRACB, FMA, 4, 8, 2, 2>;
 }
 
 int launch_groupshare(const remap_apply_args *a, const KParams &p, int tiles,
-                      int unr, int nbuf, bool fma, int64_t grid,
-                      hipStream_t stream)
+                      bool fma, int64_t grid, hipStream_t stream)
 {
-    const int W = a->share_waves;
-    if (W == 2 || fma) {   // (the shapes these forms are built in)
-        unr = 8;
-        nbuf = 2;
-    }
-    share_fn fn = tiles == 1
-                      ? pick_groupshare<1>(W, unr, nbuf, a->mode, fma)
-                      : pick_groupshare<2>(W, unr, nbuf, a->mode, fma);
-    // the ring: nbuf buffers of unr entries, 1 KiB per entry and K tile;
-    // nbuf x W slots of a step's weights; slack for the lanes that read
-    // past the last slot
+    share_fn fn = tiles == 1 ? (fma ? pick_groupshare<1, true>(a->mode)
+                                    : pick_groupshare<1, false>(a->mode))
+                             : (fma ? pick_groupshare<2, true>(a->mode)
+                                    : pick_groupshare<2, false>(a->mode));
+    // the ring: two buffers of 8 entries, 1 KiB per entry and K tile; 2 x 4
+    // slots of a step's weights; slack for the lanes that read past the last
+    // slot
     uint32_t lds_bytes =
-        static_cast<uint32_t>(nbuf) *
-            (static_cast<uint32_t>(unr) * 1024u *
-                 static_cast<uint32_t>(tiles) +
-             static_cast<uint32_t>(W) * static_cast<uint32_t>(unr) * 64u) +
-        512u;
+        2u * (8u * 1024u * static_cast<uint32_t>(tiles) + 4u * 512u) + 512u;
     REMAP_HIP_CHECK(diag_lds_throttle(a, reinterpret_cast<const void *>(fn),
                                       lds_bytes));
     hipLaunchKernelGGL(fn, dim3(static_cast<uint32_t>(grid)),
-                       dim3(kWave * W), lds_bytes, stream, p, a->flags,
+                       dim3(kWave * 4), lds_bytes, stream, p, a->flags,
                        a->group_meta, a->group_w, a->group_rid, a->group_frac,
                        a->share_meta, a->share_col, a->share_mask,
                        static_cast<const double *>(a->X));
@@ -976,7 +948,7 @@ bool wide_share(const remap_apply_args *a, const Call &c)
         return a->share_waves == 4 && a->n_batch >= 3 &&
                (a->flags & (REMAP_FLAG_BATCH_MASKS | REMAP_FLAG_CELL_MASKS)) &&
                (a->tune[5] == 0 || a->tune[5] == 32);
-    return a->tune[5] == 32 && c.K > 128;
+    return a->share_waves == 4 && a->tune[5] == 32 && c.K > 128;
 }
 
 // REMAP_FLAG_TUNE_HINT: can the preferred family serve this call?
@@ -1113,22 +1085,13 @@ int run_rowgroup(const remap_apply_args *a, const Call &c, KParams p,
     // of the same schedule (a preference under REMAP_FLAG_TUNE_HINT, an
     // error otherwise).
     if (a->tune[5] == 32) {
-        const bool can = c.share_ok && c.dma16 && c.K > 128 &&
+        const bool can = c.share_ok && a->share_waves == 4 && c.dma16 &&
+                         c.K > 128 && a->mode != REMAP_MODE_MASKED &&
                          a->x_src_fold == 0 && a->x_row_stride >= 0 &&
                          a->x_row_stride < (int64_t(1) << 29);
         if (can) {
-            // K tiles per wave: 2 (256 columns per workgroup and step; the
-            // masked mode's per-lane normalisers leave room for one)
-            int tiles = a->tune[2];
-            if (tiles != 1 && tiles != 2)
-                tiles = a->mode == REMAP_MODE_MASKED ? 1 : 2;
-            // ring shape, tune[1] = 10 * entries per step + buffers: 82
-            // (the default), 83, 43, 44
-            const int unr = a->tune[1] / 10 == 4 ? 4 : 8;
-            const int nbuf = (a->tune[1] % 10 >= 2 && a->tune[1] % 10 <= 4 &&
-                              a->tune[1] >= 40)
-                                 ? a->tune[1] % 10
-                                 : 2;
+            // K tiles per wave: 2 (256 columns per workgroup and step)
+            const int tiles = a->tune[2] == 1 ? 1 : 2;
             p.rows_per_wave = 1;
             const int64_t k_chunks =
                 shape_tiles(p, a, c.K, kWave * 2, tiles);
@@ -1141,14 +1104,14 @@ int run_rowgroup(const remap_apply_args *a, const Call &c, KParams p,
                 return rc;
             if (a->tune[4] == 3)
                 p.xcd_map |= 2;
-            return launch_groupshare(a, p, tiles, unr, nbuf, c.fma, grid,
-                                     stream);
+            return launch_groupshare(a, p, tiles, c.fma, grid, stream);
         }
         if (!(a->flags & REMAP_FLAG_TUNE_HINT))
             return fail(REMAP_ERR_UNSUPPORTED,
                         "remap_apply_f64: the shared form (tune[5] = 32) "
-                        "serves float64 fields of more than 128 even-strided "
-                        "columns on a plan with share_* lists");
+                        "serves the frac_b and raw modes on float64 fields "
+                        "of more than 128 even-strided columns, on a plan "
+                        "with share_* lists of 4 groups");
     }
     // REMAP_FLAG_BATCH_MASKS: the masked mode of a field of several batches
     // whose mask is expected not to change from batch to batch -- (Time,

@@ -336,11 +336,17 @@ __device__ __forceinline__ void finish_row_uniform(
                     y[t][v] = __builtin_fma(rem, r, q0);
                 }
         } else {
+            // (rare: one division after the other -- interleaved by the
+            // scheduler, four 11-instruction sequences hold enough
+            // temporaries to spill in the kernels that run at the register
+            // limit of three waves per SIMD)
 #pragma unroll
             for (int t = 0; t < TILES; ++t)
 #pragma unroll
-                for (int v = 0; v < VEC; ++v)
+                for (int v = 0; v < VEC; ++v) {
                     y[t][v] = acc[t][v] / fb;
+                    asm volatile("" : "+v"(y[t][v]));
+                }
         }
     }
     bool ok[VEC];

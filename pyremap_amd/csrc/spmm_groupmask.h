@@ -151,14 +151,18 @@ __attribute__((amdgpu_waves_per_eu(3, 8))) void spmm_groupmask(
 #pragma unroll
     for (int t = 0; t < TILES; ++t)
         xo[t] = static_cast<uint32_t>(xoff[t] * sizeof(XT));
-    const int64_t n_groups_here = (p.row_end - p.row_begin + G - 1) / G;
+    // (32 bits: the host checked the grid; a 64-bit count parked in a VGPR
+    // pair for want of SGPRs was one of this kernel's two spills)
+    const int n_groups_here =
+        static_cast<int>((p.row_end - p.row_begin + G - 1) / G);
     const int wpb = static_cast<int>(blockDim.x) >> 6;
-    const int64_t block_g0 = rb * (int64_t)(wpb * p.rows_per_wave);
+    const int block_g0 = static_cast<int>(rb) * (wpb * p.rows_per_wave);
 
     for (int r = 0; r < p.rows_per_wave; ++r) {
-        const int64_t g = block_g0 + (int64_t)r * wpb + wave;
-        if (g >= n_groups_here)
+        const int g32 = block_g0 + r * wpb + wave;
+        if (g32 >= n_groups_here)
             break;
+        const int64_t g = g32;
         const int64_t slot0 = g * G;
         const int nmem = (p.row_end - p.row_begin - slot0) < G
                              ? static_cast<int>(p.row_end - p.row_begin -
@@ -292,9 +296,22 @@ __attribute__((amdgpu_waves_per_eu(3, 8))) void spmm_groupmask(
                         // the row's normaliser is one number for the whole
                         // wave: the frac_b mode's epilogue (one reciprocal
                         // per row), `den > thr` in place of `frac_b > 0`
-                        finish_row_uniform<VEC, TILES>(
-                            p, rid[m], den_u[m], den_u[m] > p.thr, act, yoff,
-                            acc[m]);
+                        // (a tile at a time: the results of both tiles
+                        // held together cost the four registers this kernel
+                        // does not have at three waves per SIMD -- two
+                        // spills; the reciprocal is refined once more)
+#pragma unroll
+                        for (int t = 0; t < TILES; ++t) {
+                            const bool act1[1] = {act[t]};
+                            const int64_t yoff1[1] = {yoff[t]};
+                            double acc1[1][VEC];
+#pragma unroll
+                            for (int v = 0; v < VEC; ++v)
+                                acc1[0][v] = acc[m][t][v];
+                            finish_row_uniform<VEC, 1>(
+                                p, rid[m], den_u[m], den_u[m] > p.thr, act1,
+                                yoff1, acc1);
+                        }
                     }
                 }
             }

@@ -88,63 +88,51 @@ def test_shared_lists_match_a_numpy_restatement(dev, share, two_d):
             y * mx + x for y in range(ty) for x in range(tx))
 
 
-@pytest.mark.parametrize('share', [2, 4])
 @pytest.mark.parametrize('K', [130, 192, 256, 300, 1024])
-def test_shared_form_bitwise(dev, share, K):
-    """Three modes, one or two K tiles per wave, the ring shapes (entries per
-    step x buffers: 8 x 2, 8 x 3, 4 x 3, 4 x 4), the work-list orders; NaNs in
-    the field (propagated in the frac_b / raw modes, masked in the masked
-    mode)."""
+def test_shared_form_bitwise(dev, K):
+    """The frac_b and raw modes, one or two K tiles per wave, the work-list
+    orders; NaNs in the field propagate as the reference lets them
+    (remap_numpy.py:268: raw data through `matrix.dot`)."""
     from pyremap_amd import engine
-    m, mm, plan, csr = _problem(dev, share)
-    fields = _fields(m.n_a, K, K + share)
+    m, mm, plan, csr = _problem(dev, 4)
+    fields = _fields(m.n_a, K, K + 4)
     for tiles in (1, 2):
-        for shape, order in ((0, 3), (83, 2), (43, 1), (44, 3)):
-            tune = [10, shape, tiles, 0, order, 32]
-            for mode, thr in ((engine.MODE_FRACB, 0.0),
-                              (engine.MODE_RAW, 0.0),
-                              (engine.MODE_MASKED, 0.3)):
+        for order in (3, 2, 1):
+            tune = [10, 0, tiles, 0, order, 32]
+            for mode in (engine.MODE_FRACB, engine.MODE_RAW):
                 for tag, x in fields:
-                    if mode != engine.MODE_MASKED and tag not in (
-                            'no NaN', 'single values'):
+                    if tag not in ('no NaN', 'single values'):
                         continue
-                    _check(plan, csr, mm['frac_b'], x, dev, mode, thr, tune,
-                           f'share {share} K={K} {tag} tune={tune} '
-                           f'mode={mode}')
+                    _check(plan, csr, mm['frac_b'], x, dev, mode, 0.0, tune,
+                           f'share K={K} {tag} tune={tune} mode={mode}')
 
 
-@pytest.mark.parametrize('share', [2, 4])
-def test_shared_form_long_lists_one_dimensional_and_fma(dev, share):
-    """Lists of more than 64 and more than 128 union entries (the lane-held
-    blocks of columns and masks wrap), a 1-D destination (supergroups of
-    consecutive rows, the last one partial), REMAP_FLAG_FMA at rtol 1e-13."""
+def test_shared_form_long_lists_one_dimensional_and_fma(dev):
+    """Lists of more than 128 union entries (a second segment of lane-held
+    columns and masks), a 1-D destination (supergroups of consecutive rows,
+    the last one partial), REMAP_FLAG_FMA at rtol 1e-13."""
     from oracle import oracle
     from pyremap_amd import engine
-    m, mm, plan, csr = _problem(dev, share, n_a=700, dims=(30, 44),
-                                k=(24, 60), seed=11)
+    m, mm, plan, csr = _problem(dev, 4, n_a=700, dims=(30, 44), k=(24, 60),
+                                seed=11)
     meta = plan.groups['share']['meta'][:, 0].cpu().numpy()
     longest = int(np.diff(meta).max())
-    assert longest > 64 * (1 if share == 2 else 2), longest   # segments of 128
+    assert longest > 128, longest   # segments of 128
     rng = np.random.default_rng(3)
     x = rng.standard_normal((m.n_a, 384))
-    for tune in ([10, 0, 2, 0, 3, 32], [10, 44, 1, 0, 2, 32],
-                 [10, 83, 2, 0, 3, 32], [10, 43, 2, 0, 3, 32]):
-        for mode, thr in ((engine.MODE_FRACB, 0.0), (engine.MODE_MASKED, 0.2)):
-            xm = x.copy()
-            if mode == engine.MODE_MASKED:
-                xm[rng.random(m.n_a) < 0.3] = np.nan
-            _check(plan, csr, mm['frac_b'], xm, dev, mode, thr, tune,
-                   f'long lists, share {share} tune={tune} mode={mode}')
+    for tune in ([10, 0, 2, 0, 3, 32], [10, 0, 1, 0, 2, 32]):
+        _check(plan, csr, mm['frac_b'], x, dev, engine.MODE_FRACB, 0.0, tune,
+               f'long lists, tune={tune}')
     # 1-D destination, n_b no multiple of the supergroup
-    m1, mm1, plan1, csr1 = _problem(dev, share, n_a=900, dims=(1, 1013),
+    m1, mm1, plan1, csr1 = _problem(dev, 4, n_a=900, dims=(1, 1013),
                                     k=(5, 14), seed=2, two_d=False)
     x1 = rng.standard_normal((m1.n_a, 258))
     _check(plan1, csr1, mm1['frac_b'], x1, dev, engine.MODE_FRACB, 0.0,
-           [10, 0, 2, 2, 3, 32], f'1-D, share {share}')
+           [10, 0, 2, 0, 3, 32], '1-D')
     # fused multiply-add: opt-in, close
     xd = torch.from_numpy(x).to(dev)
     y = engine.remap_tensor(plan, None, xd, [0], engine.MODE_FRACB,
-                            tune=[10, 0, 2, 2, 3, 32],
+                            tune=[10, 0, 2, 0, 3, 32],
                             flags=engine.FLAG_FMA)
     ref, ref_mask = oracle.remap_flat(csr, mm['frac_b'], x, False, 0.0)
     ok = ~ref_mask
@@ -154,9 +142,9 @@ def test_shared_form_long_lists_one_dimensional_and_fma(dev, share):
 
 def test_shared_form_layouts_and_what_it_declines(dev):
     """(Time, nCells, L) in place (batch strides, 256 levels and 2 x 96);
-    float32 fields, few columns and odd strides are declined -- an error
-    when demanded, the 8-row groups of the same schedule under
-    REMAP_FLAG_TUNE_HINT (same bits)."""
+    float32 fields, few columns, odd strides, the masked mode and lists of
+    two groups are declined -- an error when demanded, the 8-row groups of
+    the same schedule under REMAP_FLAG_TUNE_HINT (same bits)."""
     from oracle import oracle
     from pyremap_amd import engine
     m, mm, plan, csr = _problem(dev, 4)
@@ -184,6 +172,21 @@ def test_shared_form_layouts_and_what_it_declines(dev):
                                 tune=tune)
         _check(plan, csr, mm['frac_b'], field, dev, engine.MODE_FRACB, 0.0,
                tune, what, flags=engine.FLAG_TUNE_HINT)
+    # the masked mode keeps the 8-row groups (its shared form is
+    # spmm_timeshare, under REMAP_FLAG_BATCH_MASKS); lists of two groups have
+    # no kernel
+    holed = rng.standard_normal((m.n_a, 256))
+    holed[rng.random(m.n_a) < 0.2] = np.nan
+    with pytest.raises(engine.EngineError, match='shared form'):
+        engine.remap_tensor(plan, None, torch.from_numpy(holed).to(dev), [0],
+                            engine.MODE_MASKED, threshold=0.3, tune=tune)
+    _check(plan, csr, mm['frac_b'], holed, dev, engine.MODE_MASKED, 0.3,
+           tune, 'masked, hint', flags=engine.FLAG_TUNE_HINT)
+    m2, mm2, plan2, csr2 = _problem(dev, 2)
+    with pytest.raises(engine.EngineError, match='shared form'):
+        engine.remap_tensor(plan2, None, torch.from_numpy(
+            rng.standard_normal((m2.n_a, 256))).to(dev), [0],
+            engine.MODE_FRACB, tune=tune)
     # without the lists the switch is an error as well
     plan.build_groups(m.dst_dims, super_tile=32, rows=8)
     with pytest.raises(engine.EngineError, match='shared form'):

@@ -6,6 +6,10 @@ waves per SIMD they allow (MI355X_MICROARCH.md, register files: 512 VGPRs per
 lane per SIMD, granule 8).
 
     python tools/kernel_regs.py [filter] [-D...]
+
+KERNEL_REGS=--fail-on-spill: exit 1 if any (listed) kernel spills VGPRs --
+tools/round_check.sh runs it so (a spill is scratch traffic in a kernel the
+dispatcher may pick).
 """
 import os
 import re
@@ -50,6 +54,7 @@ def main():
     vg = re.findall(r'^\s+\.vgpr_count:\s+(\d+)$', s, re.M)
     sg = re.findall(r'^\s+\.sgpr_count:\s+(\d+)$', s, re.M)
     sp = re.findall(r'^\s+\.vgpr_spill_count:\s+(\d+)$', s, re.M)
+    spilled = []
     for n, v, g, x in zip(demangle(names), vg, sg, sp):
         n = n.replace('remap::(anonymous namespace)::', '')
         n = n.replace('void ', '').split('(')[0]
@@ -59,6 +64,12 @@ def main():
         waves = min(8, 512 // max(alloc, 8))
         print(f'{n:64s} vgpr {v:>4} sgpr {g:>4} spill {x:>3} '
               f'waves/SIMD {waves}')
+        if int(x):
+            spilled.append(n)
+    if '--fail-on-spill' in os.environ.get('KERNEL_REGS', '') and spilled:
+        print(f'FAIL: {len(spilled)} kernel(s) spill VGPRs: '
+              f'{spilled[:4]}')
+        sys.exit(1)
 
 
 if __name__ == '__main__':

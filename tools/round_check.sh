@@ -12,6 +12,9 @@ mkdir -p gpurun_out
 # the DPP read hazard (inline-asm DPP operations: LLVM does not check them)
 python tools/dpp_hazard_scan.py > gpurun_out/dpp_hazard_scan.log 2>&1 || { cat gpurun_out/dpp_hazard_scan.log; echo "FAIL: DPP hazard"; exit 1; }
 tail -1 gpurun_out/dpp_hazard_scan.log
+# no kernel of the library spills VGPRs (hipcc present: the box has ROCm)
+KERNEL_REGS=--fail-on-spill python tools/kernel_regs.py > gpurun_out/kernel_regs.log 2>&1 || { tail -3 gpurun_out/kernel_regs.log; echo "FAIL: VGPR spills"; exit 1; }
+echo "kernel_regs: $(grep -c vgpr gpurun_out/kernel_regs.log) kernels, no VGPR spill"
 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1
 echo "pytest exit $?" >> gpurun_out/pytest_gpu.log
 tail -3 gpurun_out/pytest_gpu.log

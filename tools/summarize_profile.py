@@ -120,12 +120,18 @@ def main():
               f'rocprofv3 columns VGPR_Count {mine[-1]["VGPR_Count"]} / '
               f'SGPR_Count {mine[-1]["SGPR_Count"]} (the code object\'s '
               f'.vgpr_count, which sets the occupancy, is what '
-              f'tools/kernel_regs.py prints: 60 for this kernel): the {steps} launches of the timed region average '
+              f'tools/kernel_regs.py prints): the {steps} launches of the timed region average '
               f'**{timed_avg:.0f} ns** (min {min(timed)}, max {max(timed)}); '
               f'the bench line of the same run reports kernel_ms_mean = '
               f'{live["roofline"]["kernel_ms_mean"] * 1e6:.0f} ns (one HIP '
               f'event pair around the region, i.e. including the gaps '
-              f'between launches), frac {live["roofline"]["frac"]:.4f}.', '']
+              f'between launches), frac {live["roofline"]["frac"]:.4f}.  '
+              f'**rocprof per-dispatch mean / bench kernel_ms_mean of the '
+              f'same run = '
+              f'{timed_avg / (live["roofline"]["kernel_ms_mean"] * 1e6):.4f}'
+              f'**: multiply another box\'s `ms_per_step` / kernel_ms_mean '
+              f'by it for that box\'s per-dispatch figure (boxes differ by '
+              f'up to 9 % on this launch; the ratio does not).', '']
         with open(os.path.join(out, f'{tag}_bench_under_rocprof.json'),
                   'w') as f:
             json.dump(live, f, indent=1)
