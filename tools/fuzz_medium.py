@@ -15,7 +15,9 @@ remap_plan_prepare_short_runs) -- its own routing against the same oracle.
 Round 5: masks of whole cells / of columns / both; every masked case also
 with REMAP_FLAG_CELL_MASKS and through remap_tensor_auto_mode (scan + gated
 launches); a Dataset of same-shaped variables (batched) == variable by
-variable.
+variable.  Round 6: entry-rich mappings run the shared 4 x 8 form; masked
+`(Time, n, L)` cases also under REMAP_FLAG_BATCH_MASKS, with masks that do
+and do not change in time; the auto mode is the layout-aware scan.
 
     python tools/fuzz_medium.py [seconds=480] [first_seed=0]
 """
@@ -189,7 +191,7 @@ def one(seed, dev):
             shape = [int(rng.integers(2, 40)), m.n_a, int(rng.integers(1, 8))]
             axis = 1
         else:
-            shape = [int(rng.integers(1, 6)), m.n_a, int(rng.choice(LEVELS))]
+            shape = [int(rng.integers(1, 10)), m.n_a, int(rng.choice(LEVELS))]
             axis = 1
         dtype = rng.choice([np.float64, np.float32])
         field = rng.standard_normal(shape).astype(dtype)
@@ -213,6 +215,11 @@ def one(seed, dev):
                     field[:, rng.random(m.n_a) < 0.15] = np.nan
                 if whole > 0.3:
                     field[:, cells, shape[2] // 2:] = np.nan
+                if shape[0] > 1 and rng.random() < 0.3:
+                    # round 6: a mask that DOES change in time in a few
+                    # cells (the time forms redo those groups)
+                    field[int(rng.integers(0, shape[0])),
+                          rng.random(m.n_a) < 0.02] = np.nan
             thr = float(rng.choice([0.0, 0.05, 0.5]))
             arg = np.ma.masked_array(field, mask=np.isnan(field))
         ref = oracle.remap_numpy_array(csr, frac_b, m.dst_dims, arg, [axis],
@@ -235,6 +242,14 @@ def one(seed, dev):
                                      threshold=thr or 0.0,
                                      flags=engine.FLAG_CELL_MASKS)
             assert_bitwise(yf.cpu().numpy(), ref, what + ' cell-masks hint')
+            if len(shape) == 3:
+                # round 6: "the mask does not change from batch to batch"
+                # (spmm_timeshare / spmm_grouptime; a hint as well)
+                yb = engine.remap_tensor(plan, m.dst_dims, x, [axis], emode,
+                                         threshold=thr or 0.0,
+                                         flags=engine.FLAG_BATCH_MASKS)
+                assert_bitwise(yb.cpu().numpy(), ref,
+                               what + ' batch-masks hint')
             if np.isnan(field).any():
                 ya = engine.remap_tensor_auto_mode(plan, m.dst_dims, x,
                                                    [axis], thr)
