@@ -365,7 +365,9 @@ typedef struct remap_apply_args {
      * tune[5] family 10: union entries in flight per wave (8; or 4, 16);
      *         26 / 28: the rolling form with 6 / 8 in flight (float64, even
      *         strides; spmm_grouproll.h: measured, not chosen); 9: keep the
-     *         per-lane masked form under REMAP_FLAG_CELL_MASKS; 32: the
+     *         per-lane masked form under REMAP_FLAG_CELL_MASKS; 8 (the
+     *         default count, said aloud): keep the 8-row groups under
+     *         REMAP_FLAG_CELL_MASKS on a plan with share_* lists; 32: the
      *         shared form (share_* below: the frac_b and raw modes;
      *         tune[2] = K tiles per wave, 1 or 2)
      * tune[6..7] reserved, must be 0 (a -DREMAP_DIAG build of the library,
@@ -414,9 +416,10 @@ typedef struct remap_apply_args {
      * still adds its entries in ascending column order, so results are
      * unchanged.  Used by family 10 on float64 fields with even strides:
      * with tune[5] = 32 in the frac_b and raw modes on more than 128
-     * columns, with REMAP_FLAG_BATCH_MASKS in the masked mode (share_waves
-     * = 4: the shape the kernels are built in; remap_share_build also makes
-     * the lists of 2 groups).                                              */
+     * columns, with REMAP_FLAG_BATCH_MASKS (csrc/spmm_timeshare.h) or, on
+     * more than 128 columns, REMAP_FLAG_CELL_MASKS (csrc/spmm_cellshare.h)
+     * in the masked mode (share_waves = 4: the shape the kernels are built
+     * in; remap_share_build also makes the lists of 2 groups).             */
     const int64_t *share_meta;  /* (device) 2 * (n_super + 1)               */
     const int32_t *share_col;   /* (device) union entries (+ 256 readable)  */
     const int32_t *share_mask;  /* (device) union entries (+ 256 readable)  */

@@ -67,6 +67,7 @@ namespace {
 #include "spmm_groupshare.h"
 #include "spmm_grouptime.h"
 #include "spmm_timeshare.h"
+#include "spmm_cellshare.h"
 #include "spmm_rowlane.h"
 #include "spmm_rowcell.h"
 #include "spmm_patchcell.h"
@@ -646,6 +647,31 @@ int launch_timeshare(const remap_apply_args *a, const KParams &p, bool fma,
     return REMAP_OK;
 }
 
+// REMAP_FLAG_CELL_MASKS through the LDS ring of the shared form: one
+// normaliser per ROW (spmm_cellshare.h); float64 fields in whole 16-byte
+// pieces, 256 columns per workgroup
+int launch_cellshare(const remap_apply_args *a, const KParams &p, bool fma,
+                     int64_t grid, hipStream_t stream)
+{
+    void (*fn)(const KParams, const uint32_t, const int64_t *,
+               const int32_t *, const double *, const int32_t *,
+               const int32_t *, const int64_t *, const int32_t *,
+               const int32_t *, const double *) =
+        fma ? spmm_cellshare<true, 1> : spmm_cellshare<false, 1>;
+    // the ring: two buffers of 8 entries x 2 KiB; 2 x 4 slots of a step's
+    // weights; slack
+    uint32_t lds_bytes = 2u * (8u * 2048u + 4u * 512u) + 512u;
+    REMAP_HIP_CHECK(diag_lds_throttle(a, reinterpret_cast<const void *>(fn),
+                                      lds_bytes));
+    hipLaunchKernelGGL(fn, dim3(static_cast<uint32_t>(grid)), dim3(kWave * 4),
+                       lds_bytes, stream, p, a->flags, a->group_meta,
+                       a->group_col, a->group_w, a->group_mask, a->group_rid,
+                       a->share_meta, a->share_col, a->share_mask,
+                       static_cast<const double *>(a->X));
+    REMAP_HIP_CHECK(hipGetLastError());
+    return REMAP_OK;
+}
+
 // the shared form (spmm_groupshare.h): float64, two elements per lane
 typedef void (*share_fn)(const KParams, const uint32_t, const int64_t *,
                          const double *, const int32_t *, const double *,
@@ -935,15 +961,19 @@ bool patch_serves(const remap_apply_args *a, const Call &c)
 }
 
 // The forms of family 10 that address X with a flat 64-bit address per lane
-// (LDS-DMA: spmm_groupshare.h, spmm_timeshare.h) also serve fields whose
-// batches lie further apart than 32-bit offsets reach -- (Time, nCells,
-// nVertLevels) on a 3.7 M-cell mesh: 1.9 GB per time slice.  Does this call
-// take one of them?
+// (LDS-DMA: spmm_groupshare.h, spmm_timeshare.h, spmm_cellshare.h) also serve
+// fields whose batches lie further apart than 32-bit offsets reach -- (Time,
+// nCells, nVertLevels) on a 3.7 M-cell mesh: 1.9 GB per time slice.  Does
+// this call take one of them?
 bool wide_share(const remap_apply_args *a, const Call &c)
 {
     if (!c.share_ok || !c.dma16 || a->x_src_fold != 0 ||
         a->x_row_stride < 0 || a->x_row_stride >= (int64_t(1) << 29))
         return false;
+    if (a->mode == REMAP_MODE_MASKED && (a->flags & REMAP_FLAG_CELL_MASKS) &&
+        a->share_waves == 4 && (a->tune[5] == 0 || a->tune[5] == 32) &&
+        a->group_rows == 8 && c.K > 128)
+        return true;   // spmm_cellshare.h
     if (a->mode == REMAP_MODE_MASKED)
         return a->share_waves == 4 && a->n_batch >= 3 &&
                (a->flags & (REMAP_FLAG_BATCH_MASKS | REMAP_FLAG_CELL_MASKS)) &&
@@ -1079,6 +1109,28 @@ int run_rowgroup(const remap_apply_args *a, const Call &c, KParams p,
                     "row-group schedule for [row_begin, row_end) and 32-bit "
                     "offsets (or the shared lists and a float64 field in "
                     "whole 16-byte pieces)");
+    // REMAP_FLAG_CELL_MASKS with the shared lists (remap_schedule_auto builds
+    // them on entry-rich mappings): the per-row normaliser through the LDS
+    // ring (spmm_cellshare.h) -- flat 64-bit addresses, so a (Time, nCells,
+    // nVertLevels) field's batches are served too.  Anything it cannot serve
+    // (f32, odd strides, at most 128 columns) takes the forms below;
+    // tune[5] = 8 keeps the 8-row groups (spmm_groupmask.h).
+    if ((a->flags & REMAP_FLAG_CELL_MASKS) && a->mode == REMAP_MODE_MASKED &&
+        (a->tune[5] == 0 || a->tune[5] == 32) && a->group_rows == 8 &&
+        c.share_ok &&
+        a->share_waves == 4 && c.dma16 && c.K > 128 && a->x_src_fold == 0 &&
+        a->x_row_stride >= 0 && a->x_row_stride < (int64_t(1) << 29)) {
+        p.rows_per_wave = 1;
+        const int64_t k_chunks = shape_tiles(p, a, c.K, kWave * 2, 2);
+        int64_t grid;
+        const int rc = shape_grid(p, ceil_div(a->n_groups, (int64_t)4),
+                                  k_chunks, a->tune[4] != 1, grid);
+        if (rc != REMAP_OK)
+            return rc;
+        if (a->tune[4] == 3)
+            p.xcd_map |= 2;
+        return launch_cellshare(a, p, c.fma, grid, stream);
+    }
     // tune[5] = 32: the shared form (spmm_groupshare.h) -- W waves, one
     // union through an LDS ring; float64 fields in whole 16-byte pieces,
     // more than 128 columns.  A call it cannot serve takes the 8-row groups
@@ -1176,7 +1228,7 @@ int run_rowgroup(const remap_apply_args *a, const Call &c, KParams p,
     const bool cell_masks =
         (a->flags & REMAP_FLAG_CELL_MASKS) && a->mode == REMAP_MODE_MASKED &&
         a->group_rows == 8 && c.can_vec2 && c.K > 128 &&
-        (a->tune[5] == 0 || a->tune[5] == 32);
+        (a->tune[5] == 0 || a->tune[5] == 32 || a->tune[5] == 8);
     if (cell_masks)
         tiles = 2;
     if (tiles != 2 || c.K <= 128)
