@@ -632,7 +632,7 @@ int launch_timeshare(const remap_apply_args *a, const KParams &p, bool fma,
                const int32_t *, const double *, const int32_t *,
                const int32_t *, const int64_t *, const int32_t *,
                const int32_t *, const double *) =
-        fma ? spmm_timeshare<true, 2> : spmm_timeshare<false, 2>;
+        fma ? spmm_timeshare<true, 1> : spmm_timeshare<false, 1>;
     // the ring: two buffers of 8 entries x (4 slices x 512 B); 2 x 4 slots
     // of a step's weights; slack
     uint32_t lds_bytes = 2u * (8u * 2048u + 4u * 512u) + 512u;

@@ -202,7 +202,7 @@ __attribute__((amdgpu_waves_per_eu(4, 8))) void spmm_cellshare(
         const int seg_steps = (seg_len + UNR - 1) / UNR;
         if (seg0 > 0)   // the ring of the segment before is read to the end
             share_barrier<0>();
-        int32_t colv[2], bitsv[2], cntv[2];
+        int32_t colv[2], bitsv[2], bitsh[2], cntv[2];
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             colv[b] = lcol[seg0 + b * kWave + lane];
@@ -213,7 +213,9 @@ __attribute__((amdgpu_waves_per_eu(4, 8))) void spmm_cellshare(
             pc += __builtin_amdgcn_update_dpp(0, pc, 0xB1, 0xf, 0xf, true);
             pc += __builtin_amdgcn_update_dpp(0, pc, 0x4E, 0xf, 0xf, true);
             pc += __builtin_amdgcn_update_dpp(0, pc, 0x141, 0xf, 0xf, true);
-            bitsv[b] = mine;
+            // (a step's member bytes packed into its first lane:
+            // spmm_groupshare.h)
+            share_pack_step<UNR>(mine, bitsv[b], bitsh[b]);
             cntv[b] = pc;
         }
         // (awaited here, in straight-line code: spmm_groupshare.h)
@@ -233,15 +235,18 @@ __attribute__((amdgpu_waves_per_eu(4, 8))) void spmm_cellshare(
 
         // this wave's pieces of step st of the segment: its entries of the
         // step and the step's weights
+        int32_t col_s = colv[0], bits_lo = bitsv[0], bits_hi = bitsh[0];
         auto send = [&](const int st) {
             const int buf = st % NBUF;
+            if (st * UNR == kWave)
+                share_switch(col_s, colv[1]);
 #pragma unroll
             for (int i = 0; i < EPW; ++i) {
                 const int uu = wave * EPW + i;
                 int e = st * UNR + uu;
                 e = e < seg_len ? e : seg_len - 1;
-                int32_t c = __builtin_amdgcn_readlane(
-                    e < kWave ? colv[0] : colv[1], e & (kWave - 1));
+                int32_t c =
+                    __builtin_amdgcn_readlane(col_s, e & (kWave - 1));
                 REMAP_DIAG_COL(p, c);
                 const char *src =
                     reinterpret_cast<const char *>(X) +
@@ -279,12 +284,14 @@ __attribute__((amdgpu_waves_per_eu(4, 8))) void spmm_cellshare(
             if (st + 1 < seg_steps)
                 send(st + 1);
             const int e0 = st * UNR;
-            const int32_t bv = e0 < kWave ? bitsv[0] : bitsv[1];
-            int bits[UNR];
-#pragma unroll
-            for (int uu = 0; uu < UNR; ++uu)
-                bits[uu] =
-                    __builtin_amdgcn_readlane(bv, (e0 & (kWave - 1)) + uu);
+            if (e0 == kWave) {
+                share_switch(bits_lo, bitsv[1]);
+                share_switch(bits_hi, bitsh[1]);
+            }
+            const uint32_t step_lo = static_cast<uint32_t>(
+                __builtin_amdgcn_readlane(bits_lo, e0 & (kWave - 1)));
+            const uint32_t step_hi = static_cast<uint32_t>(
+                __builtin_amdgcn_readlane(bits_hi, e0 & (kWave - 1)));
 
             const uint32_t mine = ring_lds + buf * kBufBytes + lane * 16;
             share_x2 xr[AHEAD + 1][TILES];
@@ -307,8 +314,9 @@ __attribute__((amdgpu_waves_per_eu(4, 8))) void spmm_cellshare(
                         share_read<(uu + AHEAD) * kEntryBytes + 1024>(
                             xr[nx][1], mine);
                     }
-                    const int b = bits[uu];
-                    if (b) {
+                    const uint32_t word = uu < 4 ? step_lo : step_hi;
+                    constexpr int sb = 8 * (uu & 3);
+                    if (word & (0xffu << sb)) {
                         constexpr int behind =
                             (uu + AHEAD < UNR ? AHEAD : UNR - 1 - uu) *
                             TILES;
@@ -325,7 +333,7 @@ __attribute__((amdgpu_waves_per_eu(4, 8))) void spmm_cellshare(
                                 // products, the weight onto the row's den
 #pragma unroll
                                 for (int m = 0; m < G; ++m) {
-                                    if (b & (1 << m)) {
+                                    if (word & (1u << (sb + m))) {
                                         const double a =
                                             readlane_f64(my_w, idx);
                                         ++idx;
@@ -356,7 +364,7 @@ __attribute__((amdgpu_waves_per_eu(4, 8))) void spmm_cellshare(
                                     // weight
 #pragma unroll
                                     for (int m = 0; m < G; ++m) {
-                                        if (b & (1 << m)) {
+                                        if (word & (1u << (sb + m))) {
                                             const int hi =
                                                 __builtin_amdgcn_readlane(
                                                     __double2hiint(my_w),

@@ -128,6 +128,28 @@ __device__ __forceinline__ void share_wait_w(double &w)
     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(w) : "n"(N));
 }
 
+// Member bytes of the UNR entries of a step, packed into the step's first
+// lane: lo = entries 0 - 3 (byte j = entry j), hi = entries 4 - 7.
+template <int UNR>
+__device__ __forceinline__ void share_pack_step(int32_t mine, int32_t &lo,
+                                                int32_t &hi)
+{
+    int32_t t = mine | (__builtin_amdgcn_update_dpp(0, mine, 0x101, 0xf, 0xf,
+                                                    true)
+                        << 8);
+    t |= __builtin_amdgcn_update_dpp(0, t, 0x102, 0xf, 0xf, true) << 16;
+    lo = t;
+    hi = UNR == 8 ? __builtin_amdgcn_update_dpp(0, t, 0x104, 0xf, 0xf, true)
+                  : 0;
+}
+
+// v = w behind a SCALAR branch (left to itself hipcc turns `half ? a : b`
+// into s_cmp, s_cselect, v_cndmask in every step of the loop)
+__device__ __forceinline__ void share_switch(int32_t &v, int32_t w)
+{
+    asm volatile("v_mov_b32 %0, %1" : "+v"(v) : "v"(w));
+}
+
 template <int TILES, int MODE, bool FMA, int W, int UNR, int NBUF, int AHEAD>
 __global__ __launch_bounds__(W *kWave) void spmm_groupshare(
     const KParams p, const uint32_t flags,
@@ -230,7 +252,7 @@ __global__ __launch_bounds__(W *kWave) void spmm_groupshare(
         // arrays are padded: always in bounds); the masks cut down to this
         // wave's member bits (none behind the list's end); in the lanes of a
         // step the number of bits set in the step
-        int32_t colv[2], bitsv[2], cntv[2];
+        int32_t colv[2], bitsv[2], bitsh[2], cntv[2];
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             colv[b] = lcol[seg0 + b * kWave + lane];
@@ -243,7 +265,11 @@ __global__ __launch_bounds__(W *kWave) void spmm_groupshare(
             if constexpr (UNR == 8)
                 pc += __builtin_amdgcn_update_dpp(0, pc, 0x141, 0xf, 0xf,
                                                   true);
-            bitsv[b] = mine;
+            // a step's member bytes side by side in the step's first lane
+            // (row_shl: lane i reads lane i + n of its row of 16): entries
+            // 0 - 3 of the step in bitsv, 4 - 7 in bitsh -- two v_readlane
+            // per step instead of eight
+            share_pack_step<UNR>(mine, bitsv[b], bitsh[b]);
             cntv[b] = pc;
         }
         // (the loads above are awaited HERE, in straight-line code: met
@@ -267,15 +293,20 @@ __global__ __launch_bounds__(W *kWave) void spmm_groupshare(
 
         // this wave's pieces of step st of the segment: its entries of the
         // step and the step's weights
+        // the half of the segment (64 entries: one register of columns, two
+        // of member bytes) the sending side / the summing side is in
+        int32_t col_s = colv[0], bits_lo = bitsv[0], bits_hi = bitsh[0];
         auto send = [&](const int st) {
             const int buf = st % NBUF;
+            if (st * UNR == kWave)
+                share_switch(col_s, colv[1]);
 #pragma unroll
             for (int i = 0; i < EPW; ++i) {
                 const int uu = wave * EPW + i;
                 int e = st * UNR + uu;
-                e = e < seg_len ? e : seg_len - 1;
-                int32_t c = __builtin_amdgcn_readlane(
-                    e < kWave ? colv[0] : colv[1], e & (kWave - 1));
+                e = e < seg_len ? e : seg_len - 1;   // (same step, same half)
+                int32_t c =
+                    __builtin_amdgcn_readlane(col_s, e & (kWave - 1));
                 REMAP_DIAG_COL(p, c);
                 const char *src =
                     reinterpret_cast<const char *>(X) +
@@ -326,12 +357,16 @@ __global__ __launch_bounds__(W *kWave) void spmm_groupshare(
             if (st + A < seg_steps)
                 send(st + A);
             const int e0 = st * UNR;
-            const int32_t bv = e0 < kWave ? bitsv[0] : bitsv[1];
-            int bits[UNR];
-#pragma unroll
-            for (int uu = 0; uu < UNR; ++uu)
-                bits[uu] =
-                    __builtin_amdgcn_readlane(bv, (e0 & (kWave - 1)) + uu);
+            if (e0 == kWave) {
+                share_switch(bits_lo, bitsv[1]);
+                share_switch(bits_hi, bitsh[1]);
+            }
+            const uint32_t step_lo = static_cast<uint32_t>(
+                __builtin_amdgcn_readlane(bits_lo, e0 & (kWave - 1)));
+            const uint32_t step_hi =
+                UNR == 8 ? static_cast<uint32_t>(__builtin_amdgcn_readlane(
+                               bits_hi, e0 & (kWave - 1)))
+                         : 0u;
 
             // the step's entries from LDS, AHEAD of the sums (its weights
             // were asked for in front of the barrier)
@@ -358,8 +393,10 @@ __global__ __launch_bounds__(W *kWave) void spmm_groupshare(
                             share_read<(uu + AHEAD) * kEntryBytes + 1024>(
                                 xr[nx][1], mine);
                     }
-                    const int b = bits[uu];
-                    if (b) {
+                    // the entry's member byte: tested in place
+                    const uint32_t word = uu < 4 ? step_lo : step_hi;
+                    constexpr int sb = 8 * (uu & 3);
+                    if (word & (0xffu << sb)) {
                         // reads issued behind this entry's: those of the
                         // entries uu + 1 ... min(uu + AHEAD, UNR - 1)
                         constexpr int behind =
@@ -389,7 +426,7 @@ __global__ __launch_bounds__(W *kWave) void spmm_groupshare(
                             }
 #pragma unroll
                         for (int m = 0; m < G; ++m) {
-                            if (b & (1 << m)) {
+                            if (word & (1u << (sb + m))) {
                                 const double a = readlane_f64(my_w, idx);
                                 ++idx;
 #pragma unroll
