@@ -896,8 +896,9 @@ def extras_todo(args, world):
          4),
         # masked mode, a quarter of the source cells missing in every field
         # (land / ice shelf): REMAP_FLAG_CELL_MASKS (16), the form
-        # `remap_tensor_auto_mode` picks when remap_scan_nan_kinds finds the
-        # NaNs in whole cells ...
+        # `remap_tensor_auto_mode` picks when the scan finds the NaNs in
+        # whole cells (one normaliser per row through the shared LDS ring:
+        # csrc/spmm_cellshare.h) ...
         ('config5_masked', dict(name='config5', sets=1, mode='masked',
                                 share='config5', flags=16), 4),
         # ... the same as MPAS lays a 3-D variable out, (Time = 16, nCells,
@@ -1114,7 +1115,9 @@ def kernel_of(e):
     rich = sched.get('rows_per_group') == 8
     if family == 'spmm_rowgroup' and e.get('mode') == 'masked' and \
             (e.get('flags') or 0) & 16 and rich and e['K'] > 128:
-        family = 'spmm_groupmask (REMAP_FLAG_CELL_MASKS)'
+        family = ('spmm_cellshare' if sched.get('shared_by') and
+                  e.get('dtype', 'f64') == 'f64' else
+                  'spmm_groupmask') + ' (REMAP_FLAG_CELL_MASKS)'
     elif family == 'spmm_rowgroup' and e.get('mode') == 'masked' and \
             (e.get('flags') or 0) & 32 and rich and e['layout'] == 'tnl':
         family = ('spmm_timeshare' if sched.get('shared_by') else
