@@ -51,6 +51,29 @@ __device__ __forceinline__ void tshare_wait(double (&x)[4])
                  : "n"(N));
 }
 
+// x where the lane's bit of `mask` is clear, +0.0 where it is set: two
+// v_cndmask_b32 reading the mask from its SGPR pair (written as `mask >> lane
+// & 1` hipcc shifts a 64-bit VGPR pair per element; written as `x != x ? 0 :
+// x` it compares again).  Inside a branch on the mask: the asm is volatile so
+// that the branch is not flattened into selects on every entry.
+__device__ __forceinline__ double tshare_zero_where(double x, uint64_t mask)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    asm volatile("v_cndmask_b32_e64 %0, %0, 0, %2\n\t"
+                 "v_cndmask_b32_e64 %1, %1, 0, %2"
+                 : "+v"(lo), "+v"(hi)
+                 : "s"(mask));
+    return __hiloint2double(hi, lo);
+}
+
+// 1.0 where the lane's bit of `mask` is clear, +0.0 where it is set
+__device__ __forceinline__ double tshare_one_where_clear(uint64_t mask)
+{
+    int hi = 0x3ff00000;
+    asm volatile("v_cndmask_b32_e64 %0, %0, 0, %1" : "+v"(hi) : "s"(mask));
+    return __hiloint2double(hi, 0);
+}
+
 template <bool FMA, int AHEAD>
 __global__ __launch_bounds__(4 * kWave)
 __attribute__((amdgpu_waves_per_eu(4, 8))) void spmm_timeshare(
@@ -146,7 +169,8 @@ __attribute__((amdgpu_waves_per_eu(4, 8))) void spmm_timeshare(
         for (int e = 0; e < TB; ++e)
             acc[m][e][0] = 0.0;
     }
-    bool mixed = false;
+    // lanes that met an entry whose slices disagree: != 0 -> the general form
+    uint64_t mixed_bits = 0;
 
     int seg_w = 0;
     for (int seg0 = 0; seg0 < len; seg0 += kSeg) {
@@ -275,36 +299,30 @@ __attribute__((amdgpu_waves_per_eu(4, 8))) void spmm_timeshare(
 #pragma unroll
                         for (int e = 0; e < TB; ++e)
                             x[e] = xr[slot][e];
-                        // lanes whose slice e is missing
+                        // lanes whose slice e is missing; lanes whose
+                        // slices disagree (kept as BITS: tested as a number,
+                        // hipcc turns every `^` into s_cmp + s_cselect)
                         uint64_t nan_m[TB];
 #pragma unroll
                         for (int e = 0; e < TB; ++e)
                             nan_m[e] = __ballot(x[e] != x[e]);
-                        uint64_t differ = 0, any = nan_m[0];
 #pragma unroll
-                        for (int e = 1; e < TB; ++e) {
-                            differ |= nan_m[e] ^ nan_m[0];
-                            any |= nan_m[e];
-                        }
-                        if (differ != 0)
-                            mixed = true;   // -> the general form, later
-                        if (!mixed) {
+                        for (int e = 1; e < TB; ++e)
+                            mixed_bits |= nan_m[e] ^ nan_m[0];
+                        if (mixed_bits == 0) {
                             // valid in every lane and slice (the open
                             // ocean): the products as they are; else
                             // missing in some lanes, in all their slices:
-                            // those lanes add a * 0.0 to num and to den
+                            // those lanes add a * 0.0 to num and to den --
+                            // selected by slice 0's mask, which is every
+                            // slice's, straight from its SGPR pair
                             double vf = 1.0;
-                            if (any != 0) {
-                                const bool valid = x[0] == x[0];
-                                vf = valid ? 1.0 : 0.0;
+                            if (nan_m[0] != 0) {
 #pragma unroll
                                 for (int e = 0; e < TB; ++e)
-                                    x[e] = valid ? x[e] : 0.0;
+                                    x[e] = tshare_zero_where(x[e], nan_m[0]);
+                                vf = tshare_one_where_clear(nan_m[0]);
                             }
-#pragma unroll
-                            for (int e = 0; e < TB; ++e)
-                                asm volatile("" : "+v"(x[e]));
-                            asm volatile("" : "+v"(vf));
 #pragma unroll
                             for (int m = 0; m < G; ++m) {
                                 if (word & (1u << (sb + m))) {
@@ -334,6 +352,7 @@ __attribute__((amdgpu_waves_per_eu(4, 8))) void spmm_timeshare(
         act[e] = lane_on && b < n_batch;
         yoff[e] = act[e] ? static_cast<int64_t>(b) * p.bsy + k : 0;
     }
+    const bool mixed = mixed_bits != 0;
     if (nmem > 0 && !mixed) {
         const rvec_t rid = *reinterpret_cast<const rvec_t *>(grid + slot0);
 #pragma unroll
