@@ -359,6 +359,57 @@ __device__ __forceinline__ void finish_row_uniform(
             store_row_tile<VEC>(p, i * p.ldy + yoff[t], y[t], ok);
 }
 
+// One row of the masked mode whose N elements per lane share ONE normaliser
+// per LANE (spmm_timeshare.h: a lane holds N time slices of its level):
+// `ok = den > thr`, `y = ok ? acc / den : NaN` (remap_numpy.py:266, 277-278).
+// The reciprocal and its two refinements depend on den alone -- once per lane
+// instead of once per element -- under finish_row_uniform's conditions, which
+// are conditions on a LANE's operands (v_div_scale scaling nothing, VCC = 0
+// in that lane, v_div_fixup with nothing to repair): a lane that keeps its
+// row (`ok`) needs den in [2^-126, 2^126] and every |acc| in [2^-800,
+// 2^600]; a lane that does not is filled with NaN whatever it computes.  One
+// lane outside and the wave divides the row the long way.
+template <int N>
+__device__ __forceinline__ void finish_row_lane_den(
+    const KParams &p, int64_t i, double den, const bool (&act)[N],
+    const int64_t (&yoff)[N], const double (&acc)[N][1])
+{
+    const bool ok = den > p.thr;
+    bool in = div_fast_divisor(den);
+#pragma unroll
+    for (int e = 0; e < N; ++e)
+        in = in && div_fast_numerator(acc[e][0]);
+    double y[N];
+    if (__ballot(ok && !in) == 0ull) {
+        double r = __builtin_amdgcn_rcp(den);
+        double e1 = __builtin_fma(-den, r, 1.0);
+        r = __builtin_fma(r, e1, r);
+        e1 = __builtin_fma(-den, r, 1.0);
+        r = __builtin_fma(r, e1, r);
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            const double q0 = acc[e][0] * r;
+            const double rem = __builtin_fma(-den, q0, acc[e][0]);
+            const double q = __builtin_fma(rem, r, q0);
+            y[e] = ok ? q : __builtin_nan("");
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            y[e] = ok ? acc[e][0] / den : __builtin_nan("");
+            asm volatile("" : "+v"(y[e]));
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+        if (!act[e])
+            continue;
+        const double y1[1] = {y[e]};
+        const bool ok1[1] = {ok};
+        store_row_tile<1>(p, i * p.ldy + yoff[e], y1, ok1);
+    }
+}
+
 // Fused epilogue of one row: normalise, mask, store (remap_numpy.py:266-278).
 template <int VEC, int TILES, int MODE>
 __device__ __forceinline__ void finish_row(

@@ -357,14 +357,9 @@ __attribute__((amdgpu_waves_per_eu(4, 8))) void spmm_timeshare(
         const rvec_t rid = *reinterpret_cast<const rvec_t *>(grid + slot0);
 #pragma unroll
         for (int m = 0; m < G; ++m) {
-            if (m < nmem) {
-                double den[TB][1];
-#pragma unroll
-                for (int e = 0; e < TB; ++e)
-                    den[e][0] = den_l[m];
-                finish_row<1, TB, REMAP_MODE_MASKED>(p, rid[m], 0.0, act,
-                                                     yoff, acc[m], den);
-            }
+            if (m < nmem)
+                finish_row_lane_den<TB>(p, rid[m], den_l[m], act, yoff,
+                                        acc[m]);
         }
     }
     if (nmem > 0 && mixed) {

@@ -352,3 +352,61 @@ def test_csr_from_coo_at_baseline_scale_against_the_oracle(dev, name):
     assert np.array_equal(rowptr, ref.indptr)
     assert np.array_equal(col, ref.indices)
     assert np.array_equal(val.view(np.int64), ref.data.view(np.int64))
+
+
+def test_masked_division_by_a_lane_normaliser_and_its_guards(dev):
+    """`spmm_timeshare` divides the four time slices of a lane by ONE
+    normaliser: for ordinary operands the reciprocal is refined once per lane
+    and every element finished with a multiply and two FMAs -- the very
+    instructions the full IEEE division sequence ends with when its scaling
+    steps scale nothing (csrc/spmm_device.h: finish_row_lane_den); zeros,
+    denormals, 1e-250, 1e300, Inf, a normaliser outside [2^-126, 2^126] send
+    the wave's row the long way.  Every value equals the oracle's C division
+    (`num[ok] /= den[ok]`, remap_numpy.py:277), bit for bit; a negative
+    threshold keeps rows with a negative normaliser."""
+    from oracle import oracle
+    from pyremap_amd import engine
+    rng = np.random.default_rng(12)
+    n_cells, T, L = 32, 5, 64
+    x = rng.standard_normal((T, n_cells, L)) * \
+        10.0 ** rng.integers(-200, 150, (1, n_cells, 1))
+    specials = [0.0, -0.0, 1e-310, -4e-320, 1e-250, 2.0 ** -800,
+                np.nextafter(2.0 ** -800, 0.0), 2.0 ** 600,
+                np.nextafter(2.0 ** 601, 1.0), 2.0 ** 601, 1e300, np.inf,
+                -np.inf, 1.5e-241, 8.3e180]
+    for j, s in enumerate(specials):            # cells 16 ... : one each,
+        x[:, 16 + j, (37 * j) % L] = s          # in every time slice
+    depth = rng.integers(1, L + 1, n_cells)     # bathymetry: same mask at
+    depth[16:] = L                              # every time
+    x[:, np.arange(L)[None, :] >= depth[:, None]] = np.nan
+    dens = [1.0, 0.5, 0.3, 1.0 / 3.0, 1e-30, 1e-38, 2.0 ** -126,
+            np.nextafter(2.0 ** -126, 0.0), 2.0 ** 126,
+            np.nextafter(2.0 ** 127, 1.0), 1e38, 1e-310, 0.0, -0.5, 1e300,
+            0.9999999999999999]
+    row = np.arange(n_cells * len(dens))
+    col = row % n_cells
+    S = np.repeat(np.asarray(dens), n_cells)    # one entry per row: den = S
+    n_b = row.size
+    frac_b = np.ones(n_b)
+    plan = engine.RemapPlan.from_triplets(row + 1, col + 1, S, frac_b,
+                                          n_cells, n_b, index_base=1,
+                                          device=dev)
+    csr = oracle.coo_to_csr(row, col, S, n_b, n_cells)
+    plan.build_groups(None, rows=8, share=4)
+    fd = torch.from_numpy(x).to(dev)
+    with np.errstate(all='ignore'):
+        for thr in (0.0, 0.3, -1.0):
+            ref = _reference(csr, frac_b, x, thr, masked=True)
+            flat = np.ascontiguousarray(x.transpose(1, 0, 2)).reshape(
+                n_cells, T * L)
+            ref_mask = oracle.remap_flat(csr, frac_b, flat, True, thr)[1]
+            ref_mask = ref_mask.reshape(n_b, T, L).transpose(1, 0, 2)
+            for flags in (engine.FLAG_BATCH_MASKS, 0):
+                y, mask = engine.remap_tensor(
+                    plan, None, fd, [1], engine.MODE_MASKED, threshold=thr,
+                    flags=flags, tune=[10, 1, 1, 1, 3], want_mask=True)
+                what = f'division by a lane normaliser, thr={thr} ' \
+                       f'flags={flags}'
+                assert_bitwise(y.cpu().numpy(), ref, what)
+                assert np.array_equal(mask.cpu().numpy().astype(bool),
+                                      ref_mask), what
