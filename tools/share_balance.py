@@ -42,36 +42,52 @@ def main():
     pick = np.sort(rng.choice(n_super, min(args.sample, n_super),
                               replace=False))
     mask = sh['mask'].cpu().numpy().view(np.uint32)
-    pop8 = np.array([bin(i).count('1') for i in range(256)], dtype=np.int64)
-    tot_mean = tot_max = 0.0
-    n_steps = 0
-    own_hist = np.zeros(9, dtype=np.int64)
-    lens = []
-    for s in pick:
-        lo, hi = meta[s], meta[s + 1]
-        mk = mask[lo:hi]
-        n = hi - lo
-        lens.append(n)
-        pad = (-n) % 8
-        if pad:
-            mk = np.concatenate([mk, np.zeros(pad, dtype=np.uint32)])
-        by = np.stack([(mk >> (8 * w)) & 0xff for w in range(4)], axis=1)
-        prod = pop8[by].reshape(-1, 8, 4).sum(axis=1)          # (steps, 4)
-        own = (by != 0).reshape(-1, 8, 4).sum(axis=1)
-        cost = args.c_step + args.c_own * own + args.c_prod * prod
-        tot_mean += cost.mean(axis=1).sum()
-        tot_max += cost.max(axis=1).sum()
-        n_steps += cost.shape[0]
-        own_hist += np.bincount(own.ravel(), minlength=9)[:9]
-    lens = np.asarray(lens)
+    # what-if: the 32 slots of a supergroup dealt to the waves differently
+    # (slot q of the tile walk -> wave perm[q] // 8, member perm[q] % 8)
+    q = np.arange(32)
+    # slot q of the walk -> its place (py, px) in the 4 x 8 tile (order_keys:
+    # wave = 2 x 4 patch (wy, wx), member = row-major inside the patch)
+    py = (q // 8 // 2) * 2 + (q % 8) // 4
+    px = (q // 8 % 2) * 4 + q % 4
+    perms = {
+        'as built (a 2 x 4 patch per wave)': q,
+        'columns: wave px % 4': (px % 4) * 8 + py * 2 + px // 4,
+        'checkerboard: wave (py % 2, px % 2)':
+            ((py % 2) * 2 + px % 2) * 8 + (py // 2) * 4 + px // 2,
+        'diagonal: wave (px + py) % 4': ((px + py) % 4) * 8 + py * 2 + px // 4,
+        'diagonal 2: wave (px + 2 py) % 4':
+            ((px + 2 * py) % 4) * 8 + py * 2 + px // 4,
+        'rows: wave py': py * 8 + px,
+        'pairs of columns: wave (px // 2) % 4':
+            ((px // 2) % 4) * 8 + py * 2 + px % 2,
+    }
+    for name, perm in perms.items():
+        assert sorted(perm.tolist()) == list(range(32)), name
+    cat = [mask[meta[s]:meta[s + 1]] for s in pick]
+    lens = np.asarray([len(c) for c in cat])
+    padded = []
+    for c in cat:
+        pad = (-len(c)) % 8
+        padded.append(np.concatenate([c, np.zeros(pad, dtype=np.uint32)])
+                      if pad else c)
+    allm = np.concatenate(padded)
+    bits = ((allm[:, None] >> q[None, :]) & 1).astype(np.int64)  # (E, 32)
     print(f'{args.workload}: {len(pick)} of {n_super} supergroups, '
-          f'{n_steps} steps; union entries per supergroup: mean '
+          f'{len(allm) // 8} steps; union entries per supergroup: mean '
           f'{lens.mean():.1f}, median {np.median(lens):.0f}, max {lens.max()}')
-    print(f'owned entries per wave and step (0..8): '
-          f'{(own_hist / own_hist.sum()).round(3).tolist()}')
-    print(f'cost per step: mean over waves {tot_mean / n_steps:.1f}, mean of '
-          f'the slowest wave {tot_max / n_steps:.1f} '
-          f'(x {tot_max / tot_mean:.3f})')
+    for name, perm in perms.items():
+        nb = np.zeros_like(bits)
+        nb[:, perm] = bits
+        per_wave = nb.reshape(-1, 4, 8)                    # (E, wave, member)
+        prod = per_wave.sum(axis=2).reshape(-1, 8, 4).sum(axis=1)
+        own = (per_wave.sum(axis=2) != 0).reshape(-1, 8, 4).sum(axis=1)
+        cost = args.c_step + args.c_own * own + args.c_prod * prod
+        hist = np.bincount(own.ravel(), minlength=9)[:9]
+        print(f'{name}: owned per wave and step {own.mean():.2f} '
+              f'(0..8: {(hist / hist.sum()).round(2).tolist()}); cost per '
+              f'step: mean over waves {cost.mean():.1f}, mean of the slowest '
+              f'{cost.max(axis=1).mean():.1f} '
+              f'(x {cost.max(axis=1).mean() / cost.mean():.3f})')
 
 
 if __name__ == '__main__':
