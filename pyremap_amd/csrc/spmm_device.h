@@ -55,7 +55,11 @@ struct KParams {
             (c) &= 1023;                                                     \
     } while (0)
 #define REMAP_DIAG_SKIP_STORE(p, y0) (((p).diag & 1) && (y0) != 1.2345e300)
+// ablations of the shared form (spmm_groupshare.h; WRONG results, timing
+// only): 4 = no s_barrier, 8 = no sums, 16 = no DMA sends
+#define REMAP_DIAG_ON(p, bit) (((p).diag & (bit)) != 0)
 #else
+#define REMAP_DIAG_ON(p, bit) false
 #define REMAP_DIAG_COL(p, c) do { } while (0)
 #define REMAP_DIAG_SKIP_STORE(p, y0) false
 #endif

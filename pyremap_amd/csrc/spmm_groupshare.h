@@ -77,6 +77,19 @@ __device__ __forceinline__ void share_barrier()
 // The same with the read of the step's weights -- the wave's own slot, landed
 // once ITS DMAs have -- issued in front of the barrier: its trip to LDS runs
 // while the other waves arrive.
+#ifdef REMAP_DIAG
+// (ablation: the waits and the read without the barrier)
+template <int N>
+__device__ __forceinline__ void share_nobarrier_w(double &w, uint32_t addr)
+{
+    asm volatile("s_waitcnt vmcnt(%2) lgkmcnt(0)\n\t"
+                 "ds_read_b64 %0, %1"
+                 : "=v"(w)
+                 : "v"(addr), "n"(N)
+                 : "memory");
+}
+#endif
+
 template <int N>
 __device__ __forceinline__ void share_barrier_w(double &w, uint32_t addr)
 {
@@ -300,6 +313,8 @@ __global__ __launch_bounds__(W *kWave) void spmm_groupshare(
             const int buf = st % NBUF;
             if (st * UNR == kWave)
                 share_switch(col_s, colv[1]);
+            if (REMAP_DIAG_ON(p, 16))
+                return;
 #pragma unroll
             for (int i = 0; i < EPW; ++i) {
                 const int uu = wave * EPW + i;
@@ -348,6 +363,11 @@ __global__ __launch_bounds__(W *kWave) void spmm_groupshare(
             double my_w;
             const uint32_t my_w_lds =
                 wring_lds + (buf * W + wave) * kWSlot + lane * 8;
+#ifdef REMAP_DIAG
+            if (REMAP_DIAG_ON(p, 4))
+                share_nobarrier_w<0>(my_w, my_w_lds);
+            else
+#endif
             if (st + A - 1 < seg_steps)
                 share_barrier_w<(A - 1) * kOps>(my_w, my_w_lds);
             else
@@ -396,7 +416,7 @@ __global__ __launch_bounds__(W *kWave) void spmm_groupshare(
                     // the entry's member byte: tested in place
                     const uint32_t word = uu < 4 ? step_lo : step_hi;
                     constexpr int sb = 8 * (uu & 3);
-                    if (word & (0xffu << sb)) {
+                    if ((word & (0xffu << sb)) && !REMAP_DIAG_ON(p, 8)) {
                         // reads issued behind this entry's: those of the
                         // entries uu + 1 ... min(uu + AHEAD, UNR - 1)
                         constexpr int behind =
