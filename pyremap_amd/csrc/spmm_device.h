@@ -282,13 +282,47 @@ __device__ __forceinline__ bool div_fast_numerator(double a)
     return h - kDivLoHi < kDivSpanHi;
 }
 
+// The stores of one row whose index is wave-uniform: the row's base comes
+// from SGPRs (one scalar multiply), a lane adds its offset with ONE 64-bit
+// add per tile -- written `p.Y[i * ldy + yoff]` hipcc moved i into a VGPR and
+// spent a v_mad_u64_u32, an add and a shift-add per tile and row.  `all_on`:
+// every lane of every tile holds a column (the caller saw it once per wave):
+// no per-row exec masks.
+template <int VEC, int TILES>
+__device__ __forceinline__ void store_row_uniform(
+    const KParams &p, int64_t i, bool okrow, bool all_on,
+    const bool (&act)[TILES], const int64_t (&yoff)[TILES],
+    const double (&y)[TILES][VEC])
+{
+    double *const yrow = p.Y + i * p.ldy;
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+        if (!all_on && !act[t])
+            continue;
+        if (REMAP_DIAG_SKIP_STORE(p, y[t][0]))
+            continue;
+        store_y<VEC>(yrow + yoff[t], y[t]);
+#ifndef REMAP_STAMPS
+        if (p.mask_out) {
+            uint8_t *const mrow = p.mask_out + i * p.ldy;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v)
+                mrow[yoff[t] + v] = okrow ? 0 : 1;
+        }
+#endif
+    }
+}
+
 // One row divided by a WAVE-UNIFORM number (frac_b; the per-row normaliser of
 // spmm_groupmask): `okrow` says whether the row is kept (else NaN, masked).
+// Three ways out, each with its own stores (merged behind one store site the
+// four result registers of every way were copied twice: 8 v_mov_b64 per row
+// of an epilogue of ~50 instructions).
 template <int VEC, int TILES>
 __device__ __forceinline__ void finish_row_uniform(
-    const KParams &p, int64_t i, double fb_in, bool okrow_in,
+    const KParams &p, int64_t i_in, double fb_in, bool okrow_in,
     const bool (&act)[TILES], const int64_t (&yoff)[TILES],
-    const double (&acc)[TILES][VEC])
+    const double (&acc)[TILES][VEC], bool all_on = false)
 {
     // fb is wave-uniform (every caller: one row per wave): scalar
     // branches, no selects -- left to itself hipcc computed the
@@ -298,34 +332,35 @@ __device__ __forceinline__ void finish_row_uniform(
         __builtin_amdgcn_readfirstlane(__double2hiint(fb_in)),
         __builtin_amdgcn_readfirstlane(__double2loint(fb_in)));
     const bool okrow = __builtin_amdgcn_readfirstlane(okrow_in ? 1 : 0) != 0;
+    const int64_t i =
+        (static_cast<int64_t>(__builtin_amdgcn_readfirstlane(
+             static_cast<int32_t>(i_in >> 32)))
+         << 32) |
+        static_cast<uint32_t>(
+            __builtin_amdgcn_readfirstlane(static_cast<int32_t>(i_in)));
     // every lane computes (idle lanes of a K tail hold sums of columns
-    // that exist: nothing traps); ONE store site behind the three paths
-    double y[TILES][VEC];
-    if (!okrow) {
-#pragma unroll
-        for (int t = 0; t < TILES; ++t)
-#pragma unroll
-            for (int v = 0; v < VEC; ++v)
-                y[t][v] = __builtin_nan("");
-    } else if (fb == 1.0) {
+    // that exist: nothing traps)
+    if (okrow && fb == 1.0) {
         // x / 1.0 == x exactly: bilinear maps skip the division
-#pragma unroll
-        for (int t = 0; t < TILES; ++t)
-#pragma unroll
-            for (int v = 0; v < VEC; ++v)
-                y[t][v] = acc[t][v];
-    } else {
+        store_row_uniform<VEC, TILES>(p, i, true, all_on, act, yoff, acc);
+        return;
+    }
+    if (okrow) {
         bool fast = div_fast_divisor(fb);
         if (fast) {
-            bool in = true;
+            // one compare into an SGPR pair per element, ORed on the scalar
+            // side (as `in = in && ...` hipcc nested an exec mask per
+            // element, as `in & ...` it packed the flags into bytes)
+            uint64_t out = 0;
 #pragma unroll
             for (int t = 0; t < TILES; ++t)
 #pragma unroll
                 for (int v = 0; v < VEC; ++v)
-                    in = in && div_fast_numerator(acc[t][v]);
-            fast = __ballot(!in) == 0ull;
+                    out |= __ballot(!div_fast_numerator(acc[t][v]));
+            fast = out == 0ull;
         }
         if (fast) {
+            double y[TILES][VEC];
             double r = __builtin_amdgcn_rcp(fb);
             double e = __builtin_fma(-fb, r, 1.0);
             r = __builtin_fma(r, e, r);
@@ -339,28 +374,23 @@ __device__ __forceinline__ void finish_row_uniform(
                     const double rem = __builtin_fma(-fb, q0, acc[t][v]);
                     y[t][v] = __builtin_fma(rem, r, q0);
                 }
-        } else {
-            // (rare: one division after the other -- interleaved by the
-            // scheduler, four 11-instruction sequences hold enough
-            // temporaries to spill in the kernels that run at the register
-            // limit of three waves per SIMD)
-#pragma unroll
-            for (int t = 0; t < TILES; ++t)
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) {
-                    y[t][v] = acc[t][v] / fb;
-                    asm volatile("" : "+v"(y[t][v]));
-                }
+            store_row_uniform<VEC, TILES>(p, i, true, all_on, act, yoff, y);
+            return;
         }
     }
-    bool ok[VEC];
-#pragma unroll
-    for (int v = 0; v < VEC; ++v)
-        ok[v] = okrow;
+    // rare: a row under the mask (NaN), or operands the fast division does
+    // not cover (one division after the other -- interleaved by the
+    // scheduler, four 11-instruction sequences hold enough temporaries to
+    // spill in the kernels that run at the register limit)
+    double y[TILES][VEC];
 #pragma unroll
     for (int t = 0; t < TILES; ++t)
-        if (act[t])
-            store_row_tile<VEC>(p, i * p.ldy + yoff[t], y[t], ok);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            y[t][v] = okrow ? acc[t][v] / fb : __builtin_nan("");
+            asm volatile("" : "+v"(y[t][v]));
+        }
+    store_row_uniform<VEC, TILES>(p, i, okrow, all_on, act, yoff, y);
 }
 
 // One row of the masked mode whose N elements per lane share ONE normaliser
@@ -379,12 +409,12 @@ __device__ __forceinline__ void finish_row_lane_den(
     const int64_t (&yoff)[N], const double (&acc)[N][1])
 {
     const bool ok = den > p.thr;
-    bool in = div_fast_divisor(den);
+    uint64_t out = __ballot(ok && !div_fast_divisor(den));
 #pragma unroll
     for (int e = 0; e < N; ++e)
-        in = in && div_fast_numerator(acc[e][0]);
+        out |= __ballot(ok && !div_fast_numerator(acc[e][0]));
     double y[N];
-    if (__ballot(ok && !in) == 0ull) {
+    if (out == 0ull) {
         double r = __builtin_amdgcn_rcp(den);
         double e1 = __builtin_fma(-den, r, 1.0);
         r = __builtin_fma(r, e1, r);
