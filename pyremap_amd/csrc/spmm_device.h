@@ -393,6 +393,89 @@ __device__ __forceinline__ void finish_row_uniform(
     store_row_uniform<VEC, TILES>(p, i, okrow, all_on, act, yoff, y);
 }
 
+// finish_row_uniform as it was first written -- ONE store site behind the
+// three ways, the guards as nested conditions: spmm_groupmask.h, which sits at
+// the register limit of three waves per SIMD, spills 8 VGPRs with the form
+// above and none with this one.
+template <int VEC, int TILES>
+__device__ __forceinline__ void finish_row_uniform_one_site(
+    const KParams &p, int64_t i, double fb_in, bool okrow_in,
+    const bool (&act)[TILES], const int64_t (&yoff)[TILES],
+    const double (&acc)[TILES][VEC])
+{
+    // fb is wave-uniform (every caller: one row per wave): scalar
+    // branches, no selects -- left to itself hipcc computed the
+    // division, `fb == 1.0 ? acc : quotient` and the NaN fill for every
+    // lane and element and selected afterwards (15 VALU per element)
+    const double fb = __hiloint2double(
+        __builtin_amdgcn_readfirstlane(__double2hiint(fb_in)),
+        __builtin_amdgcn_readfirstlane(__double2loint(fb_in)));
+    const bool okrow = __builtin_amdgcn_readfirstlane(okrow_in ? 1 : 0) != 0;
+    // every lane computes (idle lanes of a K tail hold sums of columns
+    // that exist: nothing traps); ONE store site behind the three paths
+    double y[TILES][VEC];
+    if (!okrow) {
+#pragma unroll
+        for (int t = 0; t < TILES; ++t)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v)
+                y[t][v] = __builtin_nan("");
+    } else if (fb == 1.0) {
+        // x / 1.0 == x exactly: bilinear maps skip the division
+#pragma unroll
+        for (int t = 0; t < TILES; ++t)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v)
+                y[t][v] = acc[t][v];
+    } else {
+        bool fast = div_fast_divisor(fb);
+        if (fast) {
+            bool in = true;
+#pragma unroll
+            for (int t = 0; t < TILES; ++t)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v)
+                    in = in && div_fast_numerator(acc[t][v]);
+            fast = __ballot(!in) == 0ull;
+        }
+        if (fast) {
+            double r = __builtin_amdgcn_rcp(fb);
+            double e = __builtin_fma(-fb, r, 1.0);
+            r = __builtin_fma(r, e, r);
+            e = __builtin_fma(-fb, r, 1.0);
+            r = __builtin_fma(r, e, r);
+#pragma unroll
+            for (int t = 0; t < TILES; ++t)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    const double q0 = acc[t][v] * r;
+                    const double rem = __builtin_fma(-fb, q0, acc[t][v]);
+                    y[t][v] = __builtin_fma(rem, r, q0);
+                }
+        } else {
+            // (rare: one division after the other -- interleaved by the
+            // scheduler, four 11-instruction sequences hold enough
+            // temporaries to spill in the kernels that run at the register
+            // limit of three waves per SIMD)
+#pragma unroll
+            for (int t = 0; t < TILES; ++t)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    y[t][v] = acc[t][v] / fb;
+                    asm volatile("" : "+v"(y[t][v]));
+                }
+        }
+    }
+    bool ok[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v)
+        ok[v] = okrow;
+#pragma unroll
+    for (int t = 0; t < TILES; ++t)
+        if (act[t])
+            store_row_tile<VEC>(p, i * p.ldy + yoff[t], y[t], ok);
+}
+
 // One row of the masked mode whose N elements per lane share ONE normaliser
 // per LANE (spmm_timeshare.h: a lane holds N time slices of its level):
 // `ok = den > thr`, `y = ok ? acc / den : NaN` (remap_numpy.py:266, 277-278).

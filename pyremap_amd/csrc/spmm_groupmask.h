@@ -308,7 +308,7 @@ __attribute__((amdgpu_waves_per_eu(3, 8))) void spmm_groupmask(
 #pragma unroll
                             for (int v = 0; v < VEC; ++v)
                                 acc1[0][v] = acc[m][t][v];
-                            finish_row_uniform<VEC, 1>(
+                            finish_row_uniform_one_site<VEC, 1>(
                                 p, rid[m], den_u[m], den_u[m] > p.thr, act1,
                                 yoff1, acc1);
                         }
