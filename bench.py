@@ -1123,7 +1123,7 @@ def kernel_of(e):
         family = ('spmm_timeshare' if sched.get('shared_by') else
                   'spmm_grouptime') + ' (REMAP_FLAG_BATCH_MASKS)'
     elif family == 'spmm_rowgroup' and rich and sched.get('shared_by') and \
-            e.get('mode') != 'masked' and e['K'] > 128 and \
+            e.get('mode') != 'masked' and e['K'] >= 104 and \
             e.get('dtype', 'f64') == 'f64':
         family = 'spmm_groupshare'
 

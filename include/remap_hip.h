@@ -415,8 +415,9 @@ typedef struct remap_apply_args {
      * entries its own rows own from there (csrc/spmm_groupshare.h); a row
      * still adds its entries in ascending column order, so results are
      * unchanged.  Used by family 10 on float64 fields with even strides:
-     * with tune[5] = 32 in the frac_b and raw modes on more than 128
-     * columns, with REMAP_FLAG_BATCH_MASKS (csrc/spmm_timeshare.h) or, on
+     * with tune[5] = 32 in the frac_b and raw modes on at least 104
+     * columns (one K tile per wave up to 128, two beyond), with
+     * REMAP_FLAG_BATCH_MASKS (csrc/spmm_timeshare.h) or, on
      * more than 128 columns, REMAP_FLAG_CELL_MASKS (csrc/spmm_cellshare.h)
      * in the masked mode (share_waves = 4: the shape the kernels are built
      * in; remap_share_build also makes the lists of 2 groups).             */

@@ -960,6 +960,13 @@ bool patch_serves(const remap_apply_args *a, const Call &c)
             (c.K >= 16 && a->n_patches >= 8192));
 }
 
+// Fewest columns the shared form of the frac_b and raw modes takes: with one
+// K tile per wave it passes the 8-row groups between 100 and 112 columns
+// (config 5's mapping, ms per launch, groups / shared: K = 96 2.48 / 2.54,
+// 100 2.62 / 2.59, 112 2.77 / 2.65, 120 2.97 / 2.73, 128 3.12 / 2.80; 64:
+// 2.29 / 2.45 -- half the lanes idle).
+constexpr int64_t kShareMinK = 104;
+
 // The forms of family 10 that address X with a flat 64-bit address per lane
 // (LDS-DMA: spmm_groupshare.h, spmm_timeshare.h, spmm_cellshare.h) also serve
 // fields whose batches lie further apart than 32-bit offsets reach -- (Time,
@@ -978,7 +985,7 @@ bool wide_share(const remap_apply_args *a, const Call &c)
         return a->share_waves == 4 && a->n_batch >= 3 &&
                (a->flags & (REMAP_FLAG_BATCH_MASKS | REMAP_FLAG_CELL_MASKS)) &&
                (a->tune[5] == 0 || a->tune[5] == 32);
-    return a->share_waves == 4 && a->tune[5] == 32 && c.K > 128;
+    return a->share_waves == 4 && a->tune[5] == 32 && c.K >= kShareMinK;
 }
 
 // REMAP_FLAG_TUNE_HINT: can the preferred family serve this call?
@@ -1133,17 +1140,19 @@ int run_rowgroup(const remap_apply_args *a, const Call &c, KParams p,
     }
     // tune[5] = 32: the shared form (spmm_groupshare.h) -- W waves, one
     // union through an LDS ring; float64 fields in whole 16-byte pieces,
-    // more than 128 columns.  A call it cannot serve takes the 8-row groups
+    // at least 104 columns (kShareMinK).  A call it cannot serve takes the 8-row groups
     // of the same schedule (a preference under REMAP_FLAG_TUNE_HINT, an
     // error otherwise).
     if (a->tune[5] == 32) {
         const bool can = c.share_ok && a->share_waves == 4 && c.dma16 &&
-                         c.K > 128 && a->mode != REMAP_MODE_MASKED &&
+                         c.K >= kShareMinK &&
+                         a->mode != REMAP_MODE_MASKED &&
                          a->x_src_fold == 0 && a->x_row_stride >= 0 &&
                          a->x_row_stride < (int64_t(1) << 29);
         if (can) {
-            // K tiles per wave: 2 (256 columns per workgroup and step)
-            const int tiles = a->tune[2] == 1 ? 1 : 2;
+            // K tiles per wave: 2 (256 columns per workgroup and step); at
+            // most 128 columns -- ONE 3-D field of 104 ... 128 levels --: 1
+            const int tiles = (a->tune[2] == 1 || c.K <= 128) ? 1 : 2;
             p.rows_per_wave = 1;
             const int64_t k_chunks =
                 shape_tiles(p, a, c.K, kWave * 2, tiles);
@@ -1162,7 +1171,7 @@ int run_rowgroup(const remap_apply_args *a, const Call &c, KParams p,
             return fail(REMAP_ERR_UNSUPPORTED,
                         "remap_apply_f64: the shared form (tune[5] = 32) "
                         "serves the frac_b and raw modes on float64 fields "
-                        "of more than 128 even-strided columns, on a plan "
+                        "of at least 104 even-strided columns, on a plan "
                         "with share_* lists of 4 groups");
     }
     // REMAP_FLAG_BATCH_MASKS: the masked mode of a field of several batches

@@ -107,6 +107,30 @@ def test_shared_form_bitwise(dev, K):
                            f'share K={K} {tag} tune={tune} mode={mode}')
 
 
+@pytest.mark.parametrize('K', [104, 112, 128])
+def test_shared_form_one_field_of_many_levels(dev, K):
+    """At most 128 columns -- ONE 3-D field of 104 ... 128 levels: the shared
+    form with one K tile per wave, whatever tune[2] says; below 104 columns
+    the call is declined (the 8-row groups are faster there) or, under
+    REMAP_FLAG_TUNE_HINT, handed to them."""
+    from pyremap_amd import engine
+    m, mm, plan, csr = _problem(dev, 4)
+    fields = _fields(m.n_a, K, K + 1)
+    for tune in ([10, 0, 2, 0, 3, 32], [10, 0, 1, 0, 2, 32]):
+        for mode in (engine.MODE_FRACB, engine.MODE_RAW):
+            for tag, x in fields[:1] + fields[2:3]:
+                _check(plan, csr, mm['frac_b'], x, dev, mode, 0.0, tune,
+                       f'one tile K={K} {tag} tune={tune} mode={mode}')
+    x = fields[0][1][:, :100].copy()
+    xd = torch.from_numpy(x).to(dev)
+    with pytest.raises(engine.EngineError, match='shared form'):
+        engine.remap_tensor(plan, None, xd, [0], engine.MODE_FRACB,
+                            tune=[10, 0, 2, 0, 3, 32])
+    _check(plan, csr, mm['frac_b'], x, dev, engine.MODE_FRACB, 0.0,
+           [10, 0, 2, 0, 3, 32], 'K=100 under the hint',
+           flags=engine.FLAG_TUNE_HINT)
+
+
 def test_shared_form_long_lists_one_dimensional_and_fma(dev):
     """Lists of more than 128 union entries (a second segment of lane-held
     columns and masks), a 1-D destination (supergroups of consecutive rows,
