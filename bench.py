@@ -1123,9 +1123,10 @@ def kernel_of(e):
         family = ('spmm_timeshare' if sched.get('shared_by') else
                   'spmm_grouptime') + ' (REMAP_FLAG_BATCH_MASKS)'
     elif family == 'spmm_rowgroup' and rich and sched.get('shared_by') and \
-            e.get('mode') != 'masked' and e['K'] >= 104 and \
+            e.get('mode') != 'masked' and \
+            (e['K'] >= 104 or 34 <= e['K'] <= 64) and \
             e.get('dtype', 'f64') == 'f64':
-        family = 'spmm_groupshare'
+        family = 'spmm_groupshare' if e['K'] >= 104 else 'spmm_narrowshare'
 
     if sched.get('long_rows'):
         return family + ' + spmm_patchcell (long rows apart)'

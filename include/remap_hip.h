@@ -416,7 +416,8 @@ typedef struct remap_apply_args {
      * still adds its entries in ascending column order, so results are
      * unchanged.  Used by family 10 on float64 fields with even strides:
      * with tune[5] = 32 in the frac_b and raw modes on at least 104
-     * columns (one K tile per wave up to 128, two beyond), with
+     * columns (one K tile per wave up to 128, two beyond) and on 34 ... 64
+     * columns (a lane per column: csrc/spmm_narrowshare.h), with
      * REMAP_FLAG_BATCH_MASKS (csrc/spmm_timeshare.h) or, on
      * more than 128 columns, REMAP_FLAG_CELL_MASKS (csrc/spmm_cellshare.h)
      * in the masked mode (share_waves = 4: the shape the kernels are built

@@ -68,6 +68,7 @@ namespace {
 #include "spmm_grouptime.h"
 #include "spmm_timeshare.h"
 #include "spmm_cellshare.h"
+#include "spmm_narrowshare.h"
 #include "spmm_rowlane.h"
 #include "spmm_rowcell.h"
 #include "spmm_patchcell.h"
@@ -715,6 +716,30 @@ int launch_groupshare(const remap_apply_args *a, const KParams &p, int tiles,
     return REMAP_OK;
 }
 
+// the shared form for at most 64 columns (spmm_narrowshare.h)
+int launch_narrowshare(const remap_apply_args *a, const KParams &p, bool fma,
+                       int64_t grid, hipStream_t stream)
+{
+    share_fn fn =
+        a->mode == REMAP_MODE_RAW
+            ? (fma ? spmm_narrowshare<REMAP_MODE_RAW, true, 2>
+                   : spmm_narrowshare<REMAP_MODE_RAW, false, 2>)
+            : (fma ? spmm_narrowshare<REMAP_MODE_FRACB, true, 2>
+                   : spmm_narrowshare<REMAP_MODE_FRACB, false, 2>);
+    // the ring: two buffers of 8 entries x 512 B; 2 x 4 slots of a step's
+    // weights; slack
+    uint32_t lds_bytes = 2u * (8u * 512u + 4u * 512u) + 512u;
+    REMAP_HIP_CHECK(diag_lds_throttle(a, reinterpret_cast<const void *>(fn),
+                                      lds_bytes));
+    hipLaunchKernelGGL(fn, dim3(static_cast<uint32_t>(grid)),
+                       dim3(kWave * 4), lds_bytes, stream, p, a->flags,
+                       a->group_meta, a->group_w, a->group_rid, a->group_frac,
+                       a->share_meta, a->share_col, a->share_mask,
+                       static_cast<const double *>(a->X));
+    REMAP_HIP_CHECK(hipGetLastError());
+    return REMAP_OK;
+}
+
 bool aligned(const void *p, size_t a)
 {
     return (reinterpret_cast<uintptr_t>(p) % a) == 0;
@@ -966,6 +991,8 @@ bool patch_serves(const remap_apply_args *a, const Call &c)
 // 100 2.62 / 2.59, 112 2.77 / 2.65, 120 2.97 / 2.73, 128 3.12 / 2.80; 64:
 // 2.29 / 2.45 -- half the lanes idle).
 constexpr int64_t kShareMinK = 104;
+// ... and the fewest the narrow form (one column per lane, at most 64) takes
+constexpr int64_t kNarrowMinK = 34;
 
 // The forms of family 10 that address X with a flat 64-bit address per lane
 // (LDS-DMA: spmm_groupshare.h, spmm_timeshare.h, spmm_cellshare.h) also serve
@@ -1143,6 +1170,25 @@ int run_rowgroup(const remap_apply_args *a, const Call &c, KParams p,
     // at least 104 columns (kShareMinK).  A call it cannot serve takes the 8-row groups
     // of the same schedule (a preference under REMAP_FLAG_TUNE_HINT, an
     // error otherwise).
+    if (a->tune[5] == 32 && c.K <= kWave && c.K >= kNarrowMinK &&
+        c.share_ok && a->share_waves == 4 && c.dma16 &&
+        a->mode != REMAP_MODE_MASKED && a->x_src_fold == 0 &&
+        a->x_row_stride >= 0 && a->x_row_stride < (int64_t(1) << 29)) {
+        // at most 64 columns: a lane per column, two union entries per DMA
+        // instruction (spmm_narrowshare.h)
+        const int64_t k_chunks = shape_tiles(p, a, c.K, kWave, 1);
+        if (p.bpc == 0) {
+            p.rows_per_wave = 1;
+            int64_t grid;
+            const int rc = shape_grid(p, ceil_div(a->n_groups, (int64_t)4),
+                                      k_chunks, a->tune[4] != 1, grid);
+            if (rc != REMAP_OK)
+                return rc;
+            if (a->tune[4] == 3)
+                p.xcd_map |= 2;
+            return launch_narrowshare(a, p, c.fma, grid, stream);
+        }
+    }
     if (a->tune[5] == 32) {
         const bool can = c.share_ok && a->share_waves == 4 && c.dma16 &&
                          c.K >= kShareMinK &&

@@ -131,6 +131,43 @@ def test_shared_form_one_field_of_many_levels(dev, K):
            flags=engine.FLAG_TUNE_HINT)
 
 
+@pytest.mark.parametrize('K', [34, 48, 60, 64])
+def test_narrow_shared_form_bitwise(dev, K):
+    """At most 64 columns -- ONE 3-D field of up to 64 levels: a lane per
+    column, two union entries per LDS-DMA instruction
+    (csrc/spmm_narrowshare.h); the frac_b and raw modes, the work-list
+    orders, NaNs propagating as the reference lets them; as (n, K) and as
+    batches of short level runs read in place."""
+    from oracle import oracle
+    from pyremap_amd import engine
+    m, mm, plan, csr = _problem(dev, 4)
+    fields = _fields(m.n_a, K, K + 2)
+    for order in (3, 2, 1):
+        tune = [10, 0, 2, 0, order, 32]
+        for mode in (engine.MODE_FRACB, engine.MODE_RAW):
+            for tag, x in fields[:1] + fields[2:3]:
+                _check(plan, csr, mm['frac_b'], x, dev, mode, 0.0, tune,
+                       f'narrow K={K} {tag} tune={tune} mode={mode}')
+    # (T, n, L) in place: K = T * L columns in runs of L
+    # (runs of 16 levels: flat tiles, the narrow form; of 18: batch-aligned
+    # tiles, which it declines -- handed to the 8-row groups under the hint)
+    for T, L in ((4, 16), (3, 16), (2, 18)):
+        rng = np.random.default_rng(K + T)
+        f = rng.standard_normal((T, m.n_a, L))
+        flat = np.ascontiguousarray(f.transpose(1, 0, 2)).reshape(m.n_a,
+                                                                  T * L)
+        ref, ref_mask = oracle.remap_flat(csr, mm['frac_b'], flat, False,
+                                          0.0)
+        ref = ref.copy()
+        ref[ref_mask] = np.nan
+        y = engine.remap_tensor(plan, None, torch.from_numpy(f).to(dev), [1],
+                                engine.MODE_FRACB, tune=[10, 0, 2, 0, 3, 32],
+                                flags=engine.FLAG_TUNE_HINT if L == 18 else 0)
+        assert_bitwise(y.cpu().numpy(),
+                       ref.reshape(m.n_b, T, L).transpose(1, 0, 2),
+                       f'narrow (T={T}, n, L={L})')
+
+
 def test_shared_form_long_lists_one_dimensional_and_fma(dev):
     """Lists of more than 128 union entries (a second segment of lane-held
     columns and masks), a 1-D destination (supergroups of consecutive rows,
