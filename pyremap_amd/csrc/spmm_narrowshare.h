@@ -15,7 +15,11 @@
 // A step of 8 entries is ONE global_load_lds_dwordx4 per wave.  Everything
 // else -- the lanes holding the list's columns and member bytes, the weights
 // through a wave-private LDS slot, the member chain, the sums in ascending
-// column order -- is spmm_groupshare's: the same bits.
+// column order -- is spmm_groupshare's: the same bits.  (Instantiated for the
+// frac_b and raw modes.  The masked mode with its per-lane normalisers was
+// measured on config 5's mapping and is not: K = 64 2.21 ms against 2.19 of
+// the 8-row groups, 34: 2.25 against 2.13 -- profiles/r06_analysis/
+// config5_share.md section 9.)
 // ---------------------------------------------------------------------------
 
 template <int OFF>
